@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the student poser hot path (BASELINE.json configs[1]): lambda_00 distilled student,
+batch=1 real-time stream of random 45-dim poses on 512x512 RGBA, through the drop-in Poser API
+(tha4_amd.poser.modes.mode_14 -> include/tha4_hip.h -> gfx950 kernels).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one Poser.pose() call = one frame (batch 1), back-to-back on the rank's current stream,
+image and poses resident in HBM before the timed region.  With N>1 every rank poses K frames of its
+own (weak scaling, frames are independent) and finished frames are gathered to rank 0 in chunks
+over RCCL on a side stream (the only exchange the path has).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import tha4_amd  # noqa: E402,F401
+from tha4_amd.poser.modes import mode_14  # noqa: E402
+from tha4_amd.sharding import FrameShardedStream  # noqa: E402
+from tha4_amd.weights import split_flat_weights  # noqa: E402
+
+# Algorithmic work of the reference's student forward pass as written (SURVEY.md §8d, 2*MAC),
+# per 512x512 frame and per kernel of this implementation.
+GFLOP_FRAME = 37.885
+GFLOP_KERNEL = {"face": 3.947, "level0": 6.924, "level1": 11.726, "level2": 15.288}
+# What the kernels actually execute after pose folding + commuting the x2 upsample with the next
+# level's first layer: stated separately, never used for `roofline.achieved`.
+GFLOP_EXECUTED_FRAME = 27.46
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+KERNEL_NAMES = ["posebias", "face", "level0", "level1", "level2"]
+
+POSE_LO = np.array([0.0] * 37 + [-1.0] * 7 + [0.0], dtype=np.float32)
+POSE_HI = np.ones(45, dtype=np.float32)
+
+
+def make_poses(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, 45, generator=g).numpy()
+    return torch.from_numpy((POSE_LO + (POSE_HI - POSE_LO) * u).astype(np.float32))
+
+
+def load_fixture():
+    g = os.path.join(ROOT, "tests", "golden")
+    w = dict(np.load(os.path.join(g, "student_lambda_00_weights.npz")))
+    io = np.load(os.path.join(g, "student_lambda_00_io.npz"))
+    return w, io["image_f32"]
+
+
+def cpu_baseline(w, image, poses, budget_s):
+    """The CPU path timed beside the GPU path: the oracle's torch-functional restatement of the
+    reference (same ATen ops), fp32, all host cores.  Bounded sample (~budget_s of CPU work)."""
+    from oracle import student_oracle as so
+    so.student_forward_torch(w, image, poses[0].numpy(), "float32")      # warm-up (thread pool, allocator)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        so.student_forward_torch(w, image, poses[n % poses.shape[0]].numpy(), "float32")
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 64:
+            break
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frames of the same lambda_00 stream, oracle.student_forward_torch fp32 ({dt:.1f} s)",
+            "ms_per_frame": round(1e3 * dt / n, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--gather-chunk", type=int, default=32, help="frames per RCCL gather (N>1)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gather of finished frames")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--profile-frames", type=int, default=100, help="frames for the per-kernel HIP-event pass")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w, image_np = load_fixture()
+    face_sd, body_sd = split_flat_weights(w)
+    poser = mode_14.create_poser_from_state_dicts(dev, face_sd, body_sd)
+    image = torch.from_numpy(image_np).to(dev)
+    K, W = args.steps, args.warmup
+    poses_cpu = make_poses(K + W, seed=1234 + rank)
+    poses = poses_cpu.to(dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for i in range(W):
+            out = poser.pose(image, poses[i])
+        if world > 1 and not args.no_gather:
+            chunk = args.gather_chunk
+
+            def frame_fn(lo, hi):   # global frame ids of this rank start at rank*K
+                base = rank * K
+                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+                for i in range(lo, hi):
+                    blk[i - lo].copy_(poser.pose(image, poses[W + i - base])[0])
+                return blk
+
+            stream = FrameShardedStream(frame_fn, total=K * world, frame_shape=(4, 512, 512), dtype=torch.float32,
+                                        device=dev, chunk=chunk, gather=True)
+            barrier()
+            t0 = time.perf_counter()
+            gathered = stream.run()
+            barrier()
+            t1 = time.perf_counter()
+            del gathered
+        else:
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(K):
+                out = poser.pose(image, poses[W + i])
+            barrier()
+            t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        total_frames = K * world
+        fps = total_frames / elapsed
+        # per-kernel durations from HIP events recorded on the launch stream inside the C ABI
+        poser.set_timing(True)
+        acc = np.zeros(len(KERNEL_NAMES))
+        whole = 0.0
+        nprof = max(1, args.profile_frames)
+        with torch.no_grad():
+            for i in range(nprof):
+                poser.pose(image, poses[W + (i % K)])
+                for k in range(len(KERNEL_NAMES)):
+                    acc[k] += poser.last_kernel_ms(k)
+                whole += poser.last_kernel_ms(-1)
+        poser.set_timing(False)
+        kernel_ms = {n: float(acc[k] / nprof) for k, n in enumerate(KERNEL_NAMES)}
+        dom = max(GFLOP_KERNEL, key=lambda n: kernel_ms[n])
+        achieved = GFLOP_KERNEL[dom] / kernel_ms[dom]            # GFLOP / ms = TFLOP/s
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                    "frame_event_ms": round(whole / nprof, 4),
+                    "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
+                    "whole_frame_frac": round(fps / world * GFLOP_FRAME / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "algorithmic_gflop_per_frame": GFLOP_FRAME, "executed_gflop_per_frame": GFLOP_EXECUTED_FRAME}
+        cpu = cpu_baseline(w, image_np, poses_cpu, args.cpu_seconds) if args.cpu_seconds > 0 else None
+        result = {
+            "metric": "frames/sec (whole job) on 512x512 RGBA + 45-dim pose, distilled student",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic pose stream (seed 1234+rank, pose_parameters ranges); lambda_00 student weights + image fixture (tests/golden)",
+            "config": {"workload": "configs[1]: lambda_00 distilled student, batch=1 real-time stream, 512x512 RGBA, one Poser.pose() per frame",
+                       "frames_per_gpu": K, "batch": 1, "parallelism": f"frame-parallel x{world}",
+                       "gather": bool(world > 1 and not args.no_gather)},
+            "per_gpu_fps": round(fps / world, 2),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/* tha4_hip.h - C ABI of the MI355X-native THA4 poser hot path (libtha4_hip.so).
+ *
+ * The reference (pkhungurn/talking-head-anime-4-demo) has no FFI: its plugin boundary is the Python
+ * ABC `Poser` (src/tha4/poser/poser.py:132-162) implemented by `GeneralPoser02`
+ * (src/tha4/poser/general_poser_02.py:10-98) and built by `mode_14.create_poser`
+ * (src/tha4/poser/modes/mode_14.py:134-162).  This header is the native boundary underneath that
+ * surface: each entry point names the reference call it replaces.  The Python mirror of the
+ * reference interface (tha4_amd.poser.modes.mode_14) binds these symbols with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only (no torch / HIP types in signatures; a stream is an
+ * opaque `void*` = hipStream_t).  All `*_dev` pointers are device pointers on the handle's GPU.
+ * Every function returns 0 on success or a negative tha4_status; nothing throws across the ABI.
+ * `tha4_*_pose` never allocates, never synchronises and enqueues all work on the given stream
+ * (callers bracket it with stream events exactly like full_manual_poser.py:388-398 does).
+ */
+#ifndef THA4_HIP_H
+#define THA4_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THA4_ABI_VERSION 1
+
+typedef enum tha4_status {
+  THA4_OK = 0,
+  THA4_ERR_INVALID_ARGUMENT = -1,  /* null pointer, bad batch, wrong architecture dims            */
+  THA4_ERR_HIP = -2,               /* a HIP runtime call failed (message in tha4_last_error())    */
+  THA4_ERR_NO_DEVICE = -3,         /* no gfx950 device / device index out of range                */
+  THA4_ERR_BATCH_TOO_LARGE = -4    /* batch > max_batch given at create                           */
+} tha4_status;
+
+/* One Conv2d(kernel_size=1) layer as stored in the reference state_dict
+ * (src/tha4/nn/siren/vanilla/siren.py:23-29): weight [out_ch][in_ch] row-major fp32 (the [O,I,1,1]
+ * tensor), bias [out_ch].  Host pointers, only read during tha4_student_create. */
+typedef struct tha4_linear {
+  const float* weight;
+  const float* bias;
+  int32_t out_ch;
+  int32_t in_ch;
+} tha4_linear;
+
+/* The two student modules of mode_14 (src/tha4/poser/modes/mode_14.py:93-131), in state_dict order
+ * (SURVEY.md Appendix B):
+ *   face_sine[i]    <- face_morpher.pt  siren.sine_layers.{i}.linear     41->128, 7 x 128->128
+ *   face_last       <- face_morpher.pt  siren.last_linear                128->4
+ *   body_sine[l][j] <- body_morpher.pt  siren_layers.{l}.{j}.linear      47->360->360->180,
+ *                                                                        227->180->180->90, 137->90->90->90
+ *   body_last       <- body_morpher.pt  last_linear                      90->7 (grid dx,dy | alpha | colour RGBA) */
+typedef struct tha4_student_weights {
+  tha4_linear face_sine[8];
+  tha4_linear face_last;
+  tha4_linear body_sine[3][3];
+  tha4_linear body_last;
+} tha4_student_weights;
+
+/* Optional fp32 affine_grid axes (src/tha4/nn/siren/morpher/siren_morpher_03.py:92-99).  The exact
+ * values are the dyadic (2j+1)/S-1; ATen's fp32 linspace is off by one ulp in many entries and SIREN
+ * amplifies that to ~1e-4 in the image, so a caller that wants to track a particular PyTorch build
+ * bit-closely passes the axes that build produces.  Any pointer may be NULL (exact values used). */
+typedef struct tha4_position_axes {
+  const float* axis128; /* [128] */
+  const float* axis256; /* [256] */
+  const float* axis512; /* [512] */
+} tha4_position_axes;
+
+/* Optional extra outputs of SirenMorpher03.forward / TwoStepPoserComputationProtocol
+ * (src/tha4/nn/siren/morpher/siren_morpher_03.py:133-139, src/tha4/poser/modes/mode_14.py:85-88).
+ * Device pointers, each may be NULL.  Output index in the reference list is given in brackets. */
+typedef struct tha4_student_aux {
+  float* alpha_dev;        /* [1] [B,1,512,512] raw alpha (no sigmoid)      */
+  float* color_change_dev; /* [2] [B,4,512,512]                               */
+  float* warped_dev;       /* [3] [B,4,512,512] grid_sample of the input     */
+  float* grid_change_dev;  /* [4] [B,2,512,512] normalised offsets (x, y)    */
+  float* face_dev;         /* [5] [B,4,128,128] face morpher output          */
+} tha4_student_aux;
+
+typedef struct tha4_student tha4_student; /* opaque */
+
+/* ABI version of the loaded library (== THA4_ABI_VERSION of the header it was built from). */
+int tha4_abi_version(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* tha4_last_error(void);
+
+/* Replaces: mode_14.load_face_morpher / load_body_morpher + GeneralPoser02.get_modules
+ * (mode_14.py:93-131, general_poser_02.py:41-49): validates the architecture, packs the weights into
+ * the MFMA-fragment-linear HBM image, uploads them to `device` and sizes the workspace for
+ * `max_batch` frames.  `axes` may be NULL. */
+int tha4_student_create(const tha4_student_weights* weights, const tha4_position_axes* axes,
+                        int device, int max_batch, tha4_student** out);
+
+/* Replaces: GeneralPoser02.get_posing_outputs -> TwoStepPoserComputationProtocol "all_outputs"
+ * (general_poser_02.py:63-79, mode_14.py:58-90) for a batch of `batch` frames.
+ *   image_dev          fp32 [B,4,512,512] (values in [-1,1], linear RGB premultiplied by alpha)
+ *   image_batch_stride floats between consecutive frames' images; 0 = one image shared by the batch
+ *                      (the reference needs B identical copies for that; 4*512*512 = dense batch)
+ *   pose_dev           fp32 [B,45]
+ *   out_blended_dev    fp32 [B,4,512,512]  output index 0 (the posed frame); must not alias image_dev
+ *   aux                optional outputs 1..5, may be NULL
+ *   stream             hipStream_t to enqueue on (NULL = the null stream) */
+int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_batch_stride,
+                      const float* pose_dev, int batch, float* out_blended_dev,
+                      const tha4_student_aux* aux, void* stream);
+
+/* Replaces: GeneralPoser02.free (general_poser_02.py:84-85).  NULL is a no-op. */
+void tha4_student_destroy(tha4_student* h);
+
+/* Introspection used by bench.py / tests (no reference counterpart). */
+int tha4_student_max_batch(const tha4_student* h);
+int tha4_student_device(const tha4_student* h);
+/* Time (ms) of the most recent tha4_student_pose on this handle measured with HIP events recorded
+ * on the SAME stream the kernels were launched on; enabled with tha4_student_set_timing(h, 1).
+ * Reading it synchronises on the stop event.  kernel: 0 posebias, 1 face, 2 level0, 3 level1,
+ * 4 level2(+warp), -1 whole call. */
+int tha4_student_set_timing(tha4_student* h, int enable);
+int tha4_student_last_ms(tha4_student* h, int kernel, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THA4_HIP_H */

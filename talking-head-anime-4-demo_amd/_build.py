@@ -1,0 +1,39 @@
+"""Build the gfx950 shared library in-tree with hipcc (no JIT cache: the .so must travel with the tree)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB = os.path.join(CSRC, "libtha4_hip.so")
+SOURCES = ["tha4_capi.hip"]
+HEADERS = ["siren_kernels.h", "siren_layout.h", "tha4_platform.h"]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def hipcc_path() -> str:
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found (ROCm toolchain required to build libtha4_hip.so)")
+    return p
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "tha4_hip.h")]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", CSRC, "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB

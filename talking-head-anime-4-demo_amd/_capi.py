@@ -1,0 +1,142 @@
+"""ctypes binding of the C ABI declared in ``include/tha4_hip.h`` (libtha4_hip.so).
+
+This is the only place the Python host side touches native code.  There is NO fallback:
+if the shared library is missing or fails to load, importing a poser raises (the product path
+must fail loudly rather than silently run something else).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtha4_hip.so")
+
+THA4_ABI_VERSION = 1
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class Tha4Linear(C.Structure):
+    _fields_ = [("weight", c_float_p), ("bias", c_float_p), ("out_ch", C.c_int32), ("in_ch", C.c_int32)]
+
+
+class Tha4StudentWeights(C.Structure):
+    _fields_ = [("face_sine", Tha4Linear * 8),
+                ("face_last", Tha4Linear),
+                ("body_sine", (Tha4Linear * 3) * 3),
+                ("body_last", Tha4Linear)]
+
+
+class Tha4PositionAxes(C.Structure):
+    _fields_ = [("axis128", c_float_p), ("axis256", c_float_p), ("axis512", c_float_p)]
+
+
+class Tha4StudentAux(C.Structure):
+    _fields_ = [("alpha_dev", C.c_void_p), ("color_change_dev", C.c_void_p), ("warped_dev", C.c_void_p),
+                ("grid_change_dev", C.c_void_p), ("face_dev", C.c_void_p)]
+
+
+class Tha4Error(RuntimeError):
+    """Raised for every non-zero status coming back over the C ABI (the reference raises
+    RuntimeError / AssertionError from Python for the same conditions)."""
+
+
+def _linear(weight: np.ndarray, bias: np.ndarray, keep: list) -> Tha4Linear:
+    w = np.ascontiguousarray(weight, dtype=np.float32)
+    if w.ndim == 4:                      # Conv2d 1x1 kernel [O,I,1,1]
+        w = w.reshape(w.shape[0], w.shape[1])
+    b = np.ascontiguousarray(bias, dtype=np.float32)
+    if w.ndim != 2 or b.ndim != 1 or b.shape[0] != w.shape[0]:
+        raise Tha4Error(f"malformed linear layer: weight {weight.shape}, bias {bias.shape}")
+    keep.extend([w, b])
+    return Tha4Linear(w.ctypes.data_as(c_float_p), b.ctypes.data_as(c_float_p), w.shape[0], w.shape[1])
+
+
+def build_student_weights(face_sd: Dict[str, np.ndarray], body_sd: Dict[str, np.ndarray]):
+    """Map the two reference state_dicts (SURVEY.md Appendix B key layout) onto the C struct.
+    Returns (struct, keepalive list).  Missing keys raise KeyError like load_state_dict would."""
+    keep: list = []
+    s = Tha4StudentWeights()
+    for i in range(8):
+        s.face_sine[i] = _linear(face_sd[f"siren.sine_layers.{i}.linear.weight"],
+                                 face_sd[f"siren.sine_layers.{i}.linear.bias"], keep)
+    s.face_last = _linear(face_sd["siren.last_linear.weight"], face_sd["siren.last_linear.bias"], keep)
+    for l in range(3):
+        for j in range(3):
+            s.body_sine[l][j] = _linear(body_sd[f"siren_layers.{l}.{j}.linear.weight"],
+                                        body_sd[f"siren_layers.{l}.{j}.linear.bias"], keep)
+    s.body_last = _linear(body_sd["last_linear.weight"], body_sd["last_linear.bias"], keep)
+    return s, keep
+
+
+def build_position_axes(axes: Optional[Dict[int, np.ndarray]]):
+    if not axes:
+        return None, []
+    keep = []
+    s = Tha4PositionAxes()
+    for size, field in ((128, "axis128"), (256, "axis256"), (512, "axis512")):
+        a = axes.get(size)
+        if a is None:
+            continue
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.shape != (size,):
+            raise Tha4Error(f"position axis {size} has shape {a.shape}")
+        keep.append(a)
+        setattr(s, field, a.ctypes.data_as(c_float_p))
+    return s, keep
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libtha4_hip.so and declare every prototype of include/tha4_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("THA4_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise Tha4Error(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(p)
+    lib.tha4_abi_version.restype = C.c_int
+    lib.tha4_last_error.restype = C.c_char_p
+    lib.tha4_student_create.restype = C.c_int
+    lib.tha4_student_create.argtypes = [C.POINTER(Tha4StudentWeights), C.POINTER(Tha4PositionAxes), C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p)]
+    lib.tha4_student_pose.restype = C.c_int
+    lib.tha4_student_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.POINTER(Tha4StudentAux), C.c_void_p]
+    lib.tha4_student_destroy.restype = None
+    lib.tha4_student_destroy.argtypes = [C.c_void_p]
+    lib.tha4_student_max_batch.restype = C.c_int
+    lib.tha4_student_max_batch.argtypes = [C.c_void_p]
+    lib.tha4_student_device.restype = C.c_int
+    lib.tha4_student_device.argtypes = [C.c_void_p]
+    lib.tha4_student_set_timing.restype = C.c_int
+    lib.tha4_student_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.tha4_student_last_ms.restype = C.c_int
+    lib.tha4_student_last_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    v = lib.tha4_abi_version()
+    if v != THA4_ABI_VERSION:
+        raise Tha4Error(f"libtha4_hip.so ABI version {v} != expected {THA4_ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_pose", "tha4_student_destroy",
+    "tha4_student_max_batch", "tha4_student_device", "tha4_student_set_timing", "tha4_student_last_ms",
+]
+
+
+def check(lib: C.CDLL, status: int, what: str) -> None:
+    if status != 0:
+        msg = lib.tha4_last_error()
+        raise Tha4Error(f"{what} failed (status {status}): {msg.decode() if msg else ''}")

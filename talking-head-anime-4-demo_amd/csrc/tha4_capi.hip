@@ -1,0 +1,264 @@
+// C-ABI implementation (include/tha4_hip.h) of the student poser path for MI355X (gfx950).
+// Host side only: weight packing/upload, workspace, and the 5-launch frame schedule.  The kernels
+// live in siren_kernels.h.  No CPU fallback exists: without a gfx950 device create() fails.
+#include "tha4_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "siren_kernels.h"
+
+using namespace tha4;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(THA4_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+constexpr int kNumKernels = 5;
+
+}  // namespace
+
+struct tha4_student {
+  int device = 0;
+  int max_batch = 0;
+  char* blob = nullptr;       // packed parameters, one allocation
+  char* workspace = nullptr;  // pbias | face | z1 | z2
+  StudentDev dev{};           // parameter + workspace pointers filled at create
+  bool timing = false;
+  hipEvent_t ev[kNumKernels + 1] = {};
+  bool ev_valid = false;
+  bool ev_recorded = false;
+};
+
+namespace {
+
+template <class T>
+size_t align_up(T v, size_t a) { return ((size_t)v + a - 1) / a * a; }
+
+struct BlobBuilder {
+  std::vector<char> host;
+  size_t add(const std::vector<float>& v) {
+    size_t at = align_up(host.size(), 256);
+    host.resize(at + v.size() * sizeof(float));
+    std::memcpy(host.data() + at, v.data(), v.size() * sizeof(float));
+    return at;
+  }
+};
+
+StudentWeightsView to_view(const tha4_student_weights* w) {
+  StudentWeightsView v{};
+  auto cv = [](const tha4_linear& l) { return LinearView{l.weight, l.bias, l.out_ch, l.in_ch}; };
+  for (int i = 0; i < 8; ++i) v.face_sine[i] = cv(w->face_sine[i]);
+  v.face_last = cv(w->face_last);
+  for (int l = 0; l < 3; ++l)
+    for (int j = 0; j < 3; ++j) v.body_sine[l][j] = cv(w->body_sine[l][j]);
+  v.body_last = cv(w->body_last);
+  return v;
+}
+
+template <class K>
+hipError_t allow_lds(K kernel, int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tha4_abi_version(void) { return THA4_ABI_VERSION; }
+
+const char* tha4_last_error(void) { return g_last_error.c_str(); }
+
+int tha4_student_create(const tha4_student_weights* weights, const tha4_position_axes* axes, int device,
+                        int max_batch, tha4_student** out) {
+  if (!weights || !out) return fail(THA4_ERR_INVALID_ARGUMENT, "weights/out must not be NULL");
+  *out = nullptr;
+  if (max_batch < 1 || max_batch > 4096) return fail(THA4_ERR_INVALID_ARGUMENT, "max_batch must be in [1, 4096]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(THA4_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(THA4_ERR_NO_DEVICE, "device index out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(THA4_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library only contains gfx950 code");
+
+  StudentPacked p;
+  std::string err = pack_student(to_view(weights), p);
+  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, "not a mode_14 student: " + err);
+
+  std::vector<float> pos128(128), pos256(256), pos512(512);
+  exact_position_axis(128, pos128.data());
+  exact_position_axis(256, pos256.data());
+  exact_position_axis(512, pos512.data());
+  if (axes) {
+    if (axes->axis128) std::memcpy(pos128.data(), axes->axis128, 128 * sizeof(float));
+    if (axes->axis256) std::memcpy(pos256.data(), axes->axis256, 256 * sizeof(float));
+    if (axes->axis512) std::memcpy(pos512.data(), axes->axis512, 512 * sizeof(float));
+  }
+
+  BlobBuilder bb;
+  const size_t o_wf = bb.add(p.w_face), o_w0 = bb.add(p.w_l0), o_w1 = bb.add(p.w_l1), o_w2 = bb.add(p.w_l2);
+  const size_t o_bf = bb.add(p.b_face), o_b0 = bb.add(p.b_l0), o_b1 = bb.add(p.b_l1), o_b2 = bb.add(p.b_l2);
+  const FirstLayerPack* fl[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
+  size_t o_wx[4], o_wy[4], o_b[4], o_wp[4];
+  for (int i = 0; i < 4; ++i) {
+    o_wx[i] = bb.add(fl[i]->wx);
+    o_wy[i] = bb.add(fl[i]->wy);
+    o_b[i] = bb.add(fl[i]->bias);
+    o_wp[i] = bb.add(fl[i]->wpose);
+  }
+  const size_t o_p128 = bb.add(pos128), o_p256 = bb.add(pos256), o_p512 = bb.add(pos512);
+
+  DeviceGuard guard(device);
+  auto* h = new tha4_student();
+  h->device = device;
+  h->max_batch = max_batch;
+  auto cleanup = [&]() {
+    if (h->blob) (void)hipFree(h->blob);
+    if (h->workspace) (void)hipFree(h->workspace);
+    delete h;
+  };
+  hipError_t e = hipMalloc((void**)&h->blob, bb.host.size());
+  if (e == hipSuccess) e = hipMemcpy(h->blob, bb.host.data(), bb.host.size(), hipMemcpyHostToDevice);
+  const size_t B = (size_t)max_batch;
+  const size_t s_pb = align_up(B * kPbStride * sizeof(float), 256);
+  const size_t s_face = align_up(B * 4 * kFaceSize * kFaceSize * sizeof(float), 256);
+  const size_t s_z1 = align_up(B * kNB1 * 128 * 128 * 16 * sizeof(float), 256);
+  const size_t s_z2 = align_up(B * kNB2 * 256 * 256 * 16 * sizeof(float), 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->workspace, s_pb + s_face + s_z1 + s_z2);
+  if (e == hipSuccess) e = allow_lds(face_kernel<cfg::kFacePG, cfg::kFaceCQ>, cfg::kFaceLds);
+  if (e == hipSuccess) e = allow_lds(level0_kernel<cfg::kL0PG, cfg::kL0CQA, cfg::kL0CQB>, cfg::kL0Lds);
+  if (e == hipSuccess) e = allow_lds(level1_kernel<cfg::kL1PG, cfg::kL1CQA, cfg::kL1CQB>, cfg::kL1Lds);
+  if (e == hipSuccess) e = allow_lds(level2_kernel<cfg::kL2PG, cfg::kL2CQ>, cfg::kL2Lds);
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(THA4_ERR_HIP, std::string("tha4_student_create: ") + hipGetErrorString(e));
+  }
+  auto F = [&](size_t off) { return reinterpret_cast<const float*>(h->blob + off); };
+  StudentDev& d = h->dev;
+  d.w_face = F(o_wf); d.w_l0 = F(o_w0); d.w_l1 = F(o_w1); d.w_l2 = F(o_w2);
+  d.b_face = F(o_bf); d.b_l0 = F(o_b0); d.b_l1 = F(o_b1); d.b_l2 = F(o_b2);
+  for (int i = 0; i < 4; ++i) {
+    d.wx[i] = F(o_wx[i]); d.wy[i] = F(o_wy[i]); d.bias1[i] = F(o_b[i]); d.wpose[i] = F(o_wp[i]);
+  }
+  d.pos128 = F(o_p128); d.pos256 = F(o_p256); d.pos512 = F(o_p512);
+  char* ws = h->workspace;
+  d.pbias = reinterpret_cast<float*>(ws); ws += s_pb;
+  d.face = reinterpret_cast<float*>(ws); ws += s_face;
+  d.z1 = reinterpret_cast<float*>(ws); ws += s_z1;
+  d.z2 = reinterpret_cast<float*>(ws);
+  *out = h;
+  return THA4_OK;
+}
+
+int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev,
+                      int batch, float* out_blended_dev, const tha4_student_aux* aux, void* stream) {
+  if (!h || !image_dev || !pose_dev || !out_blended_dev)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "handle/image/pose/out must not be NULL");
+  if (batch < 1) return fail(THA4_ERR_INVALID_ARGUMENT, "batch must be >= 1");
+  if (batch > h->max_batch) return fail(THA4_ERR_BATCH_TOO_LARGE, "batch exceeds max_batch given at create");
+  if (image_batch_stride != 0 && image_batch_stride < 4LL * kImg * kImg)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "image_batch_stride must be 0 (shared) or >= 4*512*512");
+  if ((const void*)image_dev == (const void*)out_blended_dev)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "out_blended_dev must not alias image_dev");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  StudentDev d = h->dev;
+  d.image = image_dev;
+  d.image_stride = image_batch_stride;
+  d.pose = pose_dev;
+  d.out_blended = out_blended_dev;
+  d.out_alpha = aux ? aux->alpha_dev : nullptr;
+  d.out_color = aux ? aux->color_change_dev : nullptr;
+  d.out_warped = aux ? aux->warped_dev : nullptr;
+  d.out_grid = aux ? aux->grid_change_dev : nullptr;
+  if (aux && aux->face_dev) d.face = aux->face_dev;   // face kernel writes output 5 directly; level2 reads it there
+  d.batch = batch;
+
+  const bool t = h->timing && h->ev_valid;
+  if (t) HIP_TRY(hipEventRecord(h->ev[0], s));
+  hipLaunchKernelGGL(posebias_kernel, dim3((kPbStride + kBlock - 1) / kBlock, batch), dim3(kBlock), 0, s, d);
+  if (t) HIP_TRY(hipEventRecord(h->ev[1], s));
+  hipLaunchKernelGGL((face_kernel<cfg::kFacePG, cfg::kFaceCQ>), dim3(cfg::blocks_for(batch, 128, cfg::kFacePG)),
+                     dim3(kBlock), cfg::kFaceLds, s, d);
+  if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
+  hipLaunchKernelGGL((level0_kernel<cfg::kL0PG, cfg::kL0CQA, cfg::kL0CQB>),
+                     dim3(cfg::blocks_for(batch, 128, cfg::kL0PG)), dim3(kBlock), cfg::kL0Lds, s, d);
+  if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
+  hipLaunchKernelGGL((level1_kernel<cfg::kL1PG, cfg::kL1CQA, cfg::kL1CQB>),
+                     dim3(cfg::blocks_for(batch, 256, cfg::kL1PG)), dim3(kBlock), cfg::kL1Lds, s, d);
+  if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
+  hipLaunchKernelGGL((level2_kernel<cfg::kL2PG, cfg::kL2CQ>), dim3(cfg::blocks_for(batch, 512, cfg::kL2PG)),
+                     dim3(kBlock), cfg::kL2Lds, s, d);
+  if (t) {
+    HIP_TRY(hipEventRecord(h->ev[5], s));
+    h->ev_recorded = true;
+  }
+  HIP_TRY(hipGetLastError());
+  return THA4_OK;
+}
+
+void tha4_student_destroy(tha4_student* h) {
+  if (!h) return;
+  DeviceGuard guard(h->device);
+  if (h->ev_valid)
+    for (auto& e : h->ev) (void)hipEventDestroy(e);
+  if (h->blob) (void)hipFree(h->blob);
+  if (h->workspace) (void)hipFree(h->workspace);
+  delete h;
+}
+
+int tha4_student_max_batch(const tha4_student* h) { return h ? h->max_batch : THA4_ERR_INVALID_ARGUMENT; }
+int tha4_student_device(const tha4_student* h) { return h ? h->device : THA4_ERR_INVALID_ARGUMENT; }
+
+int tha4_student_set_timing(tha4_student* h, int enable) {
+  if (!h) return fail(THA4_ERR_INVALID_ARGUMENT, "handle must not be NULL");
+  DeviceGuard guard(h->device);
+  if (enable && !h->ev_valid) {
+    for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+    h->ev_valid = true;
+  }
+  h->timing = enable != 0;
+  h->ev_recorded = false;
+  return THA4_OK;
+}
+
+int tha4_student_last_ms(tha4_student* h, int kernel, float* ms_out) {
+  if (!h || !ms_out) return fail(THA4_ERR_INVALID_ARGUMENT, "handle/ms_out must not be NULL");
+  if (!h->ev_valid || !h->ev_recorded) return fail(THA4_ERR_INVALID_ARGUMENT, "no timed pose call recorded");
+  if (kernel < -1 || kernel >= kNumKernels) return fail(THA4_ERR_INVALID_ARGUMENT, "kernel index out of range");
+  DeviceGuard guard(h->device);
+  HIP_TRY(hipEventSynchronize(h->ev[kNumKernels]));
+  if (kernel < 0) HIP_TRY(hipEventElapsedTime(ms_out, h->ev[0], h->ev[kNumKernels]));
+  else HIP_TRY(hipEventElapsedTime(ms_out, h->ev[kernel], h->ev[kernel + 1]));
+  return THA4_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Platform glue for the THA4 HIP kernels.
+//
+// Product build: hipcc --offload-arch=gfx950 (CDNA4 only; no other backend exists).
+// THA4_EMU build: the SAME kernel source compiled as host C++ against tests/emu/emu_hip.h,
+// a fiber-based SIMT emulator used by the CPU unit tests only (never shipped, never linked
+// into libtha4_hip.so).
+#pragma once
+
+#ifdef THA4_EMU
+#include "emu_hip.h"
+#define THA4_DYN_LDS(name) char* name = emu::g_lds
+#else
+#include <hip/hip_runtime.h>
+#define THA4_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#define THA4_DEV __device__ __forceinline__
+
+namespace tha4 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef THA4_EMU
+// 16-byte async global -> LDS copy (global_load_lds_dwordx4).  The LDS destination is
+// wave-uniform base + lane*16; the global source is per lane.
+THA4_DEV void glds16(const void* gsrc_lane, void* lds_base_uniform) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc_lane,
+      (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+THA4_DEV f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+THA4_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+THA4_DEV float lane_read(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+#else
+THA4_DEV void glds16(const void* gsrc_lane, void* lds_base_uniform) { emu::glds16(gsrc_lane, lds_base_uniform); }
+THA4_DEV f32x4 mfma16(float a, float b, f32x4 c) {
+  float r[4] = {c[0], c[1], c[2], c[3]};
+  emu::mfma_f32_16x16x4(a, b, r);
+  f32x4 o = {r[0], r[1], r[2], r[3]};
+  return o;
+}
+THA4_DEV int uniform_i32(int v) { return v; }
+THA4_DEV float lane_read(float v, int src_lane) { return emu::shfl(v, src_lane); }
+#endif
+
+}  // namespace tha4

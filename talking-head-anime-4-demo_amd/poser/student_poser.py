@@ -1,0 +1,204 @@
+"""``Poser`` implementation for the distilled student (mode_14) on top of the HIP C ABI.
+
+Mirrors the surface of the reference's ``GeneralPoser02`` (src/tha4/poser/general_poser_02.py:10-98)
+as used by ``mode_14.create_poser`` (src/tha4/poser/modes/mode_14.py:134-162):
+
+  * modules are loaded lazily on the first call (general_poser_02.py:41-49);
+  * a 3-D image / 1-D pose is promoted to a batch of one (:66-69); results are always batched;
+  * ``pose(image, pose, output_index=None)`` returns ``get_posing_outputs(...)[output_index]``
+    with ``None`` -> ``default_output_index`` (:57-61);
+  * ``get_posing_outputs`` returns the 6 tensors of TwoStepPoserComputationProtocol's
+    "all_outputs" in the reference order (mode_14.py:85-88):
+        [blended, alpha, color_change, warped, grid_change, face_morpher_output];
+  * ``to(device)``, ``free()``, ``get_dtype()``, ``get_image_size()``, ``get_output_length()``,
+    ``get_pose_parameter_groups()``, ``get_num_parameters()`` as in the reference.
+
+All work is enqueued on ``torch.cuda.current_stream(device)`` without synchronising, so callers can
+bracket ``pose()`` with ``torch.cuda.Event`` exactly like full_manual_poser.py:388-398.
+PyTorch is used for device memory and streams only; the arithmetic happens in libtha4_hip.so.
+There is no CPU path: a non-CUDA device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _capi
+from .poser import PoseParameterGroup, Poser
+
+IMAGE_SIZE = 512
+FACE_SIZE = 128
+NUM_OUTPUTS = 6
+
+
+def aten_position_axes() -> Dict[int, np.ndarray]:
+    """fp32 affine_grid axes as the local PyTorch build produces them on CPU - what the reference
+    feeds its SIREN stacks every frame (siren_morpher_03.py:92-99).  Constants, computed once."""
+    import torch.nn.functional as F
+    out = {}
+    ident = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]).unsqueeze(0)
+    for s in (128, 256, 512):
+        out[s] = F.affine_grid(ident, [1, 1, s, s], align_corners=False)[0, 0, :, 0].numpy().copy()
+    return out
+
+
+class HipStudentPoser(Poser):
+    def __init__(self,
+                 state_dict_loaders: Dict[str, Callable[[], Dict[str, np.ndarray]]],
+                 device: torch.device,
+                 pose_parameters: List[PoseParameterGroup],
+                 default_output_index: int = 0,
+                 max_batch: int = 1,
+                 position_axes: Optional[Dict[int, np.ndarray]] = None,
+                 dtype: torch.dtype = torch.float):
+        self.state_dict_loaders = state_dict_loaders
+        self.device = torch.device(device)
+        self.pose_parameters = pose_parameters
+        self.default_output_index = default_output_index
+        self.image_size = IMAGE_SIZE
+        self.output_length = NUM_OUTPUTS
+        self.dtype = dtype
+        self.num_parameters = sum(p.get_arity() for p in pose_parameters)
+        self.position_axes = position_axes
+        self._max_batch = max(1, int(max_batch))
+        self._state_dicts = None
+        self._lib = None
+        self._handle = None
+
+    # ---- reference surface -----------------------------------------------------------------
+    def get_image_size(self) -> int:
+        return self.image_size
+
+    def get_output_length(self) -> int:
+        return self.output_length
+
+    def get_pose_parameter_groups(self) -> List[PoseParameterGroup]:
+        return self.pose_parameters
+
+    def get_num_parameters(self) -> int:
+        return self.num_parameters
+
+    def get_dtype(self) -> torch.dtype:
+        return self.dtype
+
+    def get_modules(self):
+        """Lazy load (general_poser_02.py:41-49): read the state_dicts and create the native handle."""
+        self._ensure_handle(self._max_batch)
+        return self._state_dicts
+
+    def pose(self, image: Tensor, pose: Tensor, output_index: Optional[int] = None) -> Tensor:
+        if output_index is None:
+            output_index = self.default_output_index
+        if output_index == 0:
+            return self._run(image, pose, all_outputs=False)[0]
+        return self.get_posing_outputs(image, pose)[output_index]
+
+    def get_posing_outputs(self, image: Tensor, pose: Tensor) -> List[Tensor]:
+        return self._run(image, pose, all_outputs=True)
+
+    def free(self):
+        self._destroy_handle()
+        self._state_dicts = None
+
+    def to(self, device: torch.device) -> "HipStudentPoser":
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        self._destroy_handle()
+        self.device = device
+        return self
+
+    # ---- native plumbing ---------------------------------------------------------------------
+    def _device_index(self) -> int:
+        if self.device.type != "cuda":
+            raise _capi.Tha4Error(f"HipStudentPoser needs a ROCm GPU device, got {self.device} (no CPU path exists)")
+        return self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+    def _destroy_handle(self):
+        if self._handle is not None and self._lib is not None:
+            self._lib.tha4_student_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy_handle()
+        except Exception:
+            pass
+
+    def _ensure_handle(self, batch: int):
+        if self._handle is not None and batch <= self._max_batch:
+            return
+        dev = self._device_index()
+        if self._lib is None:
+            self._lib = _capi.load_library()
+        if self._state_dicts is None:
+            self._state_dicts = {k: loader() for k, loader in self.state_dict_loaders.items()}
+        self._destroy_handle()
+        self._max_batch = max(self._max_batch, batch)
+        weights, keep = _capi.build_student_weights(self._state_dicts["face_morpher"], self._state_dicts["body_morpher"])
+        axes, keep2 = _capi.build_position_axes(self.position_axes)
+        handle = C.c_void_p()
+        st = self._lib.tha4_student_create(C.byref(weights), C.byref(axes) if axes is not None else None, dev,
+                                           self._max_batch, C.byref(handle))
+        _capi.check(self._lib, st, "tha4_student_create")
+        del keep, keep2
+        self._handle = handle
+
+    def _check_inputs(self, image: Tensor, pose: Tensor):
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
+        if pose.dim() == 1:
+            pose = pose.unsqueeze(0)
+        if image.dim() != 4 or tuple(image.shape[1:]) != (4, IMAGE_SIZE, IMAGE_SIZE):
+            raise AssertionError(f"image must be [B,4,512,512] or [4,512,512], got {tuple(image.shape)}")
+        if pose.dim() != 2 or pose.shape[1] != self.num_parameters:
+            raise AssertionError(f"pose must be [B,{self.num_parameters}] or [{self.num_parameters}], got {tuple(pose.shape)}")
+        b = pose.shape[0]
+        if image.shape[0] not in (1, b):
+            raise AssertionError(f"image batch {image.shape[0]} does not match pose batch {b}")
+        for name, t in (("image", image), ("pose", pose)):
+            if t.dtype != torch.float32:
+                raise AssertionError(f"{name} must be float32, got {t.dtype}")
+            if t.device != self.device and not (t.device.type == "cuda" and self.device.type == "cuda"
+                                                and t.device.index == self._device_index()):
+                raise AssertionError(f"{name} is on {t.device}, poser is on {self.device}")
+        return image.contiguous(), pose.contiguous(), b
+
+    def _run(self, image: Tensor, pose: Tensor, all_outputs: bool) -> List[Tensor]:
+        image, pose, b = self._check_inputs(image, pose)
+        self._ensure_handle(b)
+        dev = self._device_index()
+        opts = dict(dtype=torch.float32, device=image.device)
+        blended = torch.empty((b, 4, IMAGE_SIZE, IMAGE_SIZE), **opts)
+        outs = [blended]
+        aux_ref = None
+        if all_outputs:
+            alpha = torch.empty((b, 1, IMAGE_SIZE, IMAGE_SIZE), **opts)
+            color = torch.empty((b, 4, IMAGE_SIZE, IMAGE_SIZE), **opts)
+            warped = torch.empty((b, 4, IMAGE_SIZE, IMAGE_SIZE), **opts)
+            grid = torch.empty((b, 2, IMAGE_SIZE, IMAGE_SIZE), **opts)
+            face = torch.empty((b, 4, FACE_SIZE, FACE_SIZE), **opts)
+            aux = _capi.Tha4StudentAux(alpha.data_ptr(), color.data_ptr(), warped.data_ptr(), grid.data_ptr(),
+                                       face.data_ptr())
+            aux_ref = C.byref(aux)
+            outs += [alpha, color, warped, grid, face]
+        stride = 0 if (image.shape[0] == 1 and b > 1) else 4 * IMAGE_SIZE * IMAGE_SIZE
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        st = self._lib.tha4_student_pose(self._handle, image.data_ptr(), stride, pose.data_ptr(), b,
+                                         blended.data_ptr(), aux_ref, C.c_void_p(stream))
+        _capi.check(self._lib, st, "tha4_student_pose")
+        return outs
+
+    # ---- measurement hooks (bench.py) ----------------------------------------------------------
+    def set_timing(self, enable: bool):
+        self._ensure_handle(self._max_batch)
+        _capi.check(self._lib, self._lib.tha4_student_set_timing(self._handle, int(enable)), "tha4_student_set_timing")
+
+    def last_kernel_ms(self, kernel: int) -> float:
+        ms = C.c_float()
+        _capi.check(self._lib, self._lib.tha4_student_last_ms(self._handle, kernel, C.byref(ms)), "tha4_student_last_ms")
+        return float(ms.value)

@@ -1,0 +1,129 @@
+// CPU emulation harness for the student kernels (TEST INFRASTRUCTURE ONLY).
+// Builds the unmodified kernel source against emu_hip.h and exposes a tiny C API for pytest
+// (tests/test_emu_kernels.py): host buffers stand in for HBM, selected workgroups are executed.
+#define THA4_EMU 1
+#include "siren_kernels.h"
+#include "tha4_hip.h"
+
+#include <map>
+#include <string>
+
+using namespace tha4;
+
+namespace {
+struct EmuStudent {
+  StudentPacked packed;
+  std::vector<float> pos128, pos256, pos512;
+  std::map<std::string, std::vector<float>> buf;
+  StudentDev dev{};
+};
+
+StudentWeightsView to_view(const tha4_student_weights* w) {
+  StudentWeightsView v{};
+  auto cv = [](const tha4_linear& l) { return LinearView{l.weight, l.bias, l.out_ch, l.in_ch}; };
+  for (int i = 0; i < 8; ++i) v.face_sine[i] = cv(w->face_sine[i]);
+  v.face_last = cv(w->face_last);
+  for (int l = 0; l < 3; ++l)
+    for (int j = 0; j < 3; ++j) v.body_sine[l][j] = cv(w->body_sine[l][j]);
+  v.body_last = cv(w->body_last);
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+void* emu_student_create(const tha4_student_weights* w, const tha4_position_axes* axes) {
+  auto* e = new EmuStudent();
+  std::string err = pack_student(to_view(w), e->packed);
+  if (!err.empty()) {
+    std::fprintf(stderr, "emu_student_create: %s\n", err.c_str());
+    delete e;
+    return nullptr;
+  }
+  e->pos128.resize(128); e->pos256.resize(256); e->pos512.resize(512);
+  exact_position_axis(128, e->pos128.data());
+  exact_position_axis(256, e->pos256.data());
+  exact_position_axis(512, e->pos512.data());
+  if (axes) {
+    if (axes->axis128) std::memcpy(e->pos128.data(), axes->axis128, 128 * 4);
+    if (axes->axis256) std::memcpy(e->pos256.data(), axes->axis256, 256 * 4);
+    if (axes->axis512) std::memcpy(e->pos512.data(), axes->axis512, 512 * 4);
+  }
+  auto& b = e->buf;
+  b["pbias"].assign(kPbStride, 0.f);
+  b["z1"].assign((size_t)kNB1 * 128 * 128 * 16, 0.f);
+  b["z2"].assign((size_t)kNB2 * 256 * 256 * 16, 0.f);
+  b["face"].assign(4 * 128 * 128, 0.f);
+  b["image"].assign(4 * 512 * 512, 0.f);
+  b["pose"].assign(kPose, 0.f);
+  b["out_blended"].assign(4 * 512 * 512, 0.f);
+  b["out_alpha"].assign(512 * 512, 0.f);
+  b["out_color"].assign(4 * 512 * 512, 0.f);
+  b["out_warped"].assign(4 * 512 * 512, 0.f);
+  b["out_grid"].assign(2 * 512 * 512, 0.f);
+  StudentDev& d = e->dev;
+  const StudentPacked& p = e->packed;
+  d.w_face = p.w_face.data(); d.w_l0 = p.w_l0.data(); d.w_l1 = p.w_l1.data(); d.w_l2 = p.w_l2.data();
+  d.b_face = p.b_face.data(); d.b_l0 = p.b_l0.data(); d.b_l1 = p.b_l1.data(); d.b_l2 = p.b_l2.data();
+  const FirstLayerPack* f[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
+  for (int i = 0; i < 4; ++i) {
+    d.wx[i] = f[i]->wx.data(); d.wy[i] = f[i]->wy.data();
+    d.bias1[i] = f[i]->bias.data(); d.wpose[i] = f[i]->wpose.data();
+  }
+  d.pos128 = e->pos128.data(); d.pos256 = e->pos256.data(); d.pos512 = e->pos512.data();
+  d.pbias = b["pbias"].data(); d.z1 = b["z1"].data(); d.z2 = b["z2"].data(); d.face = b["face"].data();
+  d.image = b["image"].data(); d.image_stride = 4 * 512 * 512; d.pose = b["pose"].data();
+  d.out_blended = b["out_blended"].data(); d.out_alpha = b["out_alpha"].data();
+  d.out_color = b["out_color"].data(); d.out_warped = b["out_warped"].data(); d.out_grid = b["out_grid"].data();
+  d.batch = 1;
+  return e;
+}
+
+float* emu_student_buffer(void* h, const char* name, int64_t* nfloats) {
+  auto* e = static_cast<EmuStudent*>(h);
+  auto it = e->buf.find(name);
+  if (it == e->buf.end()) return nullptr;
+  if (nfloats) *nfloats = (int64_t)it->second.size();
+  return it->second.data();
+}
+
+// number of workgroups of kernel k (0 posebias, 1 face, 2 level0, 3 level1, 4 level2) at batch 1
+int emu_student_grid(int kernel) {
+  switch (kernel) {
+    case 0: return (kPbStride + kBlock - 1) / kBlock;
+    case 1: return cfg::blocks_for(1, 128, cfg::kFacePG);
+    case 2: return cfg::blocks_for(1, 128, cfg::kL0PG);
+    case 3: return cfg::blocks_for(1, 256, cfg::kL1PG);
+    case 4: return cfg::blocks_for(1, 512, cfg::kL2PG);
+  }
+  return -1;
+}
+
+int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
+  auto* e = static_cast<EmuStudent*>(h);
+  const int grid = emu_student_grid(kernel);
+  if (grid < 0 || first_block < 0 || first_block + nblocks > grid) return -1;
+  for (int b = first_block; b < first_block + nblocks; ++b) {
+    switch (kernel) {
+      case 0: emu::run_block(posebias_kernel, dim3(grid, 1), dim3(b, 0), kBlock, 0, e->dev); break;
+      case 1: emu::run_block(face_kernel<cfg::kFacePG, cfg::kFaceCQ>, dim3(grid), dim3(b), kBlock, cfg::kFaceLds, e->dev); break;
+      case 2: emu::run_block(level0_kernel<cfg::kL0PG, cfg::kL0CQA, cfg::kL0CQB>, dim3(grid), dim3(b), kBlock, cfg::kL0Lds, e->dev); break;
+      case 3: emu::run_block(level1_kernel<cfg::kL1PG, cfg::kL1CQA, cfg::kL1CQB>, dim3(grid), dim3(b), kBlock, cfg::kL1Lds, e->dev); break;
+      case 4: emu::run_block(level2_kernel<cfg::kL2PG, cfg::kL2CQ>, dim3(grid), dim3(b), kBlock, cfg::kL2Lds, e->dev); break;
+    }
+  }
+  return 0;
+}
+
+// pixels [first, first+count) (row-major index at the kernel's resolution) covered by workgroup b
+void emu_student_block_pixels(int kernel, int block, int* first, int* count) {
+  const int pg = kernel == 1 ? cfg::kFacePG : kernel == 2 ? cfg::kL0PG : kernel == 3 ? cfg::kL1PG : cfg::kL2PG;
+  *count = kWaves * pg * 16;
+  *first = block * (*count);
+}
+
+float emu_sin_omega(float z) { return sin_omega(z); }
+
+void emu_student_destroy(void* h) { delete static_cast<EmuStudent*>(h); }
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+"""Kernel-logic tests on CPU: the UNMODIFIED kernel source (csrc/siren_kernels.h) compiled against
+the fiber SIMT emulator (tests/emu) and checked workgroup-by-workgroup against the fp64 oracle.
+This validates the MFMA fragment packing, the LDS images, the weight streaming schedule, the
+upsample taps and the warp/blend epilogue without a GPU.  (GPU parity proper: test_student_gpu.py.)"""
+import numpy as np
+import pytest
+
+from oracle import student_oracle as so
+from tests.emu_util import K_FACE, K_L0, K_L1, K_L2, K_POSEBIAS, EmuStudent, pack_z, unpack_z
+
+
+@pytest.fixture(scope="module")
+def ctx(built, golden_weights, golden_io):
+    pose = golden_io["poses"][0]
+    emu = EmuStudent(golden_weights)
+    emu.buf("pose")[:] = pose
+    emu.buf("image")[:] = golden_io["image_f32"].reshape(-1)
+    it = so.student_intermediates(golden_weights, pose)
+    yield emu, it, pose
+    emu.close()
+
+
+def test_sin_omega_accuracy(ctx):
+    emu = ctx[0]
+    z = np.random.default_rng(0).uniform(-1.6, 1.6, 4000).astype(np.float32)
+    err = max(abs(emu.sin_omega(v) - np.sin(np.float64(np.float32(30.0) * v))) for v in z)
+    assert err < 2.5e-7
+    assert emu.sin_omega(0.0) == 0.0          # padded channels must stay exactly zero
+
+
+def test_posebias_kernel(ctx):
+    emu, it, _ = ctx
+    emu.run(K_POSEBIAS, 0, emu.grid(K_POSEBIAS))
+    pb = emu.buf("pbias")
+    assert np.abs(pb[0:128] - it["pb_face"]).max() < 1e-6
+    assert np.abs(pb[128:488] - it["pb0"]).max() < 1e-6
+    assert np.abs(pb[496:676] - it["pb1"]).max() < 1e-6
+    assert np.abs(pb[688:778] - it["pb2"]).max() < 1e-6
+    assert not pb[488:496].any() and not pb[676:688].any() and not pb[778:784].any()
+
+
+def test_face_kernel_blocks(ctx, golden_weights):
+    emu, it, pose = ctx
+    emu.run(K_POSEBIAS, 0, emu.grid(K_POSEBIAS))
+    ref = so.face_forward_numpy(golden_weights, pose[:39].astype(np.float64)).reshape(4, -1)
+    for b in (0, 131, emu.grid(K_FACE) - 1):
+        emu.run(K_FACE, b)
+        px = emu.block_pixels(K_FACE, b)
+        got = emu.buf("face").reshape(4, -1)[:, px]
+        assert np.abs(got - ref[:, px]).max() < 5e-5
+
+
+def test_level0_kernel_blocks(ctx):
+    emu, it, _ = ctx
+    emu.run(K_POSEBIAS, 0, emu.grid(K_POSEBIAS))
+    ref = it["z1"].reshape(180, -1)
+    for b in (0, 77, emu.grid(K_L0) - 1):
+        emu.run(K_L0, b)
+        px = emu.block_pixels(K_L0, b)
+        got = unpack_z(emu.buf("z1"), 12, 128 * 128, 180)[:, px]
+        assert np.abs(got - ref[:, px]).max() < 5e-4       # fp32 through 2x360-wide sine layers
+        pad = emu.buf("z1").reshape(12, 128 * 128, 16)[11, px, 4:]
+        assert not pad.any()                                # channels 180..191 are exact zeros
+
+
+def test_level1_kernel_blocks(ctx):
+    emu, it, _ = ctx
+    emu.run(K_POSEBIAS, 0, emu.grid(K_POSEBIAS))
+    emu.buf("z1")[:] = pack_z(it["z1"].reshape(180, -1), 12)
+    ref = it["z2"].reshape(90, -1)
+    for b in (0, 1, 300, emu.grid(K_L1) - 1):               # 0/1: image corners (clamped taps)
+        emu.run(K_L1, b)
+        px = emu.block_pixels(K_L1, b)
+        got = unpack_z(emu.buf("z2"), 6, 256 * 256, 90)[:, px]
+        assert np.abs(got - ref[:, px]).max() < 2e-5
+
+
+def test_level2_kernel_blocks(ctx, golden_weights, golden_io):
+    emu, it, pose = ctx
+    emu.run(K_POSEBIAS, 0, emu.grid(K_POSEBIAS))
+    emu.buf("z2")[:] = pack_z(it["z2"].reshape(90, -1), 6)
+    face = so.face_forward_numpy(golden_weights, pose[:39].astype(np.float64))
+    emu.buf("face")[:] = face.astype(np.float32).reshape(-1)
+    ref = so.student_forward_numpy(golden_weights, golden_io["image_f32"], pose)
+    tol = {"out_blended": 5e-4, "out_alpha": 1e-5, "out_color": 2e-5, "out_warped": 5e-4, "out_grid": 5e-6}
+    # 288/289: row 144 (inside the pasted face rows), 160..: row 80 = first face row
+    for b in (0, 1, 160, 288, 289, 400, emu.grid(K_L2) - 1):
+        emu.run(K_L2, b)
+        px = emu.block_pixels(K_L2, b)
+        for name, k, c in (("out_blended", 0, 4), ("out_alpha", 1, 1), ("out_color", 2, 4), ("out_warped", 3, 4),
+                           ("out_grid", 4, 2)):
+            got = emu.buf(name).reshape(c, -1)[:, px]
+            assert np.abs(got - ref[k].reshape(c, -1)[:, px]).max() < tol[name], (b, name)
