@@ -98,6 +98,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # libtha4_hip.so needs libamdhip64.so.7; PyTorch-ROCm bundles its own copy under the same soname.
+    # Import torch FIRST so that one HIP runtime (torch's) serves both - streams, events and device
+    # pointers are only interchangeable inside a single runtime instance.
+    import torch  # noqa: F401
     p = path or os.environ.get("THA4_HIP_LIB", LIB_PATH)
     if not os.path.exists(p):
         raise Tha4Error(

@@ -17,14 +17,18 @@
 // The bilinear x2 upsample between levels commutes with the (linear) feature part of the next
 // level's first layer, so each level emits z = W_next[:, :C] h at ITS resolution and the next level
 // only gathers 4 taps of z per pixel (4x fewer MACs for that layer, no 180/90-channel upsampled map).
+//
+// Workgroup geometry: NS pixel slots x MS row splits = NS*MS waves (8 = two per SIMD, so one
+// wave's sin()/LDS/epilogue work hides under the other's MFMAs).  A pixel slot owns PG pixel
+// groups of 16 px (a 16-px strip of one image row) and one activation image in LDS; with MS = 2
+// two waves share a slot and each computes half of every layer's output blocks (this is what lets
+// level 0 / face fill all 256 CUs with two waves per SIMD at batch 1, where there are only 1024
+// pixel groups for 1024 SIMDs).
 #pragma once
 #include "tha4_platform.h"
 #include "siren_layout.h"
 
 namespace tha4 {
-
-constexpr int kWaves = 4;            // waves per workgroup (one per SIMD)
-constexpr int kBlock = kWaves * 64;
 
 struct StudentDev {
   // packed parameters (device)
@@ -55,6 +59,9 @@ struct StudentDev {
 // sin(r) = r + r^3 q(r^2) on [-pi/2, pi/2] (degree-9 minimax), sign flipped for odd k.
 // ---------------------------------------------------------------------------------------------
 THA4_DEV float sin_omega(float z) {
+#ifdef THA4_ABLATE_SIN   // timing ablation only (tools/sweep.py): results are wrong
+  return z;
+#endif
   const float u = kOmega * z;
   const float k = rintf(u * 0x1.45f306p-2f);
   float r = fmaf(-k, 0x1.92p+1f, u);
@@ -71,120 +78,191 @@ THA4_DEV float sin_omega(float z) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight stream: all waves of the workgroup copy PIECES x 1 KiB from global to an LDS ring slot
+// workgroup geometry + LDS carve:  [ring slot 0][ring slot 1][act slot 0]..[act slot NS-1]
 // ---------------------------------------------------------------------------------------------
-template <int PIECES>
+template <int NS_, int MS_, int PG_, int ACTQ_, int SLOT_PIECES_>
+struct Geo {
+  static constexpr int NS = NS_, MS = MS_, PG = PG_, ACTQ = ACTQ_;
+  static constexpr int WAVES = NS * MS, THREADS = WAVES * 64;
+  static constexpr int SLOT = SLOT_PIECES_ * 1024;              // bytes of one ring slot
+  static constexpr int ACT_BYTES = PG * ACTQ * 1024;            // one pixel slot's activation image
+  static constexpr int LDS = 2 * SLOT + NS * ACT_BYTES;
+  static constexpr int PX = NS * PG * 16;                       // pixels per workgroup
+  static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
+  static_assert(THREADS <= 1024, "too many waves");
+};
+
+struct WaveCtx {
+  int lane, wave, ns, ms;   // ns: pixel slot, ms: row split
+};
+
+template <class G>
+THA4_DEV WaveCtx wave_ctx() {
+  WaveCtx c;
+  c.lane = threadIdx.x & 63;
+  c.wave = uniform_i32(threadIdx.x >> 6);
+  c.ns = c.wave % G::NS;
+  c.ms = c.wave / G::NS;
+  return c;
+}
+
+// weight stream: all waves of the workgroup copy PIECES x 1 KiB from global to an LDS ring slot
+template <int PIECES, int WAVES>
 THA4_DEV void fetch_pieces(const char* g, char* l, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < (PIECES + kWaves - 1) / kWaves; ++i) {
-    const int pc = i * kWaves + wave;
+  for (int i = 0; i < (PIECES + WAVES - 1) / WAVES; ++i) {
+    const int pc = i * WAVES + wave;
+#ifndef THA4_ABLATE_FETCH
     if (pc < PIECES) glds16(g + pc * 1024 + lane * 16, l + pc * 1024);
+#endif
   }
 }
 
-// One linear layer for the wave's PG pixel groups (16 px each): acc[b][pg] += W-block b x act.
-//   NB  output blocks (16 channels each)      KQ  input quads (16 channels each)
-//   CQ  quads per streamed chunk (KQ % CQ == 0)   ACTQ  quads per pixel group in the act image
-//   NEXT_PIECES  size (KiB) of the first chunk of whatever layer follows in the stream (0: none);
-//                it is prefetched during this layer's last chunk so layer boundaries cost no bubble.
-// On entry chunk 0 of this layer is resident in ring slot `slot` (the preceding barrier covered it).
-template <int NB, int KQ, int CQ, int PG, int ACTQ, int SLOT_BYTES, int NEXT_PIECES>
-THA4_DEV void gemm_stream(const char*& gw, char* ring, int& slot, const f32x4* actv,
-                          f32x4 (&acc)[NB][PG], int wave, int lane) {
+#if !defined(THA4_EMU) && !defined(THA4_NO_PIPELINE)
+#define THA4_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define THA4_SCHED_FENCE()
+#endif
+
+// blocks per software-pipeline group: the A fragments of group t+1 are read from LDS while the
+// MFMAs of group t issue; inside a group MFMAs are ordered k-step-major so that consecutive
+// instructions hit different accumulators (a dependent v_mfma_f32_16x16x4_f32 costs 40 cycles, an
+// independent one 32).
+constexpr int group_blocks(int nbw) { return nbw % 4 == 0 ? 4 : (nbw % 3 == 0 ? 3 : (nbw % 2 == 0 ? 2 : 1)); }
+
+// One linear layer, this wave's share: acc[b][pg] += W-block (mbase+b) x act of pixel group pg.
+//   NB   output blocks of the layer in the stream (all waves)   NBW  blocks computed by this wave
+//   KQ   input quads   CQ quads per streamed chunk (KQ % CQ == 0)
+//   NEXT_PIECES  KiB of the first chunk of whatever follows in the stream (0: nothing); prefetched
+//                during this layer's last chunk so layer boundaries cost no load bubble.
+// On entry chunk 0 of this layer is resident in ring slot `slot` (covered by the preceding barrier).
+// `active` (wave-uniform) = false: take part in the fetches and barriers only.
+template <class G, int NB, int NBW, int KQ, int CQ, int NEXT_PIECES>
+THA4_DEV void gemm_stream(const char*& gw, char* ring, int& slot, const f32x4* actv, f32x4 (&acc)[NBW][G::PG],
+                          const WaveCtx& w, int mbase, bool active) {
   static_assert(KQ % CQ == 0, "chunking must divide K");
-  static_assert(CQ * NB * 1024 <= SLOT_BYTES, "chunk exceeds ring slot");
-  static_assert(NEXT_PIECES * 1024 <= SLOT_BYTES, "next chunk exceeds ring slot");
+  static_assert(CQ * NB * 1024 <= G::SLOT, "chunk exceeds ring slot");
+  static_assert(NEXT_PIECES * 1024 <= G::SLOT, "next chunk exceeds ring slot");
   constexpr int NC = KQ / CQ;
   constexpr int CHUNK = CQ * NB * 1024;
+  constexpr int PG = G::PG;
+  constexpr int GB = group_blocks(NBW), NG = NBW / GB, T = CQ * NG;
 #pragma unroll 1
   for (int c = 0; c < NC; ++c) {
     const int nslot = slot ^ 1;
     if (c + 1 < NC) {
-      fetch_pieces<CQ * NB>(gw + (size_t)(c + 1) * CHUNK, ring + nslot * SLOT_BYTES, wave, lane);
+      fetch_pieces<CQ * NB, G::WAVES>(gw + (size_t)(c + 1) * CHUNK, ring + nslot * G::SLOT, w.wave, w.lane);
     } else if (NEXT_PIECES > 0) {
-      fetch_pieces<NEXT_PIECES>(gw + (size_t)NC * CHUNK, ring + nslot * SLOT_BYTES, wave, lane);
+      fetch_pieces<NEXT_PIECES, G::WAVES>(gw + (size_t)NC * CHUNK, ring + nslot * G::SLOT, w.wave, w.lane);
     }
-    const f32x4* wv = reinterpret_cast<const f32x4*>(ring + slot * SLOT_BYTES);
+    if (active) {
+      const f32x4* wv = reinterpret_cast<const f32x4*>(ring + slot * G::SLOT) + (size_t)mbase * 64 + w.lane;
+      const f32x4* av = actv + (size_t)c * CQ * 64 + w.lane;
+      f32x4 abuf[2][GB], bbuf[2][PG];
 #pragma unroll
-    for (int qq = 0; qq < CQ; ++qq) {
-      f32x4 bf[PG];
+      for (int pg = 0; pg < PG; ++pg) bbuf[0][pg] = av[pg * G::ACTQ * 64];
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) bf[pg] = actv[(pg * ACTQ + c * CQ + qq) * 64 + lane];
+      for (int b = 0; b < GB; ++b) abuf[0][b] = wv[b * 64];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const f32x4 a = wv[(qq * NB + b) * 64 + lane];
+      for (int t = 0; t < T; ++t) {
+        const int qq = t / NG, g = t % NG;
+        // k-step 0 of this group first: the compiler's s_waitcnt for the group's fragments lands
+        // here, BEFORE the next group's LDS reads are issued, so it never drains those
 #pragma unroll
-        for (int pg = 0; pg < PG; ++pg) {
+        for (int b = 0; b < GB; ++b)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[b][pg] = mfma16(a[j], bf[pg][j], acc[b][pg]);
+          for (int pg = 0; pg < PG; ++pg)
+            acc[g * GB + b][pg] = mfma16(abuf[t & 1][b][0], bbuf[qq & 1][pg][0], acc[g * GB + b][pg]);
+        THA4_SCHED_FENCE();
+        if (t + 1 < T) {   // LDS reads of the next group fly under the remaining 3/4 of this group's MFMAs
+          const int nq = (t + 1) / NG, ng = (t + 1) % NG;
+          if (ng == 0) {
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) bbuf[nq & 1][pg] = av[(pg * G::ACTQ + nq) * 64];
+          }
+#pragma unroll
+          for (int b = 0; b < GB; ++b) abuf[(t + 1) & 1][b] = wv[(nq * NB + ng * GB + b) * 64];
         }
+        THA4_SCHED_FENCE();
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+#pragma unroll
+          for (int b = 0; b < GB; ++b)
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg)
+              acc[g * GB + b][pg] = mfma16(abuf[t & 1][b][j], bbuf[qq & 1][pg][j], acc[g * GB + b][pg]);
+        THA4_SCHED_FENCE();
       }
     }
+#ifndef THA4_ABLATE_BARRIER
     __syncthreads();   // next slot landed (vmcnt(0)) and every wave is done reading this one
+#endif
     slot = nslot;
   }
   gw += (size_t)NC * CHUNK;
 }
 
-template <int NB, int PG>
-THA4_DEV void zero_acc(f32x4 (&acc)[NB][PG]) {
+template <int NBW, int PG>
+THA4_DEV void zero_acc(f32x4 (&acc)[NBW][PG]) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int b = 0; b < NBW; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// acc + bias -> (sin) -> act image (block b becomes input quad b of the next layer)
-template <int NB, int PG, int ACTQ, bool SIN>
-THA4_DEV void store_act(f32x4 (&acc)[NB][PG], const float* bias, f32x4* actv, int lane) {
-  const int g4 = (lane >> 4) * 4;
+// sine hidden layer: act <- sin(30 (W act + b)).  Output block b becomes input quad b of the next layer.
+template <class G, int NB, int KQ, int CQ, int NEXT_PIECES>
+THA4_DEV void sine_layer(const char*& gw, const float*& bias, char* ring, int& slot, f32x4* actv, const WaveCtx& w) {
+  static_assert(NB % G::MS == 0, "row split must divide the block count");
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int mbase = w.ms * NBW;
+  f32x4 acc[NBW][PG];
+  zero_acc<NBW, PG>(acc);
+  gemm_stream<G, NB, NBW, KQ, CQ, NEXT_PIECES>(gw, ring, slot, actv, acc, w, mbase, true);
+  const int g4 = (w.lane >> 4) * 4;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + b * 16 + g4);
+  for (int b = 0; b < NBW; ++b) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + (mbase + b) * 16 + g4);
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       f32x4 v = acc[b][pg] + bb;
-      if (SIN) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
-      }
-      actv[(pg * ACTQ + b) * 64 + lane] = v;
+      for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
+      actv[(pg * G::ACTQ + mbase + b) * 64 + w.lane] = v;
     }
   }
-}
-
-// sine hidden layer: act <- sin(30 (W act + b))
-template <int NB, int KQ, int CQ, int PG, int ACTQ, int SLOT_BYTES, int NEXT_PIECES>
-THA4_DEV void sine_layer(const char*& gw, const float*& bias, char* ring, int& slot, f32x4* actv, int wave, int lane) {
-  f32x4 acc[NB][PG];
-  zero_acc<NB, PG>(acc);
-  gemm_stream<NB, KQ, CQ, PG, ACTQ, SLOT_BYTES, NEXT_PIECES>(gw, ring, slot, actv, acc, wave, lane);
-  store_act<NB, PG, ACTQ, true>(acc, bias, actv, lane);
   bias += NB * 16;
+  if (G::MS > 1) __syncthreads();   // the slot's other row-split wave reads these blocks next
 }
 
 // z layer: z = W act, written to global as z[n][b][pix][16] (one 1 KiB run per (block, pixel group))
-template <int NB, int KQ, int CQ, int PG, int ACTQ, int SLOT_BYTES>
+template <class G, int NB, int KQ, int CQ>
 THA4_DEV void z_layer(const char*& gw, char* ring, int& slot, const f32x4* actv, float* zframe, int npix,
-                      const int (&pix0)[PG], int wave, int lane) {
-  f32x4 acc[NB][PG];
-  zero_acc<NB, PG>(acc);
-  gemm_stream<NB, KQ, CQ, PG, ACTQ, SLOT_BYTES, 0>(gw, ring, slot, actv, acc, wave, lane);
-  const int p = lane & 15, g4 = (lane >> 4) * 4;
+                      const int (&pix0)[G::PG], const WaveCtx& w) {
+  static_assert(NB % G::MS == 0, "row split must divide the block count");
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int mbase = w.ms * NBW;
+  f32x4 acc[NBW][PG];
+  zero_acc<NBW, PG>(acc);
+  gemm_stream<G, NB, NBW, KQ, CQ, 0>(gw, ring, slot, actv, acc, w, mbase, true);
+  const int p = w.lane & 15, g4 = (w.lane >> 4) * 4;
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int b = 0; b < NBW; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg)
-      *reinterpret_cast<f32x4*>(zframe + ((size_t)b * npix + pix0[pg] + p) * 16 + g4) = acc[b][pg];
+      *reinterpret_cast<f32x4*>(zframe + ((size_t)(mbase + b) * npix + pix0[pg] + p) * 16 + g4) = acc[b][pg];
 }
 
 // first layer from position only: act <- sin(30 (wx x + wy y + pb))      (pose folded into pb)
-template <int NB, int PG, int ACTQ>
-THA4_DEV void first_layer_pos(const float* wx, const float* wy, const float* pb, const float (&x)[PG],
-                              const float (&y)[PG], f32x4* actv, int lane) {
-  const int g4 = (lane >> 4) * 4;
+template <class G, int NB>
+THA4_DEV void first_layer_pos(const float* wx, const float* wy, const float* pb, const float (&x)[G::PG],
+                              const float (&y)[G::PG], f32x4* actv, const WaveCtx& w) {
+  static_assert(NB % G::MS == 0, "row split must divide the block count");
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int g4 = (w.lane >> 4) * 4, mbase = w.ms * NBW;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
+  for (int bb = 0; bb < NBW; ++bb) {
+    const int b = mbase + bb;
     const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
     const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
     const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
@@ -193,7 +271,7 @@ THA4_DEV void first_layer_pos(const float* wx, const float* wy, const float* pb,
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = sin_omega(fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));
-      actv[(pg * ACTQ + b) * 64 + lane] = v;
+      actv[(pg * G::ACTQ + b) * 64 + w.lane] = v;
     }
   }
 }
@@ -208,11 +286,13 @@ THA4_DEV void up2_taps(int d, int n, int& i0, int& i1, float& l0, float& l1) {
 }
 
 // first layer of level 1/2: act <- sin(30 (upsample2x(z)[pixel] + wx x + wy y + pb))
-template <int NB, int PG, int ACTQ>
+template <class G, int NB>
 THA4_DEV void first_layer_up(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb,
-                             const int (&X0)[PG], const int (&Y)[PG], const float (&x)[PG], const float (&y)[PG],
-                             f32x4* actv, int lane) {
-  const int p = lane & 15, g4 = (lane >> 4) * 4;
+                             const int (&X0)[G::PG], const int (&Y)[G::PG], const float (&x)[G::PG],
+                             const float (&y)[G::PG], f32x4* actv, const WaveCtx& w) {
+  static_assert(NB % G::MS == 0, "row split must divide the block count");
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int p = w.lane & 15, g4 = (w.lane >> 4) * 4, mbase = w.ms * NBW;
   const int npix = lowS * lowS;
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) {
@@ -225,7 +305,8 @@ THA4_DEV void first_layer_up(const float* zframe, int lowS, const float* wx, con
     const float* z10 = zframe + ((size_t)y1 * lowS + x0) * 16 + g4;
     const float* z11 = zframe + ((size_t)y1 * lowS + x1) * 16 + g4;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int bb = 0; bb < NBW; ++bb) {
+      const int b = mbase + bb;
       const size_t off = (size_t)b * npix * 16;
       const f32x4 a = *reinterpret_cast<const f32x4*>(z00 + off);
       const f32x4 bq = *reinterpret_cast<const f32x4*>(z01 + off);
@@ -240,94 +321,94 @@ THA4_DEV void first_layer_up(const float* zframe, int lowS, const float* wx, con
         const float up = ly0 * (lx0 * a[j] + lx1 * bq[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
         v[j] = sin_omega(up + fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));
       }
-      actv[(pg * ACTQ + b) * 64 + lane] = v;
+      actv[(pg * G::ACTQ + b) * 64 + w.lane] = v;
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// kernel 0: pose-folded first-layer biases.  pb[n][c] = b[c] + sum_k Wpose[c][k] pose[n][k]
-// grid (ceil(kPbStride/256), B)
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) posebias_kernel(StudentDev d) {
-  const int idx = blockIdx.x * kBlock + threadIdx.x;
-  const int n = blockIdx.y;
-  if (idx >= kPbStride) return;
-  int net, c;
-  if (idx < kPbL0) { net = 0; c = idx - kPbFace; }
-  else if (idx < kPbL1) { net = 1; c = idx - kPbL0; }
-  else if (idx < kPbL2) { net = 2; c = idx - kPbL1; }
-  else { net = 3; c = idx - kPbL2; }
-  const int P = (net == 0) ? kFacePose : kPose;
-  const float* w = d.wpose[net] + (size_t)c * P;
-  const float* pose = d.pose + (size_t)n * kPose;
-  float s = d.bias1[net][c];
-  for (int k = 0; k < P; ++k) s = fmaf(w[k], pose[k], s);
-  d.pbias[(size_t)n * kPbStride + idx] = s;
+// pixel groups of this wave's slot: global id (over the batch) -> frame, strip origin, positions
+template <class G, int S>
+THA4_DEV int slot_pixels(const WaveCtx& w, const float* axis, int (&pix0)[G::PG], int (&X0)[G::PG], int (&Y)[G::PG],
+                         float (&px)[G::PG], float (&py)[G::PG]) {
+  constexpr int PGS = S * S / 16;
+  static_assert(PGS % (G::NS * G::PG) == 0, "a workgroup must not straddle frames");
+  const int pg_first = (blockIdx.x * G::NS + w.ns) * G::PG;
+#pragma unroll
+  for (int pg = 0; pg < G::PG; ++pg) {
+    pix0[pg] = ((pg_first + pg) % PGS) * 16;
+    X0[pg] = pix0[pg] % S;
+    Y[pg] = pix0[pg] / S;
+    px[pg] = axis[X0[pg] + (w.lane & 15)];
+    py[pg] = axis[Y[pg]];
+  }
+  return pg_first / PGS;   // frame index
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS carve: [ring slot 0][ring slot 1][act wave 0]..[act wave 3]
+// kernel 0: pose-folded first-layer biases.  pb[n][c] = b[c] + sum_k Wpose[k][c] pose[n][k]
+// grid (ceil(kPbStride/64), B), 64 threads: latency-bound, so spread over many CUs
 // ---------------------------------------------------------------------------------------------
-template <int SLOT_BYTES, int PG, int ACTQ>
-struct LdsPlan {
-  static constexpr int kActBytesPerWave = PG * ACTQ * 1024;
-  static constexpr int kBytes = 2 * SLOT_BYTES + kWaves * kActBytesPerWave;
-  static_assert(kBytes <= 160 * 1024, "LDS budget exceeded");
-};
-
-// ---------------------------------------------------------------------------------------------
-// kernel 1: face morpher.  Each wave owns PG strips of 16 px of the 128x128 face image.
-// ---------------------------------------------------------------------------------------------
-template <int PG, int CQ>
-struct FaceCfg {
-  static constexpr int kSlot = (CQ * kNBF > 8 ? CQ * kNBF : 8) * 1024;
-  using Lds = LdsPlan<kSlot, PG, kNBF>;
-};
-
-template <int PG, int CQ>
-__global__ void __launch_bounds__(kBlock) face_kernel(StudentDev d) {
-  using Cfg = FaceCfg<PG, CQ>;
-  constexpr int SLOT = Cfg::kSlot;
-  constexpr int S = kFaceSize, NPIX = S * S, PGS = NPIX / 16;
-  THA4_DYN_LDS(smem);
-  const int lane = threadIdx.x & 63;
-  const int wave = uniform_i32(threadIdx.x >> 6);
-  char* ring = smem;
-  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * SLOT + wave * Cfg::Lds::kActBytesPerWave);
-
-  const int pg_first = (blockIdx.x * kWaves + wave) * PG;     // global pixel-group id (over the batch)
-  const int n = pg_first / PGS;                                  // PGS % (kWaves*PG) == 0: one frame per wave
-  int pix0[PG];
-  float px[PG], py[PG];
+constexpr int kPoseBiasBlock = 64;
+__global__ void __launch_bounds__(kPoseBiasBlock) posebias_kernel(StudentDev d) {
+  const int idx = blockIdx.x * kPoseBiasBlock + threadIdx.x;
+  const int n = blockIdx.y;
+  if (idx >= kPbStride) return;
+  int net, c, width;
+  if (idx < kPbL0) { net = 0; c = idx - kPbFace; width = kNBF * 16; }
+  else if (idx < kPbL1) { net = 1; c = idx - kPbL0; width = kNB0 * 16; }
+  else if (idx < kPbL2) { net = 2; c = idx - kPbL1; width = kNB1 * 16; }
+  else { net = 3; c = idx - kPbL2; width = kNB2 * 16; }
+  // wpose is zero-padded to kPose rows for every net (the face net only sees pose[0:39], mode_14.py:66),
+  // so all 45 loads are independent and issued up front: the kernel is pure load latency otherwise
+  const float* wp = d.wpose[net] + c;
+  const float* pose = d.pose + (size_t)n * kPose;
+  float s[3] = {d.bias1[net][c], 0.f, 0.f};
 #pragma unroll
-  for (int pg = 0; pg < PG; ++pg) {
-    pix0[pg] = ((pg_first + pg) % PGS) * 16;
-    px[pg] = d.pos128[(pix0[pg] % S) + (lane & 15)];
-    py[pg] = d.pos128[pix0[pg] / S];
-  }
+  for (int k = 0; k < kPose; ++k) s[k % 3] = fmaf(wp[(size_t)k * width], pose[k], s[k % 3]);
+  d.pbias[(size_t)n * kPbStride + idx] = s[0] + (s[1] + s[2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 1: face morpher (128x128): 41->128 (VALU, pose folded), 7 x 128->128, 128->4
+// ---------------------------------------------------------------------------------------------
+template <int NS, int MS, int PG, int CQ>
+struct FaceCfg {
+  static constexpr int kSlotPieces = CQ * kNBF > 8 ? CQ * kNBF : 8;
+  using G = Geo<NS, MS, PG, kNBF, kSlotPieces>;
+};
+
+template <int NS, int MS, int PG, int CQ>
+__global__ void __launch_bounds__(NS* MS * 64) face_kernel(StudentDev d) {
+  using G = typename FaceCfg<NS, MS, PG, CQ>::G;
+  constexpr int S = kFaceSize, NPIX = S * S;
+  THA4_DYN_LDS(smem);
+  const WaveCtx w = wave_ctx<G>();
+  char* ring = smem;
+  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * G::SLOT + w.ns * G::ACT_BYTES);
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_face);
   const float* bias = d.b_face;
   int slot = 0;
-  fetch_pieces<CQ * kNBF>(gw, ring, wave, lane);
-  first_layer_pos<kNBF, PG, kNBF>(d.wx[0], d.wy[0], d.pbias + (size_t)n * kPbStride + kPbFace, px, py, actv, lane);
+  fetch_pieces<CQ * kNBF, G::WAVES>(gw, ring, w.wave, w.lane);
+  first_layer_pos<G, kNBF>(d.wx[0], d.wy[0], d.pbias + (size_t)n * kPbStride + kPbFace, px, py, actv, w);
   __syncthreads();
 #pragma unroll 1
-  for (int l = 0; l < 6; ++l)
-    sine_layer<kNBF, kNBF, CQ, PG, kNBF, SLOT, CQ * kNBF>(gw, bias, ring, slot, actv, wave, lane);
-  sine_layer<kNBF, kNBF, CQ, PG, kNBF, SLOT, 8>(gw, bias, ring, slot, actv, wave, lane);
+  for (int l = 0; l < 6; ++l) sine_layer<G, kNBF, kNBF, CQ, CQ * kNBF>(gw, bias, ring, slot, actv, w);
+  sine_layer<G, kNBF, kNBF, CQ, 8>(gw, bias, ring, slot, actv, w);
   // last_linear 128 -> 4 (no nonlinearity, siren.py:87-91): one block, rows 0..3 live in lane group 0
   f32x4 acc[1][PG];
   zero_acc<1, PG>(acc);
-  gemm_stream<1, kNBF, kNBF, PG, kNBF, SLOT, 0>(gw, ring, slot, actv, acc, wave, lane);
-  if (lane < 16) {
+  gemm_stream<G, 1, 1, kNBF, kNBF, 0>(gw, ring, slot, actv, acc, w, 0, w.ms == 0);
+  if (w.ms == 0 && w.lane < 16) {
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias);
     float* fo = d.face + (size_t)n * 4 * NPIX;
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       const f32x4 v = acc[0][pg] + bb;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fo[(size_t)j * NPIX + pix0[pg] + lane] = v[j];
+      for (int j = 0; j < 4; ++j) fo[(size_t)j * NPIX + pix0[pg] + w.lane] = v[j];
     }
   }
 }
@@ -335,88 +416,68 @@ __global__ void __launch_bounds__(kBlock) face_kernel(StudentDev d) {
 // ---------------------------------------------------------------------------------------------
 // kernel 2: body level 0 (128x128): 47->360 (VALU, pose folded) ->360 ->180, then z1 = W10[:, :180] h0
 // ---------------------------------------------------------------------------------------------
-template <int PG, int CQA, int CQB>
-struct Level0Cfg {   // CQA: chunk of the 23-quad layers (23 is prime: 1 or 23); CQB: chunk of the 12-quad z layer
-  static constexpr int kP1 = CQA * kNB0, kP2 = CQA * kNB1, kP3 = CQB * kNB1;
-  static constexpr int kMax12 = kP1 > kP2 ? kP1 : kP2;
-  static constexpr int kSlot = (kMax12 > kP3 ? kMax12 : kP3) * 1024;
-  using Lds = LdsPlan<kSlot, PG, kNB0>;
+template <int NS, int MS, int PG, int CQB>
+struct Level0Cfg {   // the 23-quad layers stream one quad per chunk (23 is prime); CQB: chunk of the 12-quad z layer
+  static constexpr int kP1 = kNB0, kP2 = kNB1, kP3 = CQB * kNB1;
+  static constexpr int kSlotPieces = kP1 > kP3 ? kP1 : kP3;
+  using G = Geo<NS, MS, PG, kNB0, kSlotPieces>;
 };
 
-template <int PG, int CQA, int CQB>
-__global__ void __launch_bounds__(kBlock) level0_kernel(StudentDev d) {
-  using Cfg = Level0Cfg<PG, CQA, CQB>;
-  constexpr int SLOT = Cfg::kSlot;
-  constexpr int S = 128, NPIX = S * S, PGS = NPIX / 16;
+template <int NS, int MS, int PG, int CQB>
+__global__ void __launch_bounds__(NS* MS * 64) level0_kernel(StudentDev d) {
+  using Cfg = Level0Cfg<NS, MS, PG, CQB>;
+  using G = typename Cfg::G;
+  constexpr int S = 128, NPIX = S * S;
   THA4_DYN_LDS(smem);
-  const int lane = threadIdx.x & 63;
-  const int wave = uniform_i32(threadIdx.x >> 6);
+  const WaveCtx w = wave_ctx<G>();
   char* ring = smem;
-  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * SLOT + wave * Cfg::Lds::kActBytesPerWave);
-  const int pg_first = (blockIdx.x * kWaves + wave) * PG;
-  const int n = pg_first / PGS;
-  int pix0[PG];
+  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * G::SLOT + w.ns * G::ACT_BYTES);
+  int pix0[PG], X0[PG], Y[PG];
   float px[PG], py[PG];
-#pragma unroll
-  for (int pg = 0; pg < PG; ++pg) {
-    pix0[pg] = ((pg_first + pg) % PGS) * 16;
-    px[pg] = d.pos128[(pix0[pg] % S) + (lane & 15)];
-    py[pg] = d.pos128[pix0[pg] / S];
-  }
+  const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_l0);
   const float* bias = d.b_l0;
   int slot = 0;
-  fetch_pieces<Cfg::kP1>(gw, ring, wave, lane);
-  first_layer_pos<kNB0, PG, kNB0>(d.wx[1], d.wy[1], d.pbias + (size_t)n * kPbStride + kPbL0, px, py, actv, lane);
+  fetch_pieces<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
+  first_layer_pos<G, kNB0>(d.wx[1], d.wy[1], d.pbias + (size_t)n * kPbStride + kPbL0, px, py, actv, w);
   __syncthreads();
-  sine_layer<kNB0, kNB0, CQA, PG, kNB0, SLOT, Cfg::kP2>(gw, bias, ring, slot, actv, wave, lane);
-  sine_layer<kNB1, kNB0, CQA, PG, kNB0, SLOT, Cfg::kP3>(gw, bias, ring, slot, actv, wave, lane);
-  z_layer<kNB1, kNB1, CQB, PG, kNB0, SLOT>(gw, ring, slot, actv, d.z1 + (size_t)n * kNB1 * NPIX * 16, NPIX, pix0, wave, lane);
+  sine_layer<G, kNB0, kKQ0, 1, Cfg::kP2>(gw, bias, ring, slot, actv, w);
+  sine_layer<G, kNB1, kKQ0, 1, Cfg::kP3>(gw, bias, ring, slot, actv, w);
+  z_layer<G, kNB1, kNB1, CQB>(gw, ring, slot, actv, d.z1 + (size_t)n * kNB1 * NPIX * 16, NPIX, pix0, w);
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernel 3: body level 1 (256x256): up2(z1)+pos+pose -> sin ->180 ->90, then z2 = W20[:, :90] h1
 // ---------------------------------------------------------------------------------------------
-template <int PG, int CQA, int CQB>
+template <int NS, int MS, int PG, int CQA, int CQB>
 struct Level1Cfg {   // CQA: chunk of the 12-quad layers; CQB: chunk of the 6-quad z layer
   static constexpr int kP1 = CQA * kNB1, kP2 = CQA * kNB2, kP3 = CQB * kNB2;
-  static constexpr int kMax12 = kP1 > kP2 ? kP1 : kP2;
-  static constexpr int kSlot = (kMax12 > kP3 ? kMax12 : kP3) * 1024;
-  using Lds = LdsPlan<kSlot, PG, kNB1>;
+  static constexpr int kSlotPieces = kP1 > kP3 ? kP1 : kP3;
+  using G = Geo<NS, MS, PG, kNB1, kSlotPieces>;
 };
 
-template <int PG, int CQA, int CQB>
-__global__ void __launch_bounds__(kBlock) level1_kernel(StudentDev d) {
-  using Cfg = Level1Cfg<PG, CQA, CQB>;
-  constexpr int SLOT = Cfg::kSlot;
-  constexpr int S = 256, NPIX = S * S, PGS = NPIX / 16;
+template <int NS, int MS, int PG, int CQA, int CQB>
+__global__ void __launch_bounds__(NS* MS * 64) level1_kernel(StudentDev d) {
+  using Cfg = Level1Cfg<NS, MS, PG, CQA, CQB>;
+  using G = typename Cfg::G;
+  constexpr int S = 256, NPIX = S * S;
   THA4_DYN_LDS(smem);
-  const int lane = threadIdx.x & 63;
-  const int wave = uniform_i32(threadIdx.x >> 6);
+  const WaveCtx w = wave_ctx<G>();
   char* ring = smem;
-  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * SLOT + wave * Cfg::Lds::kActBytesPerWave);
-  const int pg_first = (blockIdx.x * kWaves + wave) * PG;
-  const int n = pg_first / PGS;
+  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * G::SLOT + w.ns * G::ACT_BYTES);
   int pix0[PG], X0[PG], Y[PG];
   float px[PG], py[PG];
-#pragma unroll
-  for (int pg = 0; pg < PG; ++pg) {
-    pix0[pg] = ((pg_first + pg) % PGS) * 16;
-    X0[pg] = pix0[pg] % S;
-    Y[pg] = pix0[pg] / S;
-    px[pg] = d.pos256[X0[pg] + (lane & 15)];
-    py[pg] = d.pos256[Y[pg]];
-  }
+  const int n = slot_pixels<G, S>(w, d.pos256, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_l1);
   const float* bias = d.b_l1;
   int slot = 0;
-  fetch_pieces<Cfg::kP1>(gw, ring, wave, lane);
-  first_layer_up<kNB1, PG, kNB1>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, d.wx[2], d.wy[2],
-                                 d.pbias + (size_t)n * kPbStride + kPbL1, X0, Y, px, py, actv, lane);
+  fetch_pieces<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
+  first_layer_up<G, kNB1>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, d.wx[2], d.wy[2],
+                          d.pbias + (size_t)n * kPbStride + kPbL1, X0, Y, px, py, actv, w);
   __syncthreads();
-  sine_layer<kNB1, kNB1, CQA, PG, kNB1, SLOT, Cfg::kP2>(gw, bias, ring, slot, actv, wave, lane);
-  sine_layer<kNB2, kNB1, CQA, PG, kNB1, SLOT, Cfg::kP3>(gw, bias, ring, slot, actv, wave, lane);
-  z_layer<kNB2, kNB2, CQB, PG, kNB1, SLOT>(gw, ring, slot, actv, d.z2 + (size_t)n * kNB2 * NPIX * 16, NPIX, pix0, wave, lane);
+  sine_layer<G, kNB1, kNB1, CQA, Cfg::kP2>(gw, bias, ring, slot, actv, w);
+  sine_layer<G, kNB2, kNB1, CQA, Cfg::kP3>(gw, bias, ring, slot, actv, w);
+  z_layer<G, kNB2, kNB2, CQB>(gw, ring, slot, actv, d.z2 + (size_t)n * kNB2 * NPIX * 16, NPIX, pix0, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,49 +491,39 @@ THA4_DEV float body_source(const float* img, const float* face, int c, int y, in
   return img[((size_t)c * kImg + y) * kImg + x];
 }
 
-template <int PG, int CQ>
+template <int NS, int MS, int PG, int CQ>
 struct Level2Cfg {
-  static constexpr int kSlot = (CQ * kNB2 > kNB2 ? CQ * kNB2 : kNB2) * 1024;
-  using Lds = LdsPlan<kSlot, PG, kNB2>;
+  static constexpr int kSlotPieces = CQ * kNB2;
+  using G = Geo<NS, MS, PG, kNB2, kSlotPieces>;
 };
 
-template <int PG, int CQ>
-__global__ void __launch_bounds__(kBlock) level2_kernel(StudentDev d) {
-  using Cfg = Level2Cfg<PG, CQ>;
-  constexpr int SLOT = Cfg::kSlot;
-  constexpr int S = kImg, NPIX = S * S, PGS = NPIX / 16;
+template <int NS, int MS, int PG, int CQ>
+__global__ void __launch_bounds__(NS* MS * 64) level2_kernel(StudentDev d) {
+  using G = typename Level2Cfg<NS, MS, PG, CQ>::G;
+  constexpr int S = kImg, NPIX = S * S;
   THA4_DYN_LDS(smem);
-  const int lane = threadIdx.x & 63;
-  const int wave = uniform_i32(threadIdx.x >> 6);
+  const WaveCtx w = wave_ctx<G>();
   char* ring = smem;
-  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * SLOT + wave * Cfg::Lds::kActBytesPerWave);
-  const int pg_first = (blockIdx.x * kWaves + wave) * PG;
-  const int n = pg_first / PGS;
+  f32x4* actv = reinterpret_cast<f32x4*>(smem + 2 * G::SLOT + w.ns * G::ACT_BYTES);
   int pix0[PG], X0[PG], Y[PG];
   float px[PG], py[PG];
-#pragma unroll
-  for (int pg = 0; pg < PG; ++pg) {
-    pix0[pg] = ((pg_first + pg) % PGS) * 16;
-    X0[pg] = pix0[pg] % S;
-    Y[pg] = pix0[pg] / S;
-    px[pg] = d.pos512[X0[pg] + (lane & 15)];
-    py[pg] = d.pos512[Y[pg]];
-  }
+  const int n = slot_pixels<G, S>(w, d.pos512, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_l2);
   const float* bias = d.b_l2;
   int slot = 0;
-  fetch_pieces<CQ * kNB2>(gw, ring, wave, lane);
-  first_layer_up<kNB2, PG, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
-                                 d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, actv, lane);
+  fetch_pieces<CQ * kNB2, G::WAVES>(gw, ring, w.wave, w.lane);
+  first_layer_up<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
+                          d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, actv, w);
   __syncthreads();
-  sine_layer<kNB2, kNB2, CQ, PG, kNB2, SLOT, CQ * kNB2>(gw, bias, ring, slot, actv, wave, lane);
-  sine_layer<kNB2, kNB2, CQ, PG, kNB2, SLOT, kNB2>(gw, bias, ring, slot, actv, wave, lane);
+  sine_layer<G, kNB2, kNB2, CQ, CQ * kNB2>(gw, bias, ring, slot, actv, w);
+  sine_layer<G, kNB2, kNB2, CQ, kNB2>(gw, bias, ring, slot, actv, w);
   // last_linear 90 -> 7: rows 0..3 (dx, dy, alpha, colour R) in lane group 0, rows 4..6 (G, B, A) in group 1
   f32x4 acc[1][PG];
   zero_acc<1, PG>(acc);
-  gemm_stream<1, kNB2, kNB2, PG, kNB2, SLOT, 0>(gw, ring, slot, actv, acc, wave, lane);
+  gemm_stream<G, 1, 1, kNB2, kNB2, 0>(gw, ring, slot, actv, acc, w, 0, w.ms == 0);
+  if (w.ms != 0) return;
 
-  const int p = lane & 15, g = lane >> 4;
+  const int p = w.lane & 15, g = w.lane >> 4;
   const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + g * 4);
   const float* img = d.image + (size_t)n * d.image_stride;
   const float* face = d.face + (size_t)n * 4 * kFaceSize * kFaceSize;
@@ -494,38 +545,49 @@ __global__ void __launch_bounds__(kBlock) level2_kernel(StudentDev d) {
     const float tx = ix - fx0, ty = iy - fy0;
     const float wnw = (1.0f - tx) * (1.0f - ty), wne = tx * (1.0f - ty), wsw = (1.0f - tx) * ty, wse = tx * ty;
     const int x1 = min(x0 + 1, S - 1), y1 = min(y0 + 1, S - 1);   // out-of-range taps only occur with weight 0
-    float w = body_source(img, face, g, y0, x0) * wnw;
-    w += body_source(img, face, g, y0, x1) * wne;
-    w += body_source(img, face, g, y1, x0) * wsw;
-    w += body_source(img, face, g, y1, x1) * wse;
-    const float blended = (1.0f - al) * w + al * col;            // siren_morpher_03.py:131
+    float wv = body_source(img, face, g, y0, x0) * wnw;
+    wv += body_source(img, face, g, y0, x1) * wne;
+    wv += body_source(img, face, g, y1, x0) * wsw;
+    wv += body_source(img, face, g, y1, x1) * wse;
+    const float blended = (1.0f - al) * wv + al * col;            // siren_morpher_03.py:131
     const size_t pix = (size_t)pix0[pg] + p;
     d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
-    if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = w;
+    if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = wv;
     if (d.out_alpha && g == 0) d.out_alpha[(size_t)n * NPIX + pix] = al;
     if (d.out_grid && g < 2) d.out_grid[((size_t)n * 2 + g) * NPIX + pix] = (g == 0 ? dx : dy);
   }
 }
 
-}  // namespace tha4
-
 // ---------------------------------------------------------------------------------------------
-// launch configuration shared by the C-ABI launcher and the CPU emulator tests
+// launch configuration shared by the C-ABI launcher and the CPU emulator tests.
+// Every knob can be overridden with -D at build time (tools/sweep builds variant libraries).
 // ---------------------------------------------------------------------------------------------
-namespace tha4 {
 namespace cfg {
-// pixel groups (16 px) per wave / K quads per streamed chunk, per kernel
-constexpr int kFacePG = 1, kFaceCQ = 2;
-constexpr int kL0PG = 1, kL0CQA = 1, kL0CQB = 2;
-constexpr int kL1PG = 2, kL1CQA = 2, kL1CQB = 3;
-constexpr int kL2PG = 4, kL2CQ = 3;
+#ifndef THA4_FACE_CFG
+#define THA4_FACE_CFG 4, 2, 1, 8        // NS, MS, PG, CQ   (whole layer per chunk: 1 barrier per layer)
+#endif
+#ifndef THA4_L0_CFG
+#define THA4_L0_CFG 4, 2, 1, 2          // NS, MS, PG, CQB
+#endif
+#ifndef THA4_L1_CFG
+#define THA4_L1_CFG 8, 1, 1, 2, 3       // NS, MS, PG, CQA, CQB
+#endif
+#ifndef THA4_L2_CFG
+#define THA4_L2_CFG 4, 1, 1, 2          // NS, MS, PG, CQ   (48 KiB LDS: 3 workgroups per CU run out of phase)
+#endif
+using FaceG = FaceCfg<THA4_FACE_CFG>::G;
+using L0G = Level0Cfg<THA4_L0_CFG>::G;
+using L1G = Level1Cfg<THA4_L1_CFG>::G;
+using L2G = Level2Cfg<THA4_L2_CFG>::G;
+#define THA4_FACE_KERNEL face_kernel<THA4_FACE_CFG>
+#define THA4_L0_KERNEL level0_kernel<THA4_L0_CFG>
+#define THA4_L1_KERNEL level1_kernel<THA4_L1_CFG>
+#define THA4_L2_KERNEL level2_kernel<THA4_L2_CFG>
 
-constexpr int kFaceLds = FaceCfg<kFacePG, kFaceCQ>::Lds::kBytes;
-constexpr int kL0Lds = Level0Cfg<kL0PG, kL0CQA, kL0CQB>::Lds::kBytes;
-constexpr int kL1Lds = Level1Cfg<kL1PG, kL1CQA, kL1CQB>::Lds::kBytes;
-constexpr int kL2Lds = Level2Cfg<kL2PG, kL2CQ>::Lds::kBytes;
-
-constexpr int blocks_for(int batch, int side, int pg) { return batch * (side * side / 16) / (kWaves * pg); }
+template <class G>
+constexpr int blocks_for(int batch, int side) { return batch * (side * side) / G::PX; }
+constexpr int posebias_blocks() { return (kPbStride + kPoseBiasBlock - 1) / kPoseBiasBlock; }
 }  // namespace cfg
+
 }  // namespace tha4

@@ -27,7 +27,8 @@ constexpr float kOmega = 30.0f;    // siren.py:17
 
 // channel widths and their padding to 16-row MFMA blocks ("blocks") / 16-channel K groups ("quads")
 constexpr int kCF = 128, kNBF = 8;    // face hidden width
-constexpr int kC0 = 360, kNB0 = 23;   // body level 0 hidden width (368 padded)
+constexpr int kC0 = 360, kNB0 = 24;   // body level 0 hidden width: 23 blocks, padded to 24 so two waves can split the rows
+constexpr int kKQ0 = 23;              // ... but only 23 input quads (368 channels) are ever contracted
 constexpr int kC1 = 180, kNB1 = 12;   // level 1 (192 padded)
 constexpr int kC2 = 90, kNB2 = 6;     // level 2 (96 padded)
 constexpr int kHeadC = 7;             // grid dx, dy, alpha, colour RGBA (siren_morpher_03.py:127-129)
@@ -37,7 +38,7 @@ constexpr int kPbFace = 0;
 constexpr int kPbL0 = kPbFace + kNBF * 16;
 constexpr int kPbL1 = kPbL0 + kNB0 * 16;
 constexpr int kPbL2 = kPbL1 + kNB1 * 16;
-constexpr int kPbStride = kPbL2 + kNB2 * 16;   // 784 floats per frame
+constexpr int kPbStride = kPbL2 + kNB2 * 16;   // 800 floats per frame
 
 // ---- MFMA-fragment-linear weight image --------------------------------------------------------
 // One linear layer  y[o] = sum_i W[o][i] x[i]  with O outputs (NB = ceil(O/16) blocks) and I inputs
@@ -85,23 +86,23 @@ struct StudentWeightsView {
 // pose-bias kernel).
 struct FirstLayerPack {
   std::vector<float> wx, wy, bias;   // [NB*16]
-  std::vector<float> wpose;          // [NB*16][P]
+  std::vector<float> wpose;          // [kPose][NB*16]  (pose-major: coalesced across output channels; rows >= P are zero)
   int P = 0;
 };
 
 inline FirstLayerPack pack_first(const LinearView& l, int F, int P, int NB) {
   FirstLayerPack r;
-  r.P = P;
+  r.P = kPose;   // rows beyond P stay zero: the pose-bias kernel always contracts all 45 pose slots
   r.wx.assign(NB * 16, 0.f);
   r.wy.assign(NB * 16, 0.f);
   r.bias.assign(NB * 16, 0.f);
-  r.wpose.assign((size_t)NB * 16 * P, 0.f);
+  r.wpose.assign((size_t)NB * 16 * kPose, 0.f);
   for (int o = 0; o < l.out_ch; ++o) {
     const float* row = l.weight + (size_t)o * l.in_ch;
     r.wx[o] = row[F];
     r.wy[o] = row[F + 1];
     r.bias[o] = l.bias[o];
-    for (int k = 0; k < P; ++k) r.wpose[(size_t)o * P + k] = row[F + 2 + k];
+    for (int k = 0; k < P; ++k) r.wpose[(size_t)k * NB * 16 + o] = row[F + 2 + k];
   }
   return r;
 }
@@ -116,12 +117,12 @@ inline std::vector<float> pad_bias(const LinearView& l, int NB) {
 struct StudentPacked {
   // weight streams: the layers of one kernel back to back, in execution order
   std::vector<float> w_face;   // 7 x [8x8] + [1x8]
-  std::vector<float> w_l0;     // [23x23] [12x23] + z1 layer [12x12]
+  std::vector<float> w_l0;     // [24x23] [12x23] + z1 layer [12x12]   (blocks x quads)
   std::vector<float> w_l1;     // [12x12] [6x12]  + z2 layer [6x6]
   std::vector<float> w_l2;     // [6x6] [6x6] + head [1x6]
   // biases of the streamed layers, concatenated in the same order (padded to blocks)
   std::vector<float> b_face;   // 7*128 + 16
-  std::vector<float> b_l0;     // 368 + 192          (z layers carry no bias)
+  std::vector<float> b_l0;     // 384 + 192          (z layers carry no bias)
   std::vector<float> b_l1;     // 192 + 96
   std::vector<float> b_l2;     // 96 + 96 + 16
   FirstLayerPack f_face, f_l0, f_l1, f_l2;
@@ -165,9 +166,9 @@ inline std::string pack_student(const StudentWeightsView& v, StudentPacked& p) {
   append_bias(p.b_face, v.face_last, 1);
   // level 0
   p.f_l0 = pack_first(v.body_sine[0][0], 0, kPose, kNB0);
-  append(p.w_l0, v.body_sine[0][1], 0, kC0, kNB0, kNB0);
+  append(p.w_l0, v.body_sine[0][1], 0, kC0, kNB0, kKQ0);
   append_bias(p.b_l0, v.body_sine[0][1], kNB0);
-  append(p.w_l0, v.body_sine[0][2], 0, kC0, kNB1, kNB0);
+  append(p.w_l0, v.body_sine[0][2], 0, kC0, kNB1, kKQ0);
   append_bias(p.b_l0, v.body_sine[0][2], kNB1);
   append(p.w_l0, v.body_sine[1][0], 0, kC1, kNB1, kNB1);   // z1 = W_{1,0}[:, 0:180] h0  (no bias)
   // level 1

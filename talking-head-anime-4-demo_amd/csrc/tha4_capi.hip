@@ -153,10 +153,10 @@ int tha4_student_create(const tha4_student_weights* weights, const tha4_position
   const size_t s_z1 = align_up(B * kNB1 * 128 * 128 * 16 * sizeof(float), 256);
   const size_t s_z2 = align_up(B * kNB2 * 256 * 256 * 16 * sizeof(float), 256);
   if (e == hipSuccess) e = hipMalloc((void**)&h->workspace, s_pb + s_face + s_z1 + s_z2);
-  if (e == hipSuccess) e = allow_lds(face_kernel<cfg::kFacePG, cfg::kFaceCQ>, cfg::kFaceLds);
-  if (e == hipSuccess) e = allow_lds(level0_kernel<cfg::kL0PG, cfg::kL0CQA, cfg::kL0CQB>, cfg::kL0Lds);
-  if (e == hipSuccess) e = allow_lds(level1_kernel<cfg::kL1PG, cfg::kL1CQA, cfg::kL1CQB>, cfg::kL1Lds);
-  if (e == hipSuccess) e = allow_lds(level2_kernel<cfg::kL2PG, cfg::kL2CQ>, cfg::kL2Lds);
+  if (e == hipSuccess) e = allow_lds(THA4_FACE_KERNEL, cfg::FaceG::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_L0_KERNEL, cfg::L0G::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_L1_KERNEL, cfg::L1G::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_L2_KERNEL, cfg::L2G::LDS);
   if (e != hipSuccess) {
     cleanup();
     return fail(THA4_ERR_HIP, std::string("tha4_student_create: ") + hipGetErrorString(e));
@@ -204,19 +204,19 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
 
   const bool t = h->timing && h->ev_valid;
   if (t) HIP_TRY(hipEventRecord(h->ev[0], s));
-  hipLaunchKernelGGL(posebias_kernel, dim3((kPbStride + kBlock - 1) / kBlock, batch), dim3(kBlock), 0, s, d);
+  hipLaunchKernelGGL(posebias_kernel, dim3(cfg::posebias_blocks(), batch), dim3(kPoseBiasBlock), 0, s, d);
   if (t) HIP_TRY(hipEventRecord(h->ev[1], s));
-  hipLaunchKernelGGL((face_kernel<cfg::kFacePG, cfg::kFaceCQ>), dim3(cfg::blocks_for(batch, 128, cfg::kFacePG)),
-                     dim3(kBlock), cfg::kFaceLds, s, d);
+  hipLaunchKernelGGL((THA4_FACE_KERNEL), dim3(cfg::blocks_for<cfg::FaceG>(batch, 128)), dim3(cfg::FaceG::THREADS),
+                     cfg::FaceG::LDS, s, d);
   if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
-  hipLaunchKernelGGL((level0_kernel<cfg::kL0PG, cfg::kL0CQA, cfg::kL0CQB>),
-                     dim3(cfg::blocks_for(batch, 128, cfg::kL0PG)), dim3(kBlock), cfg::kL0Lds, s, d);
+  hipLaunchKernelGGL((THA4_L0_KERNEL), dim3(cfg::blocks_for<cfg::L0G>(batch, 128)), dim3(cfg::L0G::THREADS),
+                     cfg::L0G::LDS, s, d);
   if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
-  hipLaunchKernelGGL((level1_kernel<cfg::kL1PG, cfg::kL1CQA, cfg::kL1CQB>),
-                     dim3(cfg::blocks_for(batch, 256, cfg::kL1PG)), dim3(kBlock), cfg::kL1Lds, s, d);
+  hipLaunchKernelGGL((THA4_L1_KERNEL), dim3(cfg::blocks_for<cfg::L1G>(batch, 256)), dim3(cfg::L1G::THREADS),
+                     cfg::L1G::LDS, s, d);
   if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
-  hipLaunchKernelGGL((level2_kernel<cfg::kL2PG, cfg::kL2CQ>), dim3(cfg::blocks_for(batch, 512, cfg::kL2PG)),
-                     dim3(kBlock), cfg::kL2Lds, s, d);
+  hipLaunchKernelGGL((THA4_L2_KERNEL), dim3(cfg::blocks_for<cfg::L2G>(batch, 512)), dim3(cfg::L2G::THREADS),
+                     cfg::L2G::LDS, s, d);
   if (t) {
     HIP_TRY(hipEventRecord(h->ev[5], s));
     h->ev_recorded = true;

@@ -90,11 +90,11 @@ float* emu_student_buffer(void* h, const char* name, int64_t* nfloats) {
 // number of workgroups of kernel k (0 posebias, 1 face, 2 level0, 3 level1, 4 level2) at batch 1
 int emu_student_grid(int kernel) {
   switch (kernel) {
-    case 0: return (kPbStride + kBlock - 1) / kBlock;
-    case 1: return cfg::blocks_for(1, 128, cfg::kFacePG);
-    case 2: return cfg::blocks_for(1, 128, cfg::kL0PG);
-    case 3: return cfg::blocks_for(1, 256, cfg::kL1PG);
-    case 4: return cfg::blocks_for(1, 512, cfg::kL2PG);
+    case 0: return cfg::posebias_blocks();
+    case 1: return cfg::blocks_for<cfg::FaceG>(1, 128);
+    case 2: return cfg::blocks_for<cfg::L0G>(1, 128);
+    case 3: return cfg::blocks_for<cfg::L1G>(1, 256);
+    case 4: return cfg::blocks_for<cfg::L2G>(1, 512);
   }
   return -1;
 }
@@ -105,11 +105,11 @@ int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
   if (grid < 0 || first_block < 0 || first_block + nblocks > grid) return -1;
   for (int b = first_block; b < first_block + nblocks; ++b) {
     switch (kernel) {
-      case 0: emu::run_block(posebias_kernel, dim3(grid, 1), dim3(b, 0), kBlock, 0, e->dev); break;
-      case 1: emu::run_block(face_kernel<cfg::kFacePG, cfg::kFaceCQ>, dim3(grid), dim3(b), kBlock, cfg::kFaceLds, e->dev); break;
-      case 2: emu::run_block(level0_kernel<cfg::kL0PG, cfg::kL0CQA, cfg::kL0CQB>, dim3(grid), dim3(b), kBlock, cfg::kL0Lds, e->dev); break;
-      case 3: emu::run_block(level1_kernel<cfg::kL1PG, cfg::kL1CQA, cfg::kL1CQB>, dim3(grid), dim3(b), kBlock, cfg::kL1Lds, e->dev); break;
-      case 4: emu::run_block(level2_kernel<cfg::kL2PG, cfg::kL2CQ>, dim3(grid), dim3(b), kBlock, cfg::kL2Lds, e->dev); break;
+      case 0: emu::run_block(posebias_kernel, dim3(grid, 1), dim3(b, 0), kPoseBiasBlock, 0, e->dev); break;
+      case 1: emu::run_block(THA4_FACE_KERNEL, dim3(grid), dim3(b), cfg::FaceG::THREADS, cfg::FaceG::LDS, e->dev); break;
+      case 2: emu::run_block(THA4_L0_KERNEL, dim3(grid), dim3(b), cfg::L0G::THREADS, cfg::L0G::LDS, e->dev); break;
+      case 3: emu::run_block(THA4_L1_KERNEL, dim3(grid), dim3(b), cfg::L1G::THREADS, cfg::L1G::LDS, e->dev); break;
+      case 4: emu::run_block(THA4_L2_KERNEL, dim3(grid), dim3(b), cfg::L2G::THREADS, cfg::L2G::LDS, e->dev); break;
     }
   }
   return 0;
@@ -117,8 +117,7 @@ int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
 
 // pixels [first, first+count) (row-major index at the kernel's resolution) covered by workgroup b
 void emu_student_block_pixels(int kernel, int block, int* first, int* count) {
-  const int pg = kernel == 1 ? cfg::kFacePG : kernel == 2 ? cfg::kL0PG : kernel == 3 ? cfg::kL1PG : cfg::kL2PG;
-  *count = kWaves * pg * 16;
+  *count = kernel == 1 ? cfg::FaceG::PX : kernel == 2 ? cfg::L0G::PX : kernel == 3 ? cfg::L1G::PX : cfg::L2G::PX;
   *first = block * (*count);
 }
 

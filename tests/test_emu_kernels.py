@@ -34,9 +34,10 @@ def test_posebias_kernel(ctx):
     pb = emu.buf("pbias")
     assert np.abs(pb[0:128] - it["pb_face"]).max() < 1e-6
     assert np.abs(pb[128:488] - it["pb0"]).max() < 1e-6
-    assert np.abs(pb[496:676] - it["pb1"]).max() < 1e-6
-    assert np.abs(pb[688:778] - it["pb2"]).max() < 1e-6
-    assert not pb[488:496].any() and not pb[676:688].any() and not pb[778:784].any()
+    assert np.abs(pb[512:692] - it["pb1"]).max() < 1e-6
+    assert np.abs(pb[704:794] - it["pb2"]).max() < 1e-6
+    assert pb.shape[0] == 800
+    assert not pb[488:512].any() and not pb[692:704].any() and not pb[794:800].any()
 
 
 def test_face_kernel_blocks(ctx, golden_weights):

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Build / run launch-geometry variants of libtha4_hip.so (tuning aid, not part of the product).
+
+  python tools/sweep.py build            # here (hipcc cross-compiles): variants -> build_variants/*.so
+  python tools/sweep.py run [--steps N]  # on the GPU box: bench every variant, print per-kernel ms
+
+Each variant overrides the -D knobs of csrc/siren_kernels.h (THA4_*_CFG, THA4_NO_PIPELINE).
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "talking-head-anime-4-demo_amd", "csrc")
+OUT = os.path.join(ROOT, "build_variants")
+
+VARIANTS = {
+    "default": [],
+    "x_nosin": ["-DTHA4_ABLATE_SIN"],
+    "x_nofetch": ["-DTHA4_ABLATE_FETCH"],
+    "x_nobarrier": ["-DTHA4_ABLATE_BARRIER"],
+    "x_nosin_nobar": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_BARRIER"],
+    "x_all": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_BARRIER", "-DTHA4_ABLATE_FETCH"],
+    "l2_pg2_72k": ["-DTHA4_L2_CFG=4,1,2,2"],
+    "l1_ms2": ["-DTHA4_L1_CFG=4,2,2,2,3"],
+}
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    for name, flags in VARIANTS.items():
+        out = os.path.join(OUT, f"libtha4_{name}.so")
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, "-I",
+               os.path.join(ROOT, "include")] + flags + [os.path.join(CSRC, "tha4_capi.hip"), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        print(name, "OK" if r.returncode == 0 else "FAILED\n" + r.stderr[-2000:])
+
+
+def run(steps):
+    rows = []
+    for name in VARIANTS:
+        lib = os.path.join(OUT, f"libtha4_{name}.so")
+        if not os.path.exists(lib):
+            continue
+        env = dict(os.environ, THA4_HIP_LIB=lib)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "100",
+                            "--cpu-seconds", "0", "--profile-frames", "50"], capture_output=True, text=True, env=env,
+                           timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print(name, "FAILED", r.stderr[-1500:])
+            continue
+        j = json.loads(line[-1])
+        km = j["roofline"]["kernel_ms"]
+        rows.append((name, j["value"], km))
+        print(f"{name:10s} fps {j['value']:8.1f}  " + "  ".join(f"{k} {v*1000:6.1f}us" for k, v in km.items()), flush=True)
+    return rows
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 600
+        run(steps)
