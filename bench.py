@@ -37,6 +37,11 @@ GFLOP_KERNEL = {"face": 3.947, "level0": 6.924, "level1": 11.726, "level2": 15.2
 # level's first layer: stated separately, never used for `roofline.achieved`.
 GFLOP_EXECUTED_FRAME = 27.46
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# HBM-side bytes per launch of each kernel from the PMC passes committed in profiles/r01_student_b1_profile.md
+# (FETCH_SIZE x 2 [gfx950 wide-read correction, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, KiB -> bytes).
+# bench.py cannot run rocprofv3 on itself, so this is the profiled value for the same command line.
+PMC_TRAFFIC_BYTES = {"face": (1921 * 2 + 256) * 1024, "level0": (4036 * 2 + 12288) * 1024,
+                     "level1": (27325 * 2 + 24576) * 1024, "level2": (17024 * 2 + 4096) * 1024}
 KERNEL_NAMES = ["posebias", "face", "level0", "level1", "level2"]
 
 POSE_LO = np.array([0.0] * 37 + [-1.0] * 7 + [0.0], dtype=np.float32)
@@ -165,7 +170,8 @@ def main():
         dom = max(GFLOP_KERNEL, key=lambda n: kernel_ms[n])
         achieved = GFLOP_KERNEL[dom] / kernel_ms[dom]            # GFLOP / ms = TFLOP/s
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": PMC_TRAFFIC_BYTES.get(dom), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_student_b1_profile.md)",
                     "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                     "frame_event_ms": round(whole / nprof, 4),
                     "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
