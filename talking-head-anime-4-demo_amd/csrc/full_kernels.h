@@ -1,0 +1,444 @@
+// gfx950 kernels for the full THA4 system (reference mode_07: conv encoder-decoders + diffusion-style U-Nets).
+//
+// Feature maps live in HBM in the "C16" layout  T[n][cb][pixel][16]  (cb = channel block of 16,
+// pixel = row-major y*W+x, zero padded channels).  A lane's 16-byte load at (cb, pixel, 4g) is exactly
+// the B fragment of v_mfma_f32_16x16x4_f32 for pixel column p = lane&15, k-steps 4g..4g+3, so the
+// implicit-GEMM convolution reads its im2col operand straight from L1/L2 with no LDS staging, applying
+// the producer's normalisation (per-(n,c) scale/shift), activation and x2 resampling on the fly.
+// Weights use the same fragment-linear image as the student (siren_layout.h), streamed through a 2-slot
+// LDS ring with global_load_lds.  Everything is exact fp32 (v_mfma_f32_16x16x4_f32).
+//
+// Reference ops covered (paths relative to /root/reference/src/tha4/nn):
+//   conv.py:103-177            conv3 / conv4 s2 / convT4 s2 (+ InstanceNorm + ReLU applied by the CONSUMER)
+//   resnet_block.py:52-67      residual add in the epilogue
+//   common/unet.py:33-62,154-165  nearest-up / avg-pool on both ResBlock branches, GroupNorm+FiLM+SiLU on load
+//   common/unet.py:192-239     attention (qkv/proj are 1-tap convs; core in attention_kernel)
+#pragma once
+#include "tha4_platform.h"
+
+namespace tha4 {
+
+enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
+enum : int { IN_DIRECT = 0, IN_UP2 = 1, IN_POOL2 = 2 };
+enum : int { SRC_TENSOR = 0, SRC_VECTOR = 1 };
+
+constexpr int kMaxTaps = 16;
+
+struct ConvSrc {
+  const float* data;    // SRC_TENSOR: C16 [n][cb][in_h*in_w][16];  SRC_VECTOR: [n][cb*16] (spatially constant)
+  const float* scale;   // [n][cb*16] or null (identity)
+  const float* shift;   // [n][cb*16] or null
+  int cb;               // channel blocks of this source
+  int kind;
+};
+
+struct ConvArgs {
+  ConvSrc src[2];
+  int nsrc;
+  int in_h, in_w;        // stored spatial size of the tensor sources
+  int in_mode;           // IN_DIRECT | IN_UP2 (virtual 2h x 2w, nearest) | IN_POOL2 (virtual h/2 x w/2, mean of 2x2); must equal the template INMODE
+  int act_in;            // applied after scale/shift, before zero padding / pooling
+  int ntaps;
+  int tap_dy[kMaxTaps], tap_dx[kMaxTaps];   // virtual input coord = tile coord * in_stride + d
+  int in_stride;
+  int tile_h, tile_w;    // grid of output positions computed by this launch (per frame)
+  int out_h, out_w;      // stored output size; output coord = tile * out_s + out_o
+  int out_sy, out_sx, out_oy, out_ox;
+  const float* w;        // packed [mtile][q][tap][TMB][64][4]
+  const float* bias;     // [nb*16] or null
+  const float* residual; // C16 like out, or null
+  const int* act_out;    // per-output-channel activation codes [nb*16] or null (none)
+  float* out;            // C16 [n][nb][out_h*out_w][16]
+  float* stats;          // partial sums [n][stats_tiles][nb*16][2] (sum, sum of squares) or null
+  int stats_tiles;       // tiles per frame in the stats buffer (several launches may fill one buffer: convT parity classes)
+  int stats_tile0;       // first tile index written by this launch
+  int nb;                // output channel blocks
+  int chunk_quads;       // input quads per streamed weight chunk
+  int batch;
+};
+
+THA4_DEV float apply_act(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  if (act == ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// raw operand of one (quad, tap) step for one pixel group (NV = 4 samples of the 2x2 window when pooling)
+template <int NV>
+struct RawFrag {
+  f32x4 v[NV];
+  bool valid;   // false: the tap falls into the zero padding
+};
+
+// Implicit-GEMM convolution.  Workgroup = 4 waves; each wave owns PG pixel groups (16 consecutive
+// pixels of the tile grid each) and computes TMB output blocks for them; blockIdx.x = pixel tile
+// (over the batch), blockIdx.y = output-channel tile.
+template <int TMB, int PG, int INMODE>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+  constexpr int NV = INMODE == IN_POOL2 ? 4 : 1;
+  using Raw = RawFrag<NV>;
+  THA4_DYN_LDS(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform_i32(threadIdx.x >> 6);
+  const int p = lane & 15, g4 = (lane >> 4) * 4;
+  const int tile_px = a.tile_h * a.tile_w;
+  const int pgs_per_frame = tile_px / 16;
+  const int wg_pgs = 4 * PG;
+  const int tiles_per_frame = pgs_per_frame / wg_pgs;
+  const int n = blockIdx.x / tiles_per_frame;
+  const int tile = blockIdx.x % tiles_per_frame;
+  const int mtile = blockIdx.y;
+  const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (INMODE == IN_POOL2 ? a.in_h / 2 : a.in_h);
+  const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (INMODE == IN_POOL2 ? a.in_w / 2 : a.in_w);
+  const int in_px = a.in_h * a.in_w;
+
+  int ty[PG], tx[PG];
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    const int pix = ((tile * 4 + wave) * PG + pg) * 16 + p;
+    ty[pg] = pix / a.tile_w;
+    tx[pg] = pix % a.tile_w;
+  }
+  int cbtot = 0;
+  for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
+  const int piece_per_quad = a.ntaps * TMB;                         // KiB of weights per input quad for this m-tile
+  const int slot_bytes = a.chunk_quads * piece_per_quad * 1024;
+  char* ring = smem;
+  float* red = reinterpret_cast<float*>(smem + 2 * slot_bytes);      // [4 waves][TMB*16][2]
+  const char* gw = reinterpret_cast<const char*>(a.w) + (size_t)mtile * cbtot * piece_per_quad * 1024;
+  const int nchunks = (cbtot + a.chunk_quads - 1) / a.chunk_quads;
+
+  auto fetch = [&](int chunk, int slot) {
+    const int q0 = chunk * a.chunk_quads;
+    const int nq = min(a.chunk_quads, cbtot - q0);
+    const int pieces = nq * piece_per_quad;
+    const char* g = gw + (size_t)q0 * piece_per_quad * 1024;
+    char* l = ring + slot * slot_bytes;
+    for (int pc = wave; pc < pieces; pc += 4) glds16(g + pc * 1024 + lane * 16, l + pc * 1024);
+  };
+
+  // operand fetch for global quad q (over the concatenated sources) and tap t
+  auto load_raw = [&](int q, int t, Raw (&r)[PG], f32x4& sc, f32x4& sh, bool new_quad) {
+    int s = 0, ql = q;
+    if (a.nsrc > 1 && q >= a.src[0].cb) { s = 1; ql = q - a.src[0].cb; }
+    const ConvSrc& S = a.src[s];
+    if (new_quad) {
+      if (S.scale) {
+        sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + g4);
+        sh = *reinterpret_cast<const f32x4*>(S.shift + ((size_t)n * S.cb + ql) * 16 + g4);
+      } else {
+        sc = f32x4{1.f, 1.f, 1.f, 1.f};
+        sh = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      const int vy = ty[pg] * a.in_stride + a.tap_dy[t];
+      const int vx = tx[pg] * a.in_stride + a.tap_dx[t];
+      const bool ok = (unsigned)vy < (unsigned)vh && (unsigned)vx < (unsigned)vw;
+      const int cy = min(max(vy, 0), vh - 1), cx = min(max(vx, 0), vw - 1);
+      r[pg].valid = ok;
+      if (S.kind == SRC_VECTOR) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[pg].v[i] = *reinterpret_cast<const f32x4*>(S.data + ((size_t)n * S.cb + ql) * 16 + g4);
+      } else {
+        const float* base = S.data + (((size_t)n * S.cb + ql) * in_px) * 16 + g4;
+        if (INMODE == IN_DIRECT) {
+          r[pg].v[0] = *reinterpret_cast<const f32x4*>(base + ((size_t)cy * a.in_w + cx) * 16);
+        } else if (INMODE == IN_UP2) {
+          r[pg].v[0] = *reinterpret_cast<const f32x4*>(base + ((size_t)(cy >> 1) * a.in_w + (cx >> 1)) * 16);
+        } else {
+          const float* b00 = base + ((size_t)(2 * cy) * a.in_w + 2 * cx) * 16;
+          r[pg].v[0] = *reinterpret_cast<const f32x4*>(b00);
+          r[pg].v[NV > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(b00 + 16);
+          r[pg].v[NV > 1 ? 2 : 0] = *reinterpret_cast<const f32x4*>(b00 + (size_t)a.in_w * 16);
+          r[pg].v[NV > 1 ? 3 : 0] = *reinterpret_cast<const f32x4*>(b00 + (size_t)a.in_w * 16 + 16);
+        }
+      }
+    }
+  };
+
+  auto finish = [&](const Raw& r, const f32x4& sc, const f32x4& sh) -> f32x4 {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v;
+      if (NV == 4) {   // AvgPool2d(2,2) of the activated tensor (unet.py:58; ATen sums the window then divides)
+        v = ((apply_act(fmaf(r.v[0][j], sc[j], sh[j]), a.act_in) + apply_act(fmaf(r.v[NV > 1 ? 1 : 0][j], sc[j], sh[j]), a.act_in)) +
+             (apply_act(fmaf(r.v[NV > 1 ? 2 : 0][j], sc[j], sh[j]), a.act_in) + apply_act(fmaf(r.v[NV > 1 ? 3 : 0][j], sc[j], sh[j]), a.act_in))) * 0.25f;
+      } else {
+        v = apply_act(fmaf(r.v[0][j], sc[j], sh[j]), a.act_in);
+      }
+      o[j] = r.valid ? v : 0.0f;
+    }
+    return o;
+  };
+
+  f32x4 acc[TMB][PG];
+#pragma unroll
+  for (int b = 0; b < TMB; ++b)
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(0, 0);
+  Raw nxt[PG];
+  f32x4 sc_n, sh_n;
+  load_raw(0, 0, nxt, sc_n, sh_n, true);
+  __syncthreads();
+  int slot = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) fetch(c + 1, slot ^ 1);
+    const int q0 = c * a.chunk_quads;
+    const int nq = min(a.chunk_quads, cbtot - q0);
+    const f32x4* wv = reinterpret_cast<const f32x4*>(ring + slot * slot_bytes) + lane;
+    for (int qq = 0; qq < nq; ++qq) {
+      for (int t = 0; t < a.ntaps; ++t) {
+        Raw cur[PG];
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) cur[pg] = nxt[pg];
+        const f32x4 sc = sc_n, sh = sh_n;
+        // prefetch the operand of the next (quad, tap) step under this step's MFMAs
+        int nt = t + 1, nqg = q0 + qq;
+        bool newq = false;
+        if (nt == a.ntaps) { nt = 0; nqg += 1; newq = true; }
+        if (nqg < cbtot) load_raw(nqg, nt, nxt, sc_n, sh_n, newq);
+        f32x4 bf[PG];
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) bf[pg] = finish(cur[pg], sc, sh);
+        const f32x4* wt = wv + (size_t)((qq * a.ntaps + t) * TMB) * 64;
+#pragma unroll
+        for (int b = 0; b < TMB; ++b) {
+          const f32x4 av = wt[b * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16(av[j], bf[pg][j], acc[b][pg]);
+        }
+      }
+    }
+    __syncthreads();
+    slot ^= 1;
+  }
+
+  // epilogue: bias, residual, activation, store, deterministic per-tile statistics
+  const int out_px = a.out_h * a.out_w;
+  float ssum[TMB][4], ssq[TMB][4];
+#pragma unroll
+  for (int b = 0; b < TMB; ++b) {
+    const int bo = mtile * TMB + b;
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[b][j] = 0.f; ssq[b][j] = 0.f; }
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      const int oy = ty[pg] * a.out_sy + a.out_oy, ox = tx[pg] * a.out_sx + a.out_ox;
+      const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
+      f32x4 v = acc[b][pg] + bias;
+      if (a.residual) v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
+      if (a.act_out) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
+      }
+      *reinterpret_cast<f32x4*>(a.out + off) = v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ssum[b][j] += v[j]; ssq[b][j] = fmaf(v[j], v[j], ssq[b][j]); }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = ssum[b][j], q = ssq[b][j];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          s += lane_read(s, lane ^ m);
+          q += lane_read(q, lane ^ m);
+        }
+        if (p == 0) {
+          red[((wave * TMB + b) * 16 + g4 + j) * 2 + 0] = s;
+          red[((wave * TMB + b) * 16 + g4 + j) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TMB * 16; i += 256) {
+      float s = 0.f, q = 0.f;
+      for (int wv2 = 0; wv2 < 4; ++wv2) {
+        s += red[((wv2 * TMB) * 16 + i) * 2 + 0];
+        q += red[((wv2 * TMB) * 16 + i) * 2 + 1];
+      }
+      float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + mtile * TMB) * 16 + i) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// normalisation finalize: per-tile partial sums -> per-(n, channel) scale/shift for the consumer.
+//   groups == 0 : InstanceNorm2d(affine, eps)            (normalization.py:90-95)
+//   groups  > 0 : GroupNorm(groups, eps) over the CONCATENATION of up to two tensors (unet.py:65-66),
+//                 optionally followed by two FiLM stages  h*(1+s)+b  (unet.py:90-97,157-163)
+// One workgroup per frame; fixed summation order, fp64 moments.
+// ---------------------------------------------------------------------------------------------
+struct NormArgs {
+  const float* stats[2];   // partial sums [n][tiles][cb*16][2]
+  int tiles[2], cb[2];
+  int nsrc;
+  int channels;            // real channel count of the concatenation (<= total padded)
+  int groups;
+  float inv_count;         // 1 / (pixels per channel)
+  float eps;
+  const float* gamma;      // [channels]
+  const float* beta;
+  const float* film0;      // [n][2*channels] (scale | shift) or null
+  const float* film1;
+  float* scale[2];         // outputs per source, [n][cb*16]
+  float* shift[2];
+};
+
+__global__ void __launch_bounds__(256) norm_finalize_kernel(NormArgs a) {
+  THA4_DYN_LDS(smem);
+  double* csum = reinterpret_cast<double*>(smem);            // [ctot]
+  double* csq = csum + (a.cb[0] + (a.nsrc > 1 ? a.cb[1] : 0)) * 16;
+  const int n = blockIdx.x;
+  const int c0 = a.cb[0] * 16;
+  const int ctot = c0 + (a.nsrc > 1 ? a.cb[1] * 16 : 0);
+  for (int c = threadIdx.x; c < ctot; c += 256) {
+    const int s = c < c0 ? 0 : 1;
+    const int cl = c - (s ? c0 : 0);
+    const int cw = a.cb[s] * 16;
+    const float* ps = a.stats[s] + ((size_t)n * a.tiles[s] * cw + cl) * 2;
+    double su = 0.0, sq = 0.0;
+    for (int t = 0; t < a.tiles[s]; ++t) {
+      su += (double)ps[(size_t)t * cw * 2];
+      sq += (double)ps[(size_t)t * cw * 2 + 1];
+    }
+    csum[c] = su;
+    csq[c] = sq;
+  }
+  __syncthreads();
+  // logical channel index of padded channel c: source 0 holds channels [0, C0real), source 1 the rest.
+  // Both sources are exact multiples of 16 whenever two are concatenated (unet.py skip widths).
+  for (int c = threadIdx.x; c < ctot; c += 256) {
+    const int s = c < c0 ? 0 : 1;
+    const int cl = c - (s ? c0 : 0);
+    float sc = 0.f, sh = 0.f;
+    if (c < a.channels) {
+      double mean, var;
+      if (a.groups == 0) {
+        mean = csum[c] * a.inv_count;
+        var = csq[c] * a.inv_count - mean * mean;
+      } else {
+        const int gs = a.channels / a.groups;
+        const int gi = c / gs;
+        double su = 0.0, sq = 0.0;
+        for (int k = gi * gs; k < (gi + 1) * gs; ++k) { su += csum[k]; sq += csq[k]; }
+        mean = su * a.inv_count / gs;
+        var = sq * a.inv_count / gs - mean * mean;
+      }
+      const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)a.eps);
+      double k = (double)a.gamma[c] * rstd;
+      double b = (double)a.beta[c] - mean * k;
+      if (a.film0) {
+        const double s0 = a.film0[(size_t)n * 2 * a.channels + c], b0 = a.film0[(size_t)n * 2 * a.channels + a.channels + c];
+        k *= (1.0 + s0); b = b * (1.0 + s0) + b0;
+      }
+      if (a.film1) {
+        const double s1 = a.film1[(size_t)n * 2 * a.channels + c], b1 = a.film1[(size_t)n * 2 * a.channels + a.channels + c];
+        k *= (1.0 + s1); b = b * (1.0 + s1) + b1;
+      }
+      sc = (float)k;
+      sh = (float)b;
+    }
+    a.scale[s][(size_t)n * a.cb[s] * 16 + cl] = sc;
+    a.shift[s][(size_t)n * a.cb[s] * 16 + cl] = sh;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense layers (cond/time embeddings, FiLM projections): y[n][r] = act_out(b[r] + W[r,:] . act_in(x[n,:]))
+// one wave per output row (unet.py:137-146, 443-452)
+// ---------------------------------------------------------------------------------------------
+struct GemvArgs {
+  const float* w;      // [rows][k] row-major
+  const float* bias;   // [rows]
+  const float* x;      // [n][k]
+  float* y;            // [n][rows]
+  int rows, k;
+  int act_in, act_out;
+};
+
+__global__ void __launch_bounds__(256) gemv_kernel(GemvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.y;
+  if (row >= a.rows) return;
+  const float* w = a.w + (size_t)row * a.k;
+  const float* x = a.x + (size_t)n * a.k;
+  float s = 0.f;
+  for (int i = lane; i < a.k; i += 64) s = fmaf(w[i], apply_act(x[i], a.act_in), s);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += lane_read(s, lane ^ m);
+  if (lane == 0) a.y[(size_t)n * a.rows + row] = apply_act(s + a.bias[row], a.act_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention core (unet.py:192-202, new attention order): per (frame, head) workgroup, 256 tokens,
+// head dim 32.  qkv in C16 [n][3C/16][256][16]; out C16 [n][C/16][256][16].  One thread per query
+// token; K/V broadcast from LDS.  (0.4 GFLOP per network: VALU is adequate.)
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const float* qkv;
+  float* out;
+  int channels;   // C (=256)
+  int heads;      // 8
+  int tokens;     // 256
+};
+
+__global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
+  THA4_DYN_LDS(smem);
+  const int ch = a.channels / a.heads;     // 32
+  const int L = a.tokens;
+  float* ks = reinterpret_cast<float*>(smem);   // [L][ch]
+  float* vs = ks + L * ch;                       // [L][ch]
+  const int n = blockIdx.y, h = blockIdx.x, t = threadIdx.x;
+  const int cbq = a.channels / 16;
+  const float scale = 1.0f / sqrtf(sqrtf((float)ch));
+  auto at = [&](int c, int tok) -> float {   // channel c of the qkv tensor
+    return a.qkv[(((size_t)n * 3 * cbq + (c >> 4)) * L + tok) * 16 + (c & 15)];
+  };
+  float q[32];
+  for (int c = 0; c < ch; ++c) {
+    q[c] = at(h * ch + c, t) * scale;
+    ks[t * ch + c] = at(a.channels + h * ch + c, t) * scale;
+    vs[t * ch + c] = at(2 * a.channels + h * ch + c, t);
+  }
+  __syncthreads();
+  float m = -3.0e38f;
+  for (int s = 0; s < L; ++s) {
+    float d = 0.f;
+    for (int c = 0; c < ch; ++c) d = fmaf(q[c], ks[s * ch + c], d);
+    m = fmaxf(m, d);
+  }
+  float o[32];
+  for (int c = 0; c < ch; ++c) o[c] = 0.f;
+  float den = 0.f;
+  for (int s = 0; s < L; ++s) {
+    float d = 0.f;
+    for (int c = 0; c < ch; ++c) d = fmaf(q[c], ks[s * ch + c], d);
+    const float e = expf(d - m);
+    den += e;
+    for (int c = 0; c < ch; ++c) o[c] = fmaf(e, vs[s * ch + c], o[c]);
+  }
+  const float inv = 1.0f / den;
+  for (int c = 0; c < ch; ++c) {
+    const int cc = h * ch + c;
+    a.out[(((size_t)n * cbq + (cc >> 4)) * L + t) * 16 + (cc & 15)] = o[c] * inv;
+  }
+}
+
+}  // namespace tha4

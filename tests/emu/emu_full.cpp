@@ -1,0 +1,155 @@
+// CPU emulation harness for the full-model kernels (TEST INFRASTRUCTURE ONLY): runs conv_mfma /
+// norm_finalize / gemv / attention workgroup by workgroup on host buffers for tests/test_emu_full.py.
+#define THA4_EMU 1
+#include "full_kernels.h"
+#include "full_layout.h"
+
+using namespace tha4;
+
+extern "C" {
+
+// Generic convolution driver.  All tensors NCHW on the Python side; converted to C16 here.
+//  kind: 0 conv kxk stride 1 'same', 1 conv 4x4 stride 2 pad 1, 2 convT 4x4 stride 2 pad 1
+//  x0: [n][c0][h][w]; x1: optional second source [n][c1][h][w] or, if vec1 != 0, a vector [n][c1]
+//  scale/shift: optional per (n, channel) over the concatenation [n][c0+c1]
+//  returns out [n][cout][oh][ow] and stats sums [n][cout][2] (reduced over tiles on the host)
+int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, int c0, int c1, int vec1, int h, int w,
+             const float* x0, const float* x1, const float* scale, const float* shift, const float* weight, int cout,
+             const float* bias, const float* residual, const int* act_out, int chunk_quads, float* out, float* stats_out) {
+  const int cin = c0 + c1;
+  const int cb0 = (c0 + 15) / 16, cb1 = (c1 + 15) / 16;
+  const int vh = in_mode == IN_UP2 ? 2 * h : (in_mode == IN_POOL2 ? h / 2 : h);
+  const int vw = in_mode == IN_UP2 ? 2 * w : (in_mode == IN_POOL2 ? w / 2 : w);
+  int oh, ow, th, tw, nclass = 1;
+  if (kind == 0) { oh = vh; ow = vw; th = oh; tw = ow; }
+  else if (kind == 1) { oh = vh / 2; ow = vw / 2; th = oh; tw = ow; }
+  else { oh = vh * 2; ow = vw * 2; th = vh; tw = vw; nclass = 4; }
+  const int nb = (cout + 15) / 16;
+  const int px = h * w, opx = oh * ow;
+  std::vector<float> X0((size_t)n * cb0 * px * 16), X1;
+  for (int i = 0; i < n; ++i) nchw_to_c16(x0 + (size_t)i * c0 * px, c0, px, X0.data() + (size_t)i * cb0 * px * 16);
+  std::vector<float> S0, H0, S1, H1;
+  auto split = [&](const float* v, std::vector<float>& a, std::vector<float>& b) {
+    a.assign((size_t)n * cb0 * 16, 0.f);
+    b.assign((size_t)n * cb1 * 16, 0.f);
+    for (int i = 0; i < n; ++i) {
+      for (int c = 0; c < c0; ++c) a[(size_t)i * cb0 * 16 + c] = v[(size_t)i * cin + c];
+      for (int c = 0; c < c1; ++c) b[(size_t)i * cb1 * 16 + c] = v[(size_t)i * cin + c0 + c];
+    }
+  };
+  std::vector<float> sc0, sc1, sh0, sh1;
+  if (scale) { split(scale, sc0, sc1); split(shift, sh0, sh1); }
+  if (c1 > 0) {
+    if (vec1) {
+      X1.assign((size_t)n * cb1 * 16, 0.f);
+      for (int i = 0; i < n; ++i)
+        for (int c = 0; c < c1; ++c) X1[(size_t)i * cb1 * 16 + c] = x1[(size_t)i * c1 + c];
+    } else {
+      X1.resize((size_t)n * cb1 * px * 16);
+      for (int i = 0; i < n; ++i) nchw_to_c16(x1 + (size_t)i * c1 * px, c1, px, X1.data() + (size_t)i * cb1 * px * 16);
+    }
+  }
+  std::vector<float> R;
+  if (residual) {
+    R.resize((size_t)n * nb * opx * 16);
+    for (int i = 0; i < n; ++i) nchw_to_c16(residual + (size_t)i * cout * opx, cout, opx, R.data() + (size_t)i * nb * opx * 16);
+  }
+  std::vector<float> B((size_t)nb * 16, 0.f);
+  if (bias) std::memcpy(B.data(), bias, sizeof(float) * cout);
+  std::vector<int> A((size_t)nb * 16, 0);
+  if (act_out) std::memcpy(A.data(), act_out, sizeof(int) * cout);
+  std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
+  const int tiles_per_class = (th * tw / 16) / (4 * pg);
+  if (tiles_per_class * 4 * pg * 16 != th * tw) return -2;
+  const int stats_tiles = tiles_per_class * nclass;
+  std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
+  std::vector<ChannelSegment> segs = {{0, c0}};
+  if (c1 > 0) segs.push_back({c0, c1});
+  const int mtiles = (nb + tmb - 1) / tmb;
+  if (mtiles * tmb != nb) return -3;
+  for (int cls = 0; cls < nclass; ++cls) {
+    ConvGeom g = kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1));
+    std::vector<float> P = pack_conv_weight(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb);
+    ConvArgs a{};
+    a.src[0] = ConvSrc{X0.data(), scale ? sc0.data() : nullptr, scale ? sh0.data() : nullptr, cb0, SRC_TENSOR};
+    a.nsrc = 1;
+    if (c1 > 0) {
+      a.src[1] = ConvSrc{X1.data(), scale ? sc1.data() : nullptr, scale ? sh1.data() : nullptr, cb1, vec1 ? SRC_VECTOR : SRC_TENSOR};
+      a.nsrc = 2;
+    }
+    a.in_h = h; a.in_w = w; a.in_mode = in_mode; a.act_in = act_in;
+    a.ntaps = g.ntaps;
+    for (int t = 0; t < g.ntaps; ++t) { a.tap_dy[t] = g.dy[t]; a.tap_dx[t] = g.dx[t]; }
+    a.in_stride = g.in_stride;
+    a.tile_h = th; a.tile_w = tw; a.out_h = oh; a.out_w = ow;
+    a.out_sy = g.out_sy; a.out_sx = g.out_sx; a.out_oy = g.out_oy; a.out_ox = g.out_ox;
+    a.w = P.data(); a.bias = bias ? B.data() : nullptr; a.residual = residual ? R.data() : nullptr;
+    a.act_out = act_out ? A.data() : nullptr; a.out = O.data(); a.stats = ST.data();
+    a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
+    a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
+    const size_t lds = 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
+    dim3 grid(n * tiles_per_class, mtiles);
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+#define RUN(TM, PGV)                                                                                               \
+  if (tmb == TM && pg == PGV) {                                                                                     \
+    if (in_mode == IN_DIRECT) emu::run_block(conv_mfma_kernel<TM, PGV, IN_DIRECT>, grid, dim3(bx, by), 256, lds, a); \
+    else if (in_mode == IN_UP2) emu::run_block(conv_mfma_kernel<TM, PGV, IN_UP2>, grid, dim3(bx, by), 256, lds, a);  \
+    else emu::run_block(conv_mfma_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by), 256, lds, a);                       \
+  }
+        RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
+#undef RUN
+      }
+  }
+  for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * nb * opx * 16, cout, opx, out + (size_t)i * cout * opx);
+  if (stats_out)
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < cout; ++c) {
+        double s = 0, q = 0;
+        for (int t = 0; t < stats_tiles; ++t) {
+          s += ST[((((size_t)i * stats_tiles + t) * nb * 16) + c) * 2 + 0];
+          q += ST[((((size_t)i * stats_tiles + t) * nb * 16) + c) * 2 + 1];
+        }
+        stats_out[((size_t)i * cout + c) * 2 + 0] = (float)s;
+        stats_out[((size_t)i * cout + c) * 2 + 1] = (float)q;
+      }
+  return 0;
+}
+
+// norm finalize: stats partials given as [n][tiles][cb*16][2] per source; returns scale/shift [n][cb*16] per source
+int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float* st1, int tiles1, int cb1, int channels,
+             int groups, float inv_count, float eps, const float* gamma, const float* beta, const float* film0,
+             const float* film1, float* scale0, float* shift0, float* scale1, float* shift1) {
+  NormArgs a{};
+  a.stats[0] = st0; a.tiles[0] = tiles0; a.cb[0] = cb0;
+  a.stats[1] = st1; a.tiles[1] = tiles1; a.cb[1] = cb1;
+  a.nsrc = nsrc; a.channels = channels; a.groups = groups; a.inv_count = inv_count; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.film0 = film0; a.film1 = film1;
+  a.scale[0] = scale0; a.shift[0] = shift0; a.scale[1] = scale1; a.shift[1] = shift1;
+  const size_t lds = (size_t)(cb0 + (nsrc > 1 ? cb1 : 0)) * 16 * 2 * sizeof(double);
+  for (int i = 0; i < n; ++i) emu::run_block(norm_finalize_kernel, dim3(n), dim3(i), 256, lds, a);
+  return 0;
+}
+
+int emu_gemv(int n, int rows, int k, const float* w, const float* bias, const float* x, int act_in, int act_out, float* y) {
+  GemvArgs a{w, bias, x, y, rows, k, act_in, act_out};
+  dim3 grid((rows + 3) / 4, n);
+  for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned bx = 0; bx < grid.x; ++bx) emu::run_block(gemv_kernel, grid, dim3(bx, by), 256, 0, a);
+  return 0;
+}
+
+// qkv NCHW-like [n][3C][L]; out [n][C][L]
+int emu_attention(int n, int channels, int heads, int tokens, const float* qkv, float* out) {
+  const int cb3 = 3 * channels / 16, cb = channels / 16;
+  std::vector<float> Q((size_t)n * cb3 * tokens * 16), O((size_t)n * cb * tokens * 16, 0.f);
+  for (int i = 0; i < n; ++i) nchw_to_c16(qkv + (size_t)i * 3 * channels * tokens, 3 * channels, tokens, Q.data() + (size_t)i * cb3 * tokens * 16);
+  AttnArgs a{Q.data(), O.data(), channels, heads, tokens};
+  const size_t lds = (size_t)2 * tokens * (channels / heads) * sizeof(float);
+  for (int i = 0; i < n; ++i)
+    for (int h = 0; h < heads; ++h) emu::run_block(attention_kernel, dim3(heads, n), dim3(h, i), tokens, lds, a);
+  for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * cb * tokens * 16, channels, tokens, out + (size_t)i * channels * tokens);
+  return 0;
+}
+
+}  // extern "C"

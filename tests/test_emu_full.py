@@ -1,0 +1,197 @@
+"""CPU tests of the full-model kernels (csrc/full_kernels.h compiled against the SIMT emulator)
+versus torch fp64 references of the same ops: implicit-GEMM conv (3x3 / 1x1 / 4x4 s2 / convT 4x4 s2,
+fused input norm + activation + nearest-up / avg-pool, concatenated and broadcast-vector sources,
+bias / residual / per-channel activation epilogue, per-tile statistics), norm finalize (InstanceNorm,
+GroupNorm over a concatenation, FiLM folding), gemv and the attention core."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3, "tanh": 4}
+fp = C.POINTER(C.c_float)
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    import __graft_entry__ as g
+    g.build_emulator_full()
+    L = C.CDLL(os.path.join(HERE, "emu", "libtha4_emu_full.so"))
+    return L
+
+
+def P(a):
+    return None if a is None else a.ctypes.data_as(fp)
+
+
+def torch_act(x, name):
+    return {"none": lambda v: v, "relu": F.relu, "silu": F.silu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[name](x)
+
+
+def run_conv(lib, kind, k, tmb, pg, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out, chunk_quads):
+    n, c0, h, w = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    cout = weight.shape[1] if kind == 2 else weight.shape[0]
+    vh = h * 2 if in_mode == 1 else (h // 2 if in_mode == 2 else h)
+    vw = w * 2 if in_mode == 1 else (w // 2 if in_mode == 2 else w)
+    oh, ow = (vh, vw) if kind == 0 else ((vh // 2, vw // 2) if kind == 1 else (vh * 2, vw * 2))
+    out = np.zeros((n, cout, oh, ow), np.float32)
+    stats = np.zeros((n, cout, 2), np.float32)
+    ao = None if act_out is None else np.ascontiguousarray(act_out, np.int32)
+    rc = lib.emu_conv(kind, k, tmb, pg, in_mode, ACT[act_in], n, c0, c1, int(vec1), h, w, P(x0), P(x1), P(scale), P(shift),
+                      P(weight), cout, P(bias), P(residual), None if ao is None else ao.ctypes.data_as(C.POINTER(C.c_int)),
+                      chunk_quads, P(out), P(stats))
+    assert rc == 0, rc
+    return out, stats
+
+
+def ref_conv(kind, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out):
+    t = lambda a: None if a is None else torch.from_numpy(a).double()
+    x = t(x0)
+    if x1 is not None:
+        xx1 = t(x1)
+        if vec1:
+            xx1 = xx1[:, :, None, None].expand(-1, -1, x.shape[2], x.shape[3])
+        x = torch.cat([x, xx1], dim=1)
+    if scale is not None:
+        x = x * t(scale)[:, :, None, None] + t(shift)[:, :, None, None]
+    x = torch_act(x, act_in)
+    if in_mode == 1:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    elif in_mode == 2:
+        x = F.avg_pool2d(x, 2, 2)
+    W = t(weight)
+    if kind == 0:
+        y = F.conv2d(x, W, t(bias), padding=W.shape[2] // 2)
+    elif kind == 1:
+        y = F.conv2d(x, W, t(bias), stride=2, padding=1)
+    else:
+        y = F.conv_transpose2d(x, W, t(bias), stride=2, padding=1)
+    if residual is not None:
+        y = y + t(residual)
+    if act_out is not None:
+        names = {v: k for k, v in ACT.items()}
+        y = torch.stack([torch_act(y[:, c], names[int(act_out[c])]) for c in range(y.shape[1])], dim=1)
+    return y.numpy()
+
+
+CASES = [
+    # kind k tmb pg in_mode act_in  c0  c1  vec  h   w  cout bias res  actout  scale chunk
+    (0, 3, 2, 1, 0, "relu", 20, 0, False, 8, 16, 32, True, True, False, True, 2),     # conv3 + IN/ReLU input + residual
+    (0, 3, 4, 2, 0, "silu", 32, 16, False, 16, 16, 64, True, False, False, True, 1),  # concat of two tensors (U-Net up path)
+    (0, 3, 1, 1, 0, "relu", 16, 12, True, 8, 8, 16, False, False, False, True, 3),    # tensor ++ broadcast pose vector
+    (0, 1, 2, 2, 0, "none", 32, 0, False, 8, 16, 24, True, True, False, True, 2),     # 1x1 skip / attention projection
+    (1, 4, 2, 1, 0, "relu", 16, 0, False, 16, 16, 32, False, False, False, True, 1),  # conv 4x4 stride 2
+    (2, 4, 2, 1, 0, "relu", 32, 0, False, 8, 8, 32, False, False, False, True, 2),    # convT 4x4 stride 2 (4 parity classes)
+    (0, 3, 2, 1, 1, "silu", 16, 0, False, 4, 8, 32, True, False, False, True, 1),     # nearest-up x2 on load
+    (0, 3, 2, 1, 2, "silu", 16, 0, False, 16, 16, 32, True, False, False, True, 1),   # avg-pool 2x2 on load
+    (0, 3, 1, 1, 0, "relu", 64, 0, False, 8, 8, 10, True, False, True, False, 4),     # head block: mixed sigmoid/tanh/none rows
+    (0, 3, 2, 1, 0, "none", 4, 0, False, 24, 24, 32, True, False, False, False, 1),   # 4-channel image input, 24x24 (rows not a multiple of 16 px)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_kernel_matches_torch(lib, case):
+    kind, k, tmb, pg, in_mode, act_in, c0, c1, vec1, h, w, cout, has_bias, has_res, has_act, has_scale, chunk = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    n = 2
+    x0 = rng.standard_normal((n, c0, h, w)).astype(np.float32)
+    x1 = None
+    if c1:
+        x1 = rng.standard_normal((n, c1) if vec1 else (n, c1, h, w)).astype(np.float32)
+    cin = c0 + c1
+    scale = (1 + 0.3 * rng.standard_normal((n, cin))).astype(np.float32) if has_scale else None
+    shift = (0.3 * rng.standard_normal((n, cin))).astype(np.float32) if has_scale else None
+    kk = k if kind == 0 else 4
+    wshape = (cin, cout, kk, kk) if kind == 2 else (cout, cin, kk, kk)
+    weight = (rng.standard_normal(wshape) / np.sqrt(cin * kk * kk)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32) if has_bias else None
+    act_out = np.array([3 if c % 3 == 0 else (4 if c % 3 == 1 else 0) for c in range(cout)], np.int32) if has_act else None
+    ref_shape = ref_conv(kind, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, None, act_out).shape
+    residual = rng.standard_normal(ref_shape).astype(np.float32) if has_res else None
+    ref = ref_conv(kind, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out)
+    out, stats = run_conv(lib, kind, k, tmb, pg, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out, chunk)
+    assert np.abs(out - ref).max() < 2e-5
+    assert np.abs(stats[..., 0] - ref.sum(axis=(2, 3))).max() < 2e-3
+    assert np.abs(stats[..., 1] - (ref ** 2).sum(axis=(2, 3))).max() < 5e-3
+
+
+def _partials(x, tiles):
+    """[n][c][px] -> partial sums [n][tiles][cb*16][2] like the conv epilogue writes them."""
+    n, c, px = x.shape
+    cb = (c + 15) // 16
+    st = np.zeros((n, tiles, cb * 16, 2), np.float32)
+    chunk = px // tiles
+    for t in range(tiles):
+        seg = x[:, :, t * chunk:(t + 1) * chunk].astype(np.float64)
+        st[:, t, :c, 0] = seg.sum(-1)
+        st[:, t, :c, 1] = (seg ** 2).sum(-1)
+    return st, cb
+
+
+def test_norm_finalize_instance_and_group(lib):
+    rng = np.random.default_rng(5)
+    n, px = 2, 64
+    # InstanceNorm over one 20-channel tensor
+    x = (rng.standard_normal((n, 20, px)) * 2 + 1).astype(np.float32)
+    st, cb = _partials(x, 4)
+    gamma = (1 + 0.2 * rng.standard_normal(20)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(20)).astype(np.float32)
+    sc = np.zeros((n, cb * 16), np.float32); sh = np.zeros_like(sc)
+    lib.emu_norm(n, 1, P(st), 4, cb, None, 0, 0, 20, 0, C.c_float(1.0 / px), C.c_float(1e-5), P(gamma), P(beta), None, None,
+                 P(sc), P(sh), None, None)
+    ref = F.instance_norm(torch.from_numpy(x).double().reshape(n, 20, 8, 8), weight=torch.from_numpy(gamma).double(),
+                          bias=torch.from_numpy(beta).double(), eps=1e-5).reshape(n, 20, px).numpy()
+    got = x * sc[:, :20, None] + sh[:, :20, None]
+    assert np.abs(got - ref).max() < 1e-5
+    assert not sc[:, 20:].any() and not sh[:, 20:].any()
+    # GroupNorm(32) over the concatenation of 64 + 32 channels (groups of 3 straddle the boundary) + two FiLM stages
+    a = (rng.standard_normal((n, 64, px)) + 0.5).astype(np.float32)
+    b = (rng.standard_normal((n, 32, px)) * 3).astype(np.float32)
+    sa, cba = _partials(a, 2)
+    sb, cbb = _partials(b, 4)
+    C_ = 96
+    gamma = (1 + 0.2 * rng.standard_normal(C_)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C_)).astype(np.float32)
+    f0 = (0.3 * rng.standard_normal((n, 2 * C_))).astype(np.float32)
+    f1 = (0.3 * rng.standard_normal((n, 2 * C_))).astype(np.float32)
+    sc0 = np.zeros((n, 64), np.float32); sh0 = np.zeros_like(sc0)
+    sc1 = np.zeros((n, 32), np.float32); sh1 = np.zeros_like(sc1)
+    lib.emu_norm(n, 2, P(sa), 2, cba, P(sb), 4, cbb, C_, 32, C.c_float(1.0 / px), C.c_float(1e-5), P(gamma), P(beta), P(f0), P(f1),
+                 P(sc0), P(sh0), P(sc1), P(sh1))
+    cat = torch.from_numpy(np.concatenate([a, b], 1)).double().reshape(n, C_, 8, 8)
+    h = F.group_norm(cat, 32, torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), eps=1e-5)
+    for f in (f0, f1):
+        ft = torch.from_numpy(f).double()
+        h = h * (1 + ft[:, :C_, None, None]) + ft[:, C_:, None, None]
+    ref = h.reshape(n, C_, px).numpy()
+    got = np.concatenate([a * sc0[:, :, None] + sh0[:, :, None], b * sc1[:, :, None] + sh1[:, :, None]], 1)
+    assert np.abs(got - ref).max() < 2e-5
+
+
+def test_gemv_and_attention(lib):
+    rng = np.random.default_rng(9)
+    n, rows, k = 2, 37, 256
+    w = rng.standard_normal((rows, k)).astype(np.float32) / 16
+    b = rng.standard_normal(rows).astype(np.float32)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    y = np.zeros((n, rows), np.float32)
+    lib.emu_gemv(n, rows, k, P(w), P(b), P(x), ACT["silu"], ACT["none"], P(y))
+    ref = F.linear(F.silu(torch.from_numpy(x).double()), torch.from_numpy(w).double(), torch.from_numpy(b).double()).numpy()
+    assert np.abs(y - ref).max() < 1e-5
+    # attention core (unet.py:192-202) at reduced size: 64 channels, 2 heads (head dim 32), 64 tokens
+    Cc, heads, L = 64, 2, 64
+    qkv = rng.standard_normal((n, 3 * Cc, L)).astype(np.float32)
+    out = np.zeros((n, Cc, L), np.float32)
+    lib.emu_attention(n, Cc, heads, L, P(qkv), P(out))
+    t = torch.from_numpy(qkv).double()
+    q, kk, v = t.chunk(3, dim=1)
+    ch = Cc // heads
+    s = 1.0 / np.sqrt(np.sqrt(ch))
+    wgt = torch.softmax(torch.einsum("bct,bcs->bts", (q * s).reshape(n * heads, ch, L), (kk * s).reshape(n * heads, ch, L)), -1)
+    ref = torch.einsum("bts,bcs->bct", wgt, v.reshape(n * heads, ch, L)).reshape(n, Cc, L).numpy()
+    assert np.abs(out - ref).max() < 1e-5
