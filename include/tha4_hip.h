@@ -119,6 +119,48 @@ int tha4_student_device(const tha4_student* h);
 int tha4_student_set_timing(tha4_student* h, int enable);
 int tha4_student_last_ms(tha4_student* h, int kernel, float* ms_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * Full THA4 system (reference mode_07: eyebrow_decomposer -> eyebrow_morphing_combiner -> face_morpher
+ * -> body_morpher -> upscaler; src/tha4/poser/modes/mode_07.py:54-134, 272-315).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* One entry of a state_dict: name exactly as in the reference module's state_dict(), fp32 host data. */
+typedef struct tha4_named_tensor {
+  const char* name;
+  const float* data;
+  int32_t ndim;
+  int64_t dims[4];
+} tha4_named_tensor;
+
+/* The five state_dicts in the order of mode_07.Network (mode_07.py:24-29). */
+typedef struct tha4_full_weights {
+  const tha4_named_tensor* tensors[5];
+  int32_t counts[5];
+} tha4_full_weights;
+
+#define THA4_FULL_NUM_OUTPUTS 33
+
+typedef struct tha4_full tha4_full; /* opaque */
+
+/* Replaces: the five mode_07.load_* loaders + GeneralPoser02.get_modules (mode_07.py:137-269,
+ * general_poser_02.py:41-49).  `eyebrow_morphed_image_index` as in mode_07.create_poser (:275). */
+int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
+                     tha4_full** out);
+
+/* Replaces: GeneralPoser02.get_posing_outputs -> FiveStepPoserComputationProtocol (mode_07.py:54-134).
+ *   outputs_dev[i]  device pointer for output i of the reference's 33-entry list (order mode_07.py:126-132:
+ *                   upscaler 0-4, face_morphed_full 5, body_morpher 6-10, face_morpher 11-18,
+ *                   eyebrow_morphing_combiner 19-26, eyebrow_decomposer 27-32), fp32 NCHW [B,C,S,S];
+ *                   NULL = not wanted.  outputs_dev[0] (the posed frame) is required.
+ *   reuse_decomposer  non-zero: the image (and batch) is unchanged since the previous call on this handle,
+ *                   reuse the cached eyebrow-decomposer result (the reference detects this with a
+ *                   max|delta| device->host sync, mode_07.py:56-61; here the caller states it). */
+int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev, int batch,
+                   float* const* outputs_dev, int reuse_decomposer, void* stream);
+
+void tha4_full_destroy(tha4_full* h);
+int tha4_full_max_batch(const tha4_full* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,18 @@ class Tha4StudentAux(C.Structure):
                 ("grid_change_dev", C.c_void_p), ("face_dev", C.c_void_p)]
 
 
+class Tha4NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", c_float_p), ("ndim", C.c_int32), ("dims", C.c_int64 * 4)]
+
+
+class Tha4FullWeights(C.Structure):
+    _fields_ = [("tensors", C.POINTER(Tha4NamedTensor) * 5), ("counts", C.c_int32 * 5)]
+
+
+FULL_NETWORKS = ["eyebrow_decomposer", "eyebrow_morphing_combiner", "face_morpher", "body_morpher", "upscaler"]
+FULL_NUM_OUTPUTS = 33
+
+
 class Tha4Error(RuntimeError):
     """Raised for every non-zero status coming back over the C ABI (the reference raises
     RuntimeError / AssertionError from Python for the same conditions)."""
@@ -70,6 +82,30 @@ def build_student_weights(face_sd: Dict[str, np.ndarray], body_sd: Dict[str, np.
             s.body_sine[l][j] = _linear(body_sd[f"siren_layers.{l}.{j}.linear.weight"],
                                         body_sd[f"siren_layers.{l}.{j}.linear.bias"], keep)
     s.body_last = _linear(body_sd["last_linear.weight"], body_sd["last_linear.bias"], keep)
+    return s, keep
+
+
+def build_full_weights(state_dicts: Dict[str, Dict[str, np.ndarray]]):
+    """Map the five reference state_dicts (keys = mode_07.Network names, mode_07.py:24-29) onto the C struct."""
+    keep: list = []
+    s = Tha4FullWeights()
+    for i, net in enumerate(FULL_NETWORKS):
+        sd = state_dicts[net]
+        arr = (Tha4NamedTensor * len(sd))()
+        for j, (k, v) in enumerate(sd.items()):
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            if a.ndim < 1 or a.ndim > 4:
+                raise Tha4Error(f"{net}.{k}: unsupported rank {a.ndim}")
+            name = k.encode()
+            keep.extend([a, name])
+            arr[j].name = name
+            arr[j].data = a.ctypes.data_as(c_float_p)
+            arr[j].ndim = a.ndim
+            for d in range(a.ndim):
+                arr[j].dims[d] = a.shape[d]
+        keep.append(arr)
+        s.tensors[i] = C.cast(arr, C.POINTER(Tha4NamedTensor))
+        s.counts[i] = len(sd)
     return s, keep
 
 
@@ -126,6 +162,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.tha4_student_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.tha4_student_last_ms.restype = C.c_int
     lib.tha4_student_last_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    lib.tha4_full_create.restype = C.c_int
+    lib.tha4_full_create.argtypes = [C.POINTER(Tha4FullWeights), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.tha4_full_pose.restype = C.c_int
+    lib.tha4_full_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                   C.c_void_p]
+    lib.tha4_full_destroy.restype = None
+    lib.tha4_full_destroy.argtypes = [C.c_void_p]
+    lib.tha4_full_max_batch.restype = C.c_int
+    lib.tha4_full_max_batch.argtypes = [C.c_void_p]
     v = lib.tha4_abi_version()
     if v != THA4_ABI_VERSION:
         raise Tha4Error(f"libtha4_hip.so ABI version {v} != expected {THA4_ABI_VERSION}")
@@ -137,6 +182,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_pose", "tha4_student_destroy",
     "tha4_student_max_batch", "tha4_student_device", "tha4_student_set_timing", "tha4_student_last_ms",
+    "tha4_full_create", "tha4_full_pose", "tha4_full_destroy", "tha4_full_max_batch",
 ]
 
 

@@ -30,6 +30,7 @@ struct ConvSrc {
   const float* shift;   // [n][cb*16] or null
   int cb;               // channel blocks of this source
   int kind;
+  int act;              // activation applied after scale/shift (before zero padding / pooling)
 };
 
 struct ConvArgs {
@@ -37,7 +38,6 @@ struct ConvArgs {
   int nsrc;
   int in_h, in_w;        // stored spatial size of the tensor sources
   int in_mode;           // IN_DIRECT | IN_UP2 (virtual 2h x 2w, nearest) | IN_POOL2 (virtual h/2 x w/2, mean of 2x2); must equal the template INMODE
-  int act_in;            // applied after scale/shift, before zero padding / pooling
   int ntaps;
   int tap_dy[kMaxTaps], tap_dx[kMaxTaps];   // virtual input coord = tile coord * in_stride + d
   int in_stride;
@@ -46,7 +46,8 @@ struct ConvArgs {
   int out_sy, out_sx, out_oy, out_ox;
   const float* w;        // packed [mtile][q][tap][TMB][64][4]
   const float* bias;     // [nb*16] or null
-  const float* residual; // C16 like out, or null
+  const float* residual; // C16 [n][nb][res_h*res_w][16] added before the output activation, or null
+  int res_mode;          // IN_DIRECT: same size as out | IN_UP2: nearest x2 of a half-size tensor | IN_POOL2: 2x2 mean of a double-size tensor
   const int* act_out;    // per-output-channel activation codes [nb*16] or null (none)
   float* out;            // C16 [n][nb][out_h*out_w][16]
   float* stats;          // partial sums [n][stats_tiles][nb*16][2] (sum, sum of squares) or null
@@ -120,10 +121,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   };
 
   // operand fetch for global quad q (over the concatenated sources) and tap t
-  auto load_raw = [&](int q, int t, Raw (&r)[PG], f32x4& sc, f32x4& sh, bool new_quad) {
+  auto load_raw = [&](int q, int t, Raw (&r)[PG], f32x4& sc, f32x4& sh, int& act, bool new_quad) {
     int s = 0, ql = q;
     if (a.nsrc > 1 && q >= a.src[0].cb) { s = 1; ql = q - a.src[0].cb; }
     const ConvSrc& S = a.src[s];
+    act = S.act;
     if (new_quad) {
       if (S.scale) {
         sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + g4);
@@ -160,16 +162,16 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     }
   };
 
-  auto finish = [&](const Raw& r, const f32x4& sc, const f32x4& sh) -> f32x4 {
+  auto finish = [&](const Raw& r, const f32x4& sc, const f32x4& sh, int act_in) -> f32x4 {
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v;
       if (NV == 4) {   // AvgPool2d(2,2) of the activated tensor (unet.py:58; ATen sums the window then divides)
-        v = ((apply_act(fmaf(r.v[0][j], sc[j], sh[j]), a.act_in) + apply_act(fmaf(r.v[NV > 1 ? 1 : 0][j], sc[j], sh[j]), a.act_in)) +
-             (apply_act(fmaf(r.v[NV > 1 ? 2 : 0][j], sc[j], sh[j]), a.act_in) + apply_act(fmaf(r.v[NV > 1 ? 3 : 0][j], sc[j], sh[j]), a.act_in))) * 0.25f;
+        v = ((apply_act(fmaf(r.v[0][j], sc[j], sh[j]), act_in) + apply_act(fmaf(r.v[NV > 1 ? 1 : 0][j], sc[j], sh[j]), act_in)) +
+             (apply_act(fmaf(r.v[NV > 1 ? 2 : 0][j], sc[j], sh[j]), act_in) + apply_act(fmaf(r.v[NV > 1 ? 3 : 0][j], sc[j], sh[j]), act_in))) * 0.25f;
       } else {
-        v = apply_act(fmaf(r.v[0][j], sc[j], sh[j]), a.act_in);
+        v = apply_act(fmaf(r.v[0][j], sc[j], sh[j]), act_in);
       }
       o[j] = r.valid ? v : 0.0f;
     }
@@ -185,7 +187,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   fetch(0, 0);
   Raw nxt[PG];
   f32x4 sc_n, sh_n;
-  load_raw(0, 0, nxt, sc_n, sh_n, true);
+  int act_n = ACT_NONE;
+  load_raw(0, 0, nxt, sc_n, sh_n, act_n, true);
   __syncthreads();
   int slot = 0;
   for (int c = 0; c < nchunks; ++c) {
@@ -193,20 +196,29 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int q0 = c * a.chunk_quads;
     const int nq = min(a.chunk_quads, cbtot - q0);
     const f32x4* wv = reinterpret_cast<const f32x4*>(ring + slot * slot_bytes) + lane;
+    // blocked summation: each streamed chunk (~128-256 k-terms) accumulates into a fresh fragment that is then
+    // added to the running sum, so rounding error grows like sqrt(chunk)+sqrt(#chunks) instead of sqrt(K)
+    // (K is up to 4716 in the 512-channel bottlenecks; ATen/oneDNN also sums in vector-register blocks)
+    f32x4 part[TMB][PG];
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) part[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int qq = 0; qq < nq; ++qq) {
       for (int t = 0; t < a.ntaps; ++t) {
         Raw cur[PG];
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) cur[pg] = nxt[pg];
         const f32x4 sc = sc_n, sh = sh_n;
+        const int act_c = act_n;
         // prefetch the operand of the next (quad, tap) step under this step's MFMAs
         int nt = t + 1, nqg = q0 + qq;
         bool newq = false;
         if (nt == a.ntaps) { nt = 0; nqg += 1; newq = true; }
-        if (nqg < cbtot) load_raw(nqg, nt, nxt, sc_n, sh_n, newq);
+        if (nqg < cbtot) load_raw(nqg, nt, nxt, sc_n, sh_n, act_n, newq);
         f32x4 bf[PG];
 #pragma unroll
-        for (int pg = 0; pg < PG; ++pg) bf[pg] = finish(cur[pg], sc, sh);
+        for (int pg = 0; pg < PG; ++pg) bf[pg] = finish(cur[pg], sc, sh, act_c);
         const f32x4* wt = wv + (size_t)((qq * a.ntaps + t) * TMB) * 64;
 #pragma unroll
         for (int b = 0; b < TMB; ++b) {
@@ -214,10 +226,14 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16(av[j], bf[pg][j], acc[b][pg]);
+            for (int pg = 0; pg < PG; ++pg) part[b][pg] = mfma16(av[j], bf[pg][j], part[b][pg]);
         }
       }
     }
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[b][pg] = acc[b][pg] + part[b][pg];
     __syncthreads();
     slot ^= 1;
   }
@@ -237,7 +253,20 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
       const int oy = ty[pg] * a.out_sy + a.out_oy, ox = tx[pg] * a.out_sx + a.out_ox;
       const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
       f32x4 v = acc[b][pg] + bias;
-      if (a.residual) v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
+      if (a.residual) {
+        if (a.res_mode == IN_DIRECT) {
+          v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
+        } else if (a.res_mode == IN_UP2) {      // ResBlock x_resample = Upsample (unet.py:46): nearest
+          const int rw = a.out_w >> 1, rpx = out_px >> 2;
+          v = v + *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
+        } else {                                // x_resample = Downsample = AvgPool2d(2,2) (unet.py:58)
+          const int rw = a.out_w * 2;
+          const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
+          const f32x4 r = ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
+                           (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
+          v = v + r;
+        }
+      }
       if (a.act_out) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
@@ -278,6 +307,43 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ResnetBlock output (resnet_block.py:63-67): out = actA(A*sa+ha) + (B*sb+hb) on C16 tensors of equal
+// shape; scale/shift are per (n, channel) vectors or null (identity).  One thread per 16-byte quad.
+// ---------------------------------------------------------------------------------------------
+struct AffineAddArgs {
+  const float* a; const float* sa; const float* ha; int act_a;
+  const float* b; const float* sb; const float* hb;
+  float* out;
+  int cb, px;
+};
+
+__global__ void __launch_bounds__(256) affine_add_kernel(AffineAddArgs k) {
+  const size_t quads = (size_t)k.cb * k.px * 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (i >= quads) return;
+  const int c4 = (int)(i / ((size_t)k.px * 4)) * 16 + (int)(i & 3) * 4;     // first channel of this quad
+  const size_t off = ((size_t)n * quads + i) * 4;
+  f32x4 va = *reinterpret_cast<const f32x4*>(k.a + off);
+  f32x4 vb = *reinterpret_cast<const f32x4*>(k.b + off);
+  if (k.sa) {
+    const f32x4 s = *reinterpret_cast<const f32x4*>(k.sa + (size_t)n * k.cb * 16 + c4);
+    const f32x4 h = *reinterpret_cast<const f32x4*>(k.ha + (size_t)n * k.cb * 16 + c4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) va[j] = fmaf(va[j], s[j], h[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) va[j] = apply_act(va[j], k.act_a);
+  if (k.sb) {
+    const f32x4 s = *reinterpret_cast<const f32x4*>(k.sb + (size_t)n * k.cb * 16 + c4);
+    const f32x4 h = *reinterpret_cast<const f32x4*>(k.hb + (size_t)n * k.cb * 16 + c4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = fmaf(vb[j], s[j], h[j]);
+  }
+  *reinterpret_cast<f32x4*>(k.out + off) = va + vb;
+}
+
+// ---------------------------------------------------------------------------------------------
 // normalisation finalize: per-tile partial sums -> per-(n, channel) scale/shift for the consumer.
 //   groups == 0 : InstanceNorm2d(affine, eps)            (normalization.py:90-95)
 //   groups  > 0 : GroupNorm(groups, eps) over the CONCATENATION of up to two tensors (unet.py:65-66),
@@ -294,8 +360,9 @@ struct NormArgs {
   float eps;
   const float* gamma;      // [channels]
   const float* beta;
-  const float* film0;      // [n][2*channels] (scale | shift) or null
+  const float* film0;      // [2*channels] (scale | shift) per frame with stride film0_stride (0: shared constant), or null
   const float* film1;
+  long long film0_stride, film1_stride;
   float* scale[2];         // outputs per source, [n][cb*16]
   float* shift[2];
 };
@@ -344,11 +411,11 @@ __global__ void __launch_bounds__(256) norm_finalize_kernel(NormArgs a) {
       double k = (double)a.gamma[c] * rstd;
       double b = (double)a.beta[c] - mean * k;
       if (a.film0) {
-        const double s0 = a.film0[(size_t)n * 2 * a.channels + c], b0 = a.film0[(size_t)n * 2 * a.channels + a.channels + c];
+        const double s0 = a.film0[(size_t)n * a.film0_stride + c], b0 = a.film0[(size_t)n * a.film0_stride + a.channels + c];
         k *= (1.0 + s0); b = b * (1.0 + s0) + b0;
       }
       if (a.film1) {
-        const double s1 = a.film1[(size_t)n * 2 * a.channels + c], b1 = a.film1[(size_t)n * 2 * a.channels + a.channels + c];
+        const double s1 = a.film1[(size_t)n * a.film1_stride + c], b1 = a.film1[(size_t)n * a.film1_stride + a.channels + c];
         k *= (1.0 + s1); b = b * (1.0 + s1) + b1;
       }
       sc = (float)k;
@@ -366,9 +433,10 @@ __global__ void __launch_bounds__(256) norm_finalize_kernel(NormArgs a) {
 struct GemvArgs {
   const float* w;      // [rows][k] row-major
   const float* bias;   // [rows]
-  const float* x;      // [n][k]
+  const float* x;      // [n][k] with row stride x_stride
   float* y;            // [n][rows]
   int rows, k;
+  long long x_stride;
   int act_in, act_out;
 };
 
@@ -378,7 +446,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(GemvArgs a) {
   const int n = blockIdx.y;
   if (row >= a.rows) return;
   const float* w = a.w + (size_t)row * a.k;
-  const float* x = a.x + (size_t)n * a.k;
+  const float* x = a.x + (size_t)n * a.x_stride;
   float s = 0.f;
   for (int i = lane; i < a.k; i += 64) s = fmaf(w[i], apply_act(x[i], a.act_in), s);
 #pragma unroll

@@ -1,0 +1,641 @@
+// Host-side executor of the full THA4 system (reference mode_07) on gfx950: turns the five networks'
+// state_dicts into a static schedule of kernel launches (built once at create time) over one parameter
+// blob and one workspace arena.  No allocation, no synchronisation and no host<->device traffic per frame.
+//
+// Schedule = the reference's cached-DAG evaluation (mode_07.py:54-134) flattened:
+//   eyebrow_decomposer -> eyebrow_morphing_combiner -> face_morpher -> paste/half -> body_morpher -> upscaler
+// Normalisation layers never run as standalone passes: producers emit per-tile moments, a tiny finalize
+// kernel turns them into per-(frame, channel) scale/shift (FiLM folded in), and the CONSUMER convolution
+// applies scale/shift + activation (+ nearest-up / avg-pool) while it loads its operand.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "full_image_kernels.h"
+#include "full_kernels.h"
+#include "full_layout.h"
+
+namespace tha4 {
+
+struct HostTensor {
+  const float* data = nullptr;
+  std::vector<int64_t> dims;
+  int64_t numel() const { int64_t n = 1; for (auto d : dims) n *= d; return n; }
+};
+using WeightMap = std::map<std::string, HostTensor>;
+
+struct FTensor {           // C16 feature map in the workspace
+  size_t off = 0;          // float offset
+  int cb = 0, h = 0, w = 0;
+  size_t stats_off = 0;    // partial moments [n][tiles][cb*16][2]
+  int stats_tiles = 0;
+  int px() const { return h * w; }
+};
+
+struct Pending {           // transform a consumer applies while loading a tensor
+  size_t scale_off = (size_t)-1, shift_off = (size_t)-1;   // workspace offsets of [n][cb*16]
+  bool has() const { return scale_off != (size_t)-1; }
+};
+
+constexpr size_t kNone = (size_t)-1;
+
+class FullModel {
+ public:
+  std::string error;
+  int max_batch = 1;
+  int sel_index = 2;       // eyebrow_morphed_image_index (mode_07.py:275)
+
+  // ---- arenas -------------------------------------------------------------------------------
+  std::vector<char> host_params;     // packed parameters, uploaded once
+  char* dev_params = nullptr;
+  char* dev_work = nullptr;
+  size_t work_floats = 0;
+
+  size_t add_param(const void* p, size_t bytes) {
+    size_t at = (host_params.size() + 255) / 256 * 256;
+    host_params.resize(at + bytes);
+    std::memcpy(host_params.data() + at, p, bytes);
+    return at;
+  }
+  size_t add_param(const std::vector<float>& v) { return add_param(v.data(), v.size() * sizeof(float)); }
+  size_t add_param_i(const std::vector<int>& v) { return add_param(v.data(), v.size() * sizeof(int)); }
+  size_t alloc_work(size_t floats_per_frame) {      // per-frame size; arena holds max_batch frames, n-major per tensor
+    size_t at = (work_floats + 63) / 64 * 64;
+    work_floats = at + floats_per_frame * (size_t)max_batch;
+    return at;
+  }
+  template <class T = float> const T* P(size_t off) const { return reinterpret_cast<const T*>(dev_params + off); }
+  float* Wk(size_t off) const { return reinterpret_cast<float*>(dev_work) + off; }
+
+  // ---- schedule -------------------------------------------------------------------------------
+  struct Frame {            // per-call bindings
+    const float* image; long long image_stride; const float* pose; int batch; hipStream_t stream;
+    float* out[33];         // NCHW outputs in the reference order (never null: unrequested ones point into scratch)
+  };
+  using Op = std::function<void(const Frame&)>;
+  std::vector<Op> ops_decomposer, ops_rest;
+  size_t scratch_out[33];   // workspace offsets used for outputs the caller did not ask for
+  int out_ch[33], out_size[33];
+
+  // ---- weights --------------------------------------------------------------------------------
+  const HostTensor& get(const WeightMap& w, const std::string& k) {
+    auto it = w.find(k);
+    if (it == w.end()) { if (error.empty()) error = "missing tensor '" + k + "'"; static HostTensor empty; return empty; }
+    return it->second;
+  }
+  bool expect(const HostTensor& t, std::initializer_list<int64_t> dims, const std::string& k) {
+    if (!t.data || t.dims != std::vector<int64_t>(dims)) { if (error.empty()) error = "tensor '" + k + "' has an unexpected shape"; return false; }
+    return true;
+  }
+
+  // ---- building blocks --------------------------------------------------------------------------
+  FTensor new_tensor(int cb, int h, int w) {
+    FTensor t; t.cb = cb; t.h = h; t.w = w; t.off = alloc_work((size_t)cb * h * w * 16); return t;
+  }
+
+  struct Src {              // one convolution operand
+    FTensor t; Pending pend; bool vector = false; size_t vec_off = 0; int vec_cb = 0;
+    int channels = 0;       // real channels contributed to the weight tensor
+  };
+  static Src src_tensor(const FTensor& t, int channels, Pending p = Pending()) { Src s; s.t = t; s.pend = p; s.channels = channels; return s; }
+  static Src src_vector(size_t off, int cb, int channels) { Src s; s.vector = true; s.vec_off = off; s.vec_cb = cb; s.channels = channels; return s; }
+
+  enum ConvKind { K_SAME3, K_SAME1, K_S2K4, K_CONVT };
+
+  template <int TMB, int PG, int INMODE>
+  static void launch_conv(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((conv_mfma_kernel<TMB, PG, INMODE>), grid, dim3(256), lds, s, a);
+  }
+  static void dispatch_conv(int tmb, int pg, int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+#define THA4_CASE(TM, PGV)                                                            \
+  if (tmb == TM && pg == PGV) {                                                        \
+    if (inmode == IN_DIRECT) return launch_conv<TM, PGV, IN_DIRECT>(a, grid, lds, s);  \
+    if (inmode == IN_UP2) return launch_conv<TM, PGV, IN_UP2>(a, grid, lds, s);        \
+    return launch_conv<TM, PGV, IN_POOL2>(a, grid, lds, s);                            \
+  }
+    THA4_CASE(4, 2) THA4_CASE(4, 1) THA4_CASE(2, 2) THA4_CASE(2, 1) THA4_CASE(1, 1)
+#undef THA4_CASE
+  }
+  static hipError_t allow_all_conv_lds() {
+    hipError_t e = hipSuccess;
+    auto set = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+#define THA4_ALLOW(TM, PGV)                                                         \
+  set(reinterpret_cast<const void*>(conv_mfma_kernel<TM, PGV, IN_DIRECT>));        \
+  set(reinterpret_cast<const void*>(conv_mfma_kernel<TM, PGV, IN_UP2>));           \
+  set(reinterpret_cast<const void*>(conv_mfma_kernel<TM, PGV, IN_POOL2>));
+    THA4_ALLOW(4, 2) THA4_ALLOW(4, 1) THA4_ALLOW(2, 2) THA4_ALLOW(2, 1) THA4_ALLOW(1, 1)
+#undef THA4_ALLOW
+    set(reinterpret_cast<const void*>(attention_kernel));
+    return e;
+  }
+
+  // Convolution.  weight: Conv2d [cout][cin][k][k] or ConvTranspose2d [cin][cout][4][4]; the sources are
+  // concatenated along the weight's input channels in order.  Returns the raw output tensor (+ moments).
+  FTensor conv(std::vector<Op>& ops, ConvKind kind, const std::vector<Src>& srcs, int in_mode, int act_in,
+               const HostTensor& weight, const float* bias_host, int cout, bool want_stats,
+               const FTensor* residual = nullptr, int res_mode = IN_DIRECT, const std::vector<int>* act_out = nullptr,
+               const std::vector<float>* bias_override = nullptr) {
+    const FTensor& t0 = srcs[0].t;
+    const int ih = t0.h, iw = t0.w;
+    const int vh = in_mode == IN_UP2 ? ih * 2 : (in_mode == IN_POOL2 ? ih / 2 : ih);
+    const int vw = in_mode == IN_UP2 ? iw * 2 : (in_mode == IN_POOL2 ? iw / 2 : iw);
+    int oh = vh, ow = vw, th = vh, tw = vw, nclass = 1, k = 3;
+    if (kind == K_SAME1) k = 1;
+    if (kind == K_S2K4) { oh = vh / 2; ow = vw / 2; th = oh; tw = ow; k = 4; }
+    if (kind == K_CONVT) { oh = vh * 2; ow = vw * 2; nclass = 4; k = 4; }
+    int cin = 0;
+    std::vector<ChannelSegment> segs;
+    for (auto& s : srcs) { segs.push_back({cin, s.channels}); cin += s.channels; }
+    const int nb = (cout + 15) / 16;
+    const int tmb = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
+    const int mtiles = nb / tmb;
+    const int tile_px = th * tw;
+    int pg = 1;
+    if (tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
+    if (tile_px % (64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of 64 pixels"; return FTensor(); }
+    const int tiles = tile_px / (64 * pg);
+    FTensor out = new_tensor(nb, oh, ow);
+    if (want_stats) {
+      out.stats_tiles = tiles * nclass;
+      out.stats_off = alloc_work((size_t)out.stats_tiles * nb * 16 * 2);
+    }
+    size_t bias_off = kNone;
+    if (bias_host || bias_override) {
+      std::vector<float> b(nb * 16, 0.f);
+      for (int i = 0; i < cout; ++i) b[i] = bias_override ? (*bias_override)[i] : bias_host[i];
+      bias_off = add_param(b);
+    }
+    size_t act_off = kNone;
+    if (act_out) { std::vector<int> a(nb * 16, 0); for (int i = 0; i < cout; ++i) a[i] = (*act_out)[i]; act_off = add_param_i(a); }
+    int cbtot = 0;
+    for (auto& s : srcs) cbtot += (s.channels + 15) / 16;
+    for (int cls = 0; cls < nclass; ++cls) {
+      ConvGeom g = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1)
+                 : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1);
+      const size_t w_off = add_param(pack_conv_weight(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb));
+      int cq = std::max(1, 32 / (g.ntaps * tmb));
+      cq = std::min(cq, cbtot);
+      const size_t lds = 2 * (size_t)cq * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
+      ConvArgs a{};
+      a.nsrc = (int)srcs.size();
+      a.in_h = ih; a.in_w = iw; a.in_mode = in_mode;
+      a.ntaps = g.ntaps;
+      for (int t = 0; t < g.ntaps; ++t) { a.tap_dy[t] = g.dy[t]; a.tap_dx[t] = g.dx[t]; }
+      a.in_stride = g.in_stride;
+      a.tile_h = th; a.tile_w = tw; a.out_h = oh; a.out_w = ow;
+      a.out_sy = g.out_sy; a.out_sx = g.out_sx; a.out_oy = g.out_oy; a.out_ox = g.out_ox;
+      a.res_mode = res_mode;
+      a.stats_tiles = out.stats_tiles; a.stats_tile0 = cls * tiles;
+      a.nb = nb; a.chunk_quads = cq;
+      std::vector<Src> sv = srcs;
+      const FTensor outc = out;
+      const bool has_res = residual != nullptr;
+      const FTensor resc = has_res ? *residual : FTensor();
+      ops.push_back([=](const Frame& f) {
+        ConvArgs c = a;
+        for (size_t i = 0; i < sv.size(); ++i) {
+          const Src& s = sv[i];
+          c.src[i].kind = s.vector ? SRC_VECTOR : SRC_TENSOR;
+          c.src[i].act = s.vector ? ACT_NONE : act_in;     // the pose is concatenated AFTER the activation (poser_encoder_decoder_00.py:108-113)
+          c.src[i].cb = s.vector ? s.vec_cb : s.t.cb;
+          c.src[i].data = Wk(s.vector ? s.vec_off : s.t.off);
+          c.src[i].scale = s.pend.has() ? Wk(s.pend.scale_off) : nullptr;
+          c.src[i].shift = s.pend.has() ? Wk(s.pend.shift_off) : nullptr;
+        }
+        c.w = P(w_off);
+        c.bias = bias_off == kNone ? nullptr : P(bias_off);
+        c.act_out = act_off == kNone ? nullptr : P<int>(act_off);
+        c.residual = has_res ? Wk(resc.off) : nullptr;
+        c.out = Wk(outc.off);
+        c.stats = outc.stats_tiles ? Wk(outc.stats_off) : nullptr;
+        c.batch = f.batch;
+        dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
+      });
+    }
+    return out;
+  }
+
+  // Normalisation finalize over up to two concatenated tensors; returns the pending transform per source.
+  std::vector<Pending> norm(std::vector<Op>& ops, const std::vector<FTensor>& srcs, int channels, int groups,
+                            const HostTensor& gamma, const HostTensor& beta, size_t film0_off = kNone,
+                            size_t film1_off = kNone, long long film1_stride = 0) {
+    std::vector<Pending> out(srcs.size());
+    for (size_t i = 0; i < srcs.size(); ++i) {
+      out[i].scale_off = alloc_work((size_t)srcs[i].cb * 16);
+      out[i].shift_off = alloc_work((size_t)srcs[i].cb * 16);
+    }
+    const size_t g_off = add_param(gamma.data, sizeof(float) * channels);
+    const size_t b_off = add_param(beta.data, sizeof(float) * channels);
+    const std::vector<FTensor> sv = srcs;
+    const std::vector<Pending> pv = out;
+    int cbt = 0;
+    for (auto& s : srcs) cbt += s.cb;
+    ops.push_back([=](const Frame& f) {
+      NormArgs a{};
+      a.nsrc = (int)sv.size();
+      for (size_t i = 0; i < sv.size(); ++i) {
+        a.stats[i] = Wk(sv[i].stats_off); a.tiles[i] = sv[i].stats_tiles; a.cb[i] = sv[i].cb;
+        a.scale[i] = Wk(pv[i].scale_off); a.shift[i] = Wk(pv[i].shift_off);
+      }
+      a.channels = channels; a.groups = groups;
+      a.inv_count = 1.0f / (float)(sv[0].h * sv[0].w);
+      a.eps = 1e-5f;
+      a.gamma = P(g_off); a.beta = P(b_off);
+      a.film0 = film0_off == kNone ? nullptr : P(film0_off); a.film0_stride = 0;
+      a.film1 = film1_off == kNone ? nullptr : Wk(film1_off); a.film1_stride = film1_stride;
+      hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch), dim3(256), (size_t)cbt * 16 * 2 * sizeof(double), f.stream, a);
+    });
+    return out;
+  }
+
+  FTensor affine_add(std::vector<Op>& ops, const FTensor& A, Pending pa, int act_a, const FTensor& B, Pending pb) {
+    FTensor out = new_tensor(A.cb, A.h, A.w);
+    ops.push_back([=](const Frame& f) {
+      AffineAddArgs k{};
+      k.a = Wk(A.off); k.sa = pa.has() ? Wk(pa.scale_off) : nullptr; k.ha = pa.has() ? Wk(pa.shift_off) : nullptr; k.act_a = act_a;
+      k.b = Wk(B.off); k.sb = pb.has() ? Wk(pb.scale_off) : nullptr; k.hb = pb.has() ? Wk(pb.shift_off) : nullptr;
+      k.out = Wk(out.off); k.cb = A.cb; k.px = A.px();
+      const size_t quads = (size_t)A.cb * A.px() * 4;
+      hipLaunchKernelGGL(affine_add_kernel, dim3((unsigned)((quads + 255) / 256), f.batch), dim3(256), 0, f.stream, k);
+    });
+    return out;
+  }
+
+  // ---- encoder-decoder trunk (poser_encoder_decoder_00.py:99-121 / face_morpher_08.py:159-168) ----
+  // returns the last feature map (64 ch, raw) and its pending InstanceNorm+ReLU
+  bool encdec(std::vector<Op>& ops, const WeightMap& w, const std::string& pre, const FTensor& input, int in_ch,
+              size_t pose_vec_off, int pose_count, FTensor& feat, Pending& feat_pend) {
+    auto W = [&](const std::string& k) -> const HostTensor& { return get(w, pre + k); };
+    FTensor x = conv(ops, K_SAME3, {src_tensor(input, in_ch)}, IN_DIRECT, ACT_NONE, W("downsample_blocks.0.0.weight"), nullptr, 64, true);
+    Pending px = norm(ops, {x}, 64, 0, W("downsample_blocks.0.1.weight"), W("downsample_blocks.0.1.bias"))[0];
+    int c = 64;
+    for (int i = 1; i < 4; ++i) {
+      const std::string b = "downsample_blocks." + std::to_string(i);
+      x = conv(ops, K_S2K4, {src_tensor(x, c, px)}, IN_DIRECT, ACT_RELU, W(b + ".0.weight"), nullptr, 2 * c, true);
+      c *= 2;
+      px = norm(ops, {x}, c, 0, W(b + ".1.weight"), W(b + ".1.bias"))[0];
+    }
+    std::vector<Src> s0 = {src_tensor(x, 512, px)};
+    if (pose_count > 0) s0.push_back(src_vector(pose_vec_off, (pose_count + 15) / 16, pose_count));
+    x = conv(ops, K_SAME3, s0, IN_DIRECT, ACT_RELU, W("bottleneck_blocks.0.0.weight"), nullptr, 512, true);
+    px = norm(ops, {x}, 512, 0, W("bottleneck_blocks.0.1.weight"), W("bottleneck_blocks.0.1.bias"))[0];
+    int act_x = ACT_RELU;       // x is "raw + pending IN/ReLU" after block 0, a plain tensor after every ResnetBlock
+    for (int i = 1; i < 6; ++i) {
+      const std::string b = "bottleneck_blocks." + std::to_string(i) + ".resnet_path.";
+      FTensor r1 = conv(ops, K_SAME3, {src_tensor(x, 512, px)}, IN_DIRECT, act_x, W(b + "0.weight"), nullptr, 512, true);
+      Pending p1 = norm(ops, {r1}, 512, 0, W(b + "1.weight"), W(b + "1.bias"))[0];
+      FTensor r2 = conv(ops, K_SAME3, {src_tensor(r1, 512, p1)}, IN_DIRECT, ACT_RELU, W(b + "3.weight"), nullptr, 512, true);
+      Pending p2 = norm(ops, {r2}, 512, 0, W(b + "4.weight"), W(b + "4.bias"))[0];
+      x = affine_add(ops, x, px, act_x, r2, p2);      // x + resnet_path(x)   (resnet_block.py:63-67)
+      px = Pending();
+      act_x = ACT_NONE;
+    }
+    for (int i = 0; i < 3; ++i) {
+      const std::string b = "upsample_blocks." + std::to_string(i);
+      x = conv(ops, K_CONVT, {src_tensor(x, c, px)}, IN_DIRECT, act_x, W(b + ".0.weight"), nullptr, c / 2, true);
+      c /= 2;
+      px = norm(ops, {x}, c, 0, W(b + ".1.weight"), W(b + ".1.bias"))[0];
+      act_x = ACT_RELU;
+    }
+    feat = x;
+    feat_pend = px;
+    return error.empty();
+  }
+
+  // heads: several conv3(64 -> k) layers fused into ONE output block (poser_args.py:31-68)
+  struct HeadSpec { std::string name; int channels; int act; bool bias; };
+  FTensor heads(std::vector<Op>& ops, const WeightMap& w, const std::vector<HeadSpec>& hs, const FTensor& feat, Pending fp) {
+    int total = 0;
+    for (auto& h : hs) total += h.channels;
+    std::vector<float> wcat((size_t)total * 64 * 9, 0.f), bcat(total, 0.f);
+    std::vector<int> acts(total, 0);
+    int at = 0;
+    for (auto& h : hs) {
+      const HostTensor& wt = get(w, h.name + ".weight");
+      if (!expect(wt, {h.channels, 64, 3, 3}, h.name + ".weight")) return FTensor();
+      std::memcpy(wcat.data() + (size_t)at * 64 * 9, wt.data, sizeof(float) * (size_t)h.channels * 64 * 9);
+      if (h.bias) { const HostTensor& bt = get(w, h.name + ".bias"); if (bt.data) for (int i = 0; i < h.channels; ++i) bcat[at + i] = bt.data[i]; }
+      for (int i = 0; i < h.channels; ++i) acts[at + i] = h.act;
+      at += h.channels;
+    }
+    head_storage.push_back(std::move(wcat));
+    HostTensor hw; hw.data = head_storage.back().data(); hw.dims = {total, 64, 3, 3};
+    return conv(ops, K_SAME3, {src_tensor(feat, 64, fp)}, IN_DIRECT, ACT_RELU, hw, nullptr, total, false, nullptr, IN_DIRECT, &acts, &bcat);
+  }
+  std::vector<std::vector<float>> head_storage;
+
+  // ---- U-Net (unet.py) ---------------------------------------------------------------------------
+  struct UnetCfg { int in_ch, model; std::vector<int> mults; std::vector<bool> attn; };
+  struct Feat { FTensor t; int channels; };
+
+  // small dense layers evaluated on the host at create time (constant t = 0 branch, unet.py:365-376, morpher_00.py:51)
+  static std::vector<float> host_linear(const HostTensor& W, const HostTensor& b, const std::vector<float>& x, bool silu_in) {
+    const int rows = (int)W.dims[0], k = (int)W.dims[1];
+    std::vector<float> y(rows);
+    for (int r = 0; r < rows; ++r) {
+      float s = 0.f;
+      for (int i = 0; i < k; ++i) {
+        float v = x[i];
+        if (silu_in) v = v / (1.0f + std::exp(-v));
+        s = std::fma(W.data[(size_t)r * k + i], v, s);
+      }
+      y[r] = s + b.data[r];
+    }
+    return y;
+  }
+
+  void gemv(std::vector<Op>& ops, size_t w_off, size_t b_off, int rows, int k, std::function<const float*(const Frame&)> x,
+            long long x_stride, size_t y_off, int act_in, int act_out) {
+    ops.push_back([=](const Frame& f) {
+      GemvArgs a{P(w_off), P(b_off), x(f), Wk(y_off), rows, k, x_stride, act_in, act_out};
+      hipLaunchKernelGGL(gemv_kernel, dim3((rows + 3) / 4, f.batch), dim3(256), 0, f.stream, a);
+    });
+  }
+
+  struct ResPlan { std::string p; int cin, cout; int mode; size_t film0_off; size_t film1_row; };
+
+  Feat attention(std::vector<Op>& ops, const WeightMap& w, const std::string& p, const Feat& x) {
+    const int C = x.channels;
+    Pending pn = norm(ops, {x.t}, C, 32, get(w, p + ".norm.weight"), get(w, p + ".norm.bias"))[0];
+    FTensor qkv = conv(ops, K_SAME1, {src_tensor(x.t, C, pn)}, IN_DIRECT, ACT_NONE, get(w, p + ".qkv.weight"),
+                       get(w, p + ".qkv.bias").data, 3 * C, false);
+    FTensor att = new_tensor(C / 16, x.t.h, x.t.w);
+    const int tokens = x.t.px();
+    ops.push_back([=](const Frame& f) {
+      AttnArgs a{Wk(qkv.off), Wk(att.off), C, 8, tokens};
+      hipLaunchKernelGGL(attention_kernel, dim3(8, f.batch), dim3(tokens), (size_t)2 * tokens * (C / 8) * sizeof(float), f.stream, a);
+    });
+    FTensor o = conv(ops, K_SAME1, {src_tensor(att, C)}, IN_DIRECT, ACT_NONE, get(w, p + ".conv.weight"), get(w, p + ".conv.bias").data,
+                     C, true, &x.t, IN_DIRECT);
+    return Feat{o, C};
+  }
+
+  // ResBlock (unet.py:154-165) on the concatenation of `ins`; film1 points at this block's rows of the per-frame FiLM vector
+  Feat resblock(std::vector<Op>& ops, const WeightMap& w, const std::string& p, const std::vector<Feat>& ins, int cout, int mode,
+                const std::vector<float>& t_emb, size_t film1_base, long long film1_stride, size_t& film1_row) {
+    int cin = 0;
+    std::vector<FTensor> ts;
+    for (auto& f : ins) { cin += f.channels; ts.push_back(f.t); }
+    std::vector<Pending> p0 = norm(ops, ts, cin, 32, get(w, p + ".norm0.weight"), get(w, p + ".norm0.bias"));
+    std::vector<Src> s0;
+    for (size_t i = 0; i < ins.size(); ++i) s0.push_back(src_tensor(ins[i].t, ins[i].channels, p0[i]));
+    FTensor h = conv(ops, K_SAME3, s0, mode, ACT_SILU, get(w, p + ".conv0.weight"), get(w, p + ".conv0.bias").data, cout, true);
+    // FiLM 0 comes from the constant time embedding: evaluate once on the host
+    std::vector<float> f0 = host_linear(get(w, p + ".cond0_layers.1.weight"), get(w, p + ".cond0_layers.1.bias"), t_emb, true);
+    const size_t f0_off = add_param(f0);
+    const size_t my_row = film1_row;
+    film1_row += 2 * (size_t)cout;
+    Pending p1 = norm(ops, {h}, cout, 32, get(w, p + ".norm1.weight"), get(w, p + ".norm1.bias"), f0_off, film1_base + my_row, film1_stride)[0];
+    // skip branch (unet.py:149-152,165)
+    FTensor res;
+    int res_mode = mode;
+    if (cin != cout) {
+      std::vector<Src> ss;
+      for (auto& f : ins) ss.push_back(src_tensor(f.t, f.channels));
+      res = conv(ops, K_SAME1, ss, IN_DIRECT, ACT_NONE, get(w, p + ".skip.weight"), get(w, p + ".skip.bias").data, cout, false);
+      res_mode = IN_DIRECT;
+    } else {
+      res = ins[0].t;     // resampling blocks and same-width blocks have a single input
+    }
+    FTensor o = conv(ops, K_SAME3, {src_tensor(h, cout, p1)}, IN_DIRECT, ACT_SILU, get(w, p + ".conv1.weight"),
+                     get(w, p + ".conv1.bias").data, cout, true, &res, res_mode);
+    return Feat{o, cout};
+  }
+
+  // film rows of all ResBlocks of a U-Net in execution order (must mirror unet() below)
+  struct UnetWalk { std::vector<std::string> res_prefix; std::vector<int> res_cout; };
+
+  FTensor unet(std::vector<Op>& ops, const WeightMap& w, const std::string& pre, const UnetCfg& cfg, const std::vector<Src>& first_srcs,
+               const HostTensor& first_w, const std::vector<float>& first_bias) {
+    const int L = (int)cfg.mults.size();
+    auto key = [&](const std::string& k) { return pre + k; };
+    // constant time embedding: t = 0 -> [cos 0 .. | sin 0 ..] = [1.. | 0..]
+    std::vector<float> tin(cfg.model, 0.f);
+    for (int i = 0; i < cfg.model / 2; ++i) tin[i] = 1.f;
+    std::vector<float> t1 = host_linear(get(w, key("time_embed.1.weight")), get(w, key("time_embed.1.bias")), tin, false);
+    std::vector<float> t_emb = host_linear(get(w, key("time_embed.3.weight")), get(w, key("time_embed.3.bias")), t1, true);
+    if (!error.empty()) return FTensor();
+    // enumerate the ResBlocks to lay out the per-frame FiLM-1 vector, then emit: cond MLP + one gemv for all blocks
+    std::vector<std::pair<std::string, int>> blocks;    // (prefix, cout) in execution order
+    {
+      int cur = cfg.model;
+      for (int i = 0; i < L; ++i) {
+        const int out = cfg.model * cfg.mults[i];
+        blocks.push_back({key("down_blocks." + std::to_string(i) + ".res_blocks.0"), out});
+        if (i < L - 1) blocks.push_back({key("down_blocks." + std::to_string(i) + ".downsample"), out});
+        cur = out;
+      }
+      for (int k = 0; k < 4; ++k) blocks.push_back({key("middle_blocks." + std::to_string(2 * k)), cur});
+      for (int bi = 0; bi < L; ++bi) {
+        const int i = L - 1 - bi, out = cfg.model * cfg.mults[i];
+        for (int j = 0; j < 2; ++j) blocks.push_back({key("up_blocks." + std::to_string(bi) + ".resnet_blocks." + std::to_string(j)), out});
+        if (i > 0) blocks.push_back({key("up_blocks." + std::to_string(bi) + ".upsample"), out});
+      }
+    }
+    size_t rows = 0;
+    for (auto& b : blocks) rows += 2 * (size_t)b.second;
+    std::vector<float> wall(rows * 256), ball(rows);
+    {
+      size_t r = 0;
+      for (auto& b : blocks) {
+        const HostTensor& wt = get(w, b.first + ".cond1_layers.1.weight");
+        const HostTensor& bt = get(w, b.first + ".cond1_layers.1.bias");
+        if (!expect(wt, {2 * b.second, 256}, b.first + ".cond1_layers.1.weight")) return FTensor();
+        std::memcpy(wall.data() + r * 256, wt.data, sizeof(float) * (size_t)2 * b.second * 256);
+        std::memcpy(ball.data() + r, bt.data, sizeof(float) * (size_t)2 * b.second);
+        r += 2 * (size_t)b.second;
+      }
+    }
+    const size_t c0w = add_param(get(w, key("cond_embed.0.weight")).data, sizeof(float) * 256 * 6);
+    const size_t c0b = add_param(get(w, key("cond_embed.0.bias")).data, sizeof(float) * 256);
+    const size_t c2w = add_param(get(w, key("cond_embed.2.weight")).data, sizeof(float) * 256 * 256);
+    const size_t c2b = add_param(get(w, key("cond_embed.2.bias")).data, sizeof(float) * 256);
+    const size_t fw = add_param(wall), fb = add_param(ball);
+    const size_t h1 = alloc_work(256), cemb = alloc_work(256), film1 = alloc_work(rows);
+    gemv(ops, c0w, c0b, 256, 6, [](const Frame& f) { return f.pose + 39; }, 45, h1, ACT_NONE, ACT_SILU);   // rotation pose = pose[:, 39:45]
+    gemv(ops, c2w, c2b, 256, 256, [=](const Frame&) { return (const float*)Wk(h1); }, 256, cemb, ACT_NONE, ACT_NONE);
+    gemv(ops, fw, fb, (int)rows, 256, [=](const Frame&) { return (const float*)Wk(cemb); }, 256, film1, ACT_SILU, ACT_NONE);
+
+    size_t row = 0;
+    const long long fstride = (long long)rows;
+    FTensor h0 = conv(ops, K_SAME3, first_srcs, IN_DIRECT, ACT_NONE, first_w, nullptr, cfg.model, true, nullptr, IN_DIRECT, nullptr, &first_bias);
+    std::vector<Feat> hs = {Feat{h0, cfg.model}};
+    Feat h = hs[0];
+    for (int i = 0; i < L; ++i) {
+      const int out = cfg.model * cfg.mults[i];
+      const std::string b = key("down_blocks." + std::to_string(i));
+      h = resblock(ops, w, b + ".res_blocks.0", {h}, out, IN_DIRECT, t_emb, film1, fstride, row);
+      if (cfg.attn[i]) h = attention(ops, w, b + ".attention_blocks.0", h);
+      hs.push_back(h);
+      if (i < L - 1) {
+        h = resblock(ops, w, b + ".downsample", {h}, out, IN_POOL2, t_emb, film1, fstride, row);
+        hs.push_back(h);
+      }
+    }
+    for (int k = 0; k < 3; ++k) {
+      h = resblock(ops, w, key("middle_blocks." + std::to_string(2 * k)), {h}, h.channels, IN_DIRECT, t_emb, film1, fstride, row);
+      h = attention(ops, w, key("middle_blocks." + std::to_string(2 * k + 1) + ".module"), h);
+    }
+    h = resblock(ops, w, key("middle_blocks.6"), {h}, h.channels, IN_DIRECT, t_emb, film1, fstride, row);
+    for (int bi = 0; bi < L; ++bi) {
+      const int i = L - 1 - bi, out = cfg.model * cfg.mults[i];
+      const std::string b = key("up_blocks." + std::to_string(bi));
+      for (int j = 0; j < 2; ++j) {
+        Feat skip = hs.back();
+        hs.pop_back();
+        h = resblock(ops, w, b + ".resnet_blocks." + std::to_string(j), {h, skip}, out, IN_DIRECT, t_emb, film1, fstride, row);
+        if (cfg.attn[i]) h = attention(ops, w, b + ".attention_blocks." + std::to_string(j), h);
+      }
+      if (i > 0) h = resblock(ops, w, b + ".upsample", {h}, out, IN_UP2, t_emb, film1, fstride, row);
+    }
+    if (!hs.empty() || row != rows) { if (error.empty()) error = "internal: U-Net walk mismatch"; return FTensor(); }
+    Pending pl = norm(ops, {h.t}, cfg.model, 32, get(w, key("last.0.weight")), get(w, key("last.0.bias")))[0];
+    return conv(ops, K_SAME3, {src_tensor(h.t, cfg.model, pl)}, IN_DIRECT, ACT_SILU, get(w, key("last.2.weight")),
+                get(w, key("last.2.bias")).data, 7, false);
+  }
+
+  // ---- image-domain launches -----------------------------------------------------------------------
+  template <class K>
+  void image_op(std::vector<Op>& ops, K kernel, int pixels, std::function<void(const Frame&, ImgArgs&)> bind) {
+    ops.push_back([=](const Frame& f) {
+      ImgArgs a{};
+      a.image = f.image; a.image_stride = f.image_stride; a.pose = f.pose; a.batch = f.batch; a.sel = sel_index;
+      bind(f, a);
+      hipLaunchKernelGGL(kernel, dim3((pixels + 255) / 256, f.batch), dim3(256), 0, f.stream, a);
+    });
+  }
+
+  // ---- whole pipeline ------------------------------------------------------------------------------
+  // Output order (mode_07.py:126-132): upscaler 0-4, face_morphed_full 5, body 6-10, face 11-18, combiner 19-26, decomposer 27-32
+  bool build(const WeightMap nets[5], int max_batch_, int sel) {
+    max_batch = max_batch_;
+    sel_index = sel;
+    static const int och[33] = {4, 1, 4, 2, 4, 4, 4, 1, 4, 2, 4, 4, 1, 4, 4, 1, 4, 4, 2, 4, 1, 4, 4, 1, 4, 4, 2, 4, 1, 4, 4, 1, 4};
+    static const int osz[33] = {512, 512, 512, 512, 512, 512, 256, 256, 256, 256, 256, 192, 192, 192, 192, 192, 192, 192, 192,
+                                128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+    for (int i = 0; i < 33; ++i) { out_ch[i] = och[i]; out_size[i] = osz[i]; scratch_out[i] = alloc_work((size_t)och[i] * osz[i] * osz[i]); }
+    const size_t pose_eb = alloc_work(16), pose_face = alloc_work(32);
+
+    // 1. eyebrow decomposer (its outputs are cached by the caller while the image is unchanged, mode_07.py:56-67)
+    {
+      auto& ops = ops_decomposer;
+      FTensor x = new_tensor(1, 128, 128);
+      image_op(ops, crop_eyebrow_kernel, 128 * 128, [=](const Frame&, ImgArgs& a) { a.c16_out = Wk(x.off); });
+      FTensor feat; Pending fp;
+      if (!encdec(ops, nets[0], "body.", x, 4, 0, 0, feat, fp)) return false;
+      FTensor hd = heads(ops, nets[0], {{"background_layer_alpha.0", 1, ACT_SIGMOID, true}, {"background_layer_color_change.0", 4, ACT_TANH, true},
+                                        {"eyebrow_layer_alpha.0", 1, ACT_SIGMOID, true}, {"eyebrow_layer_color_change.0", 4, ACT_TANH, true}}, feat, fp);
+      comb_in = new_tensor(1, 128, 128);
+      const FTensor ci = comb_in;
+      // the six decomposer outputs live in persistent workspace buffers: they are reused by later frames
+      // while the image is unchanged (the reference caches them the same way, mode_07.py:56-67)
+      for (int i = 0; i < 6; ++i) dec_persist[i] = alloc_work((size_t)och[27 + i] * 128 * 128);
+      image_op(ops, decomposer_tail_kernel, 128 * 128, [=](const Frame&, ImgArgs& a) {
+        a.head = Wk(hd.off); a.c16_out = Wk(ci.off);
+        for (int i = 0; i < 6; ++i) a.out[i] = Wk(dec_persist[i]);
+      });
+    }
+    auto& ops = ops_rest;
+    ops.push_back([=](const Frame& f) {
+      hipLaunchKernelGGL(pose_pad_kernel, dim3(f.batch), dim3(64), 0, f.stream, f.pose, Wk(pose_eb), Wk(pose_face), f.batch);
+    });
+    // 2. eyebrow morphing combiner
+    {
+      FTensor feat; Pending fp;
+      if (!encdec(ops, nets[1], "body.", comb_in, 8, pose_eb, 12, feat, fp)) return false;
+      FTensor hd = heads(ops, nets[1], {{"morphed_eyebrow_layer_grid_change", 2, ACT_NONE, false}, {"morphed_eyebrow_layer_alpha.0", 1, ACT_SIGMOID, true},
+                                        {"morphed_eyebrow_layer_color_change.0", 4, ACT_TANH, true}, {"combine_alpha.0", 1, ACT_SIGMOID, true}}, feat, fp);
+      image_op(ops, combiner_tail_kernel, 128 * 128, [=](const Frame& f, ImgArgs& a) {
+        a.head = Wk(hd.off); a.in0 = Wk(dec_persist[0]); a.in1 = Wk(dec_persist[3]);
+        for (int i = 0; i < 8; ++i) a.out[i] = f.out[19 + i];
+      });
+    }
+    // 3. face morpher
+    const size_t face_in_nchw = alloc_work((size_t)4 * 192 * 192);
+    {
+      FTensor x = new_tensor(1, 192, 192);
+      image_op(ops, face_input_kernel, 192 * 192, [=](const Frame& f, ImgArgs& a) {
+        a.in0 = f.out[19 + sel_index]; a.out[0] = Wk(face_in_nchw); a.c16_out = Wk(x.off);
+      });
+      FTensor feat; Pending fp;
+      if (!encdec(ops, nets[2], "", x, 4, pose_face, 27, feat, fp)) return false;
+      FTensor hd = heads(ops, nets[2], {{"iris_mouth_grid_change", 2, ACT_NONE, false}, {"iris_mouth_color_change.0", 4, ACT_TANH, true},
+                                        {"iris_mouth_alpha.0", 1, ACT_SIGMOID, true}, {"eye_color_change.0", 4, ACT_TANH, true},
+                                        {"eye_alpha.0", 1, ACT_SIGMOID, true}}, feat, fp);
+      image_op(ops, face_tail_kernel, 192 * 192, [=](const Frame& f, ImgArgs& a) {
+        a.head = Wk(hd.off); a.in0 = Wk(face_in_nchw);
+        for (int i = 0; i < 8; ++i) a.out[i] = f.out[11 + i];
+      });
+    }
+    // face_morphed_full / half (mode_07.py:93-103)
+    image_op(ops, paste_face_kernel, 512 * 512, [=](const Frame& f, ImgArgs& a) { a.in0 = f.out[11]; a.out[0] = f.out[5]; });
+    const size_t half_nchw = alloc_work((size_t)4 * 256 * 256);
+    FTensor half = new_tensor(1, 256, 256);
+    image_op(ops, half_image_kernel, 256 * 256, [=](const Frame& f, ImgArgs& a) { a.in0 = f.out[5]; a.out[0] = Wk(half_nchw); a.c16_out = Wk(half.off); });
+    // 4. body morpher
+    {
+      UnetCfg cfg{4, 64, {1, 2, 4, 4, 4}, {false, false, false, false, true}};
+      const HostTensor& fw = get(nets[3], "body.first_conv.weight");
+      const HostTensor& fb = get(nets[3], "body.first_conv.bias");
+      if (!expect(fw, {64, 4, 3, 3}, "body.first_conv.weight") || !fb.data) return false;
+      std::vector<float> bias(fb.data, fb.data + 64);
+      FTensor hd = unet(ops, nets[3], "body.", cfg, {src_tensor(half, 4)}, fw, bias);
+      if (!error.empty()) return false;
+      image_op(ops, unet_tail_kernel<256>, 256 * 256, [=](const Frame& f, ImgArgs& a) {
+        a.head = Wk(hd.off); a.in0 = Wk(half_nchw);
+        for (int i = 0; i < 5; ++i) a.out[i] = f.out[6 + i];
+      });
+    }
+    // 5. upscaler: first_conv(rest) + coarse_image_conv(cat[coarse image, warped rest, coarse grid]) as ONE 14-channel conv
+    {
+      UnetCfg cfg{4, 32, {1, 2, 4, 8, 8, 8}, {false, false, false, false, false, true}};
+      FTensor x = new_tensor(1, 512, 512);
+      image_op(ops, upscaler_input_kernel, 512 * 512, [=](const Frame& f, ImgArgs& a) {
+        a.in0 = f.out[5]; a.in1 = f.out[6]; a.in2 = f.out[9]; a.c16_out = Wk(x.off);
+      });
+      const HostTensor& fw = get(nets[4], "body.first_conv.weight");
+      const HostTensor& fb = get(nets[4], "body.first_conv.bias");
+      const HostTensor& cw = get(nets[4], "coarse_image_conv.weight");
+      const HostTensor& cb = get(nets[4], "coarse_image_conv.bias");
+      if (!expect(fw, {32, 4, 3, 3}, "body.first_conv.weight") || !expect(cw, {32, 10, 3, 3}, "coarse_image_conv.weight") || !fb.data || !cb.data) return false;
+      head_storage.push_back(std::vector<float>((size_t)32 * 14 * 9));
+      std::vector<float>& wc = head_storage.back();
+      for (int o = 0; o < 32; ++o)
+        for (int i = 0; i < 14; ++i)
+          for (int t = 0; t < 9; ++t)
+            wc[((size_t)o * 14 + i) * 9 + t] = i < 4 ? fw.data[((size_t)o * 4 + i) * 9 + t] : cw.data[((size_t)o * 10 + (i - 4)) * 9 + t];
+      HostTensor hw; hw.data = wc.data(); hw.dims = {32, 14, 3, 3};
+      std::vector<float> bias(32);
+      for (int o = 0; o < 32; ++o) bias[o] = fb.data[o] + cb.data[o];
+      FTensor hd = unet(ops, nets[4], "body.", cfg, {src_tensor(x, 14)}, hw, bias);
+      if (!error.empty()) return false;
+      image_op(ops, unet_tail_kernel<512>, 512 * 512, [=](const Frame& f, ImgArgs& a) {
+        a.head = Wk(hd.off); a.in0 = f.out[5];
+        for (int i = 0; i < 5; ++i) a.out[i] = f.out[i];
+      });
+    }
+    head_storage.clear();
+    return error.empty();
+  }
+
+  FTensor comb_in;
+  size_t dec_persist[6];
+
+  // `want_dec[i]`: the caller asked for decomposer output i (copied out of the persistent buffers)
+  void run(const Frame& f, bool run_decomposer, const bool want_dec[6]) {
+    if (run_decomposer)
+      for (auto& op : ops_decomposer) op(f);
+    for (int i = 0; i < 6; ++i)
+      if (want_dec[i])
+        (void)hipMemcpyAsync(f.out[27 + i], Wk(dec_persist[i]), sizeof(float) * (size_t)f.batch * out_ch[27 + i] * 128 * 128,
+                             hipMemcpyDeviceToDevice, f.stream);
+    for (auto& op : ops_rest) op(f);
+  }
+};
+
+}  // namespace tha4

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "siren_kernels.h"
+#include "full_net.h"
 
 using namespace tha4;
 
@@ -260,5 +261,100 @@ int tha4_student_last_ms(tha4_student* h, int kernel, float* ms_out) {
   else HIP_TRY(hipEventElapsedTime(ms_out, h->ev[kernel], h->ev[kernel + 1]));
   return THA4_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// full model (mode_07)
+// ---------------------------------------------------------------------------------------------
+struct tha4_full {
+  int device = 0;
+  FullModel model;
+  bool decomposer_valid = false;
+  int last_batch = 0;
+};
+
+int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
+                     tha4_full** out) {
+  if (!weights || !out) return fail(THA4_ERR_INVALID_ARGUMENT, "weights/out must not be NULL");
+  *out = nullptr;
+  if (max_batch < 1 || max_batch > 256) return fail(THA4_ERR_INVALID_ARGUMENT, "max_batch must be in [1, 256]");
+  if (eyebrow_morphed_image_index != 0 && eyebrow_morphed_image_index != 2)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "eyebrow_morphed_image_index must be 0 or 2");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(THA4_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(THA4_ERR_NO_DEVICE, "device index out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(THA4_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library only contains gfx950 code");
+  WeightMap nets[5];
+  for (int n = 0; n < 5; ++n) {
+    if (!weights->tensors[n] || weights->counts[n] <= 0) return fail(THA4_ERR_INVALID_ARGUMENT, "empty state_dict");
+    for (int i = 0; i < weights->counts[n]; ++i) {
+      const tha4_named_tensor& t = weights->tensors[n][i];
+      if (!t.name || !t.data || t.ndim < 1 || t.ndim > 4) return fail(THA4_ERR_INVALID_ARGUMENT, "malformed named tensor");
+      HostTensor h;
+      h.data = t.data;
+      h.dims.assign(t.dims, t.dims + t.ndim);
+      nets[n][t.name] = h;
+    }
+  }
+  auto* h = new tha4_full();
+  h->device = device;
+  if (!h->model.build(nets, max_batch, eyebrow_morphed_image_index)) {
+    std::string msg = "not a mode_07 model: " + h->model.error;
+    delete h;
+    return fail(THA4_ERR_INVALID_ARGUMENT, msg);
+  }
+  DeviceGuard guard(device);
+  FullModel& m = h->model;
+  hipError_t e = hipMalloc((void**)&m.dev_params, m.host_params.size());
+  if (e == hipSuccess) e = hipMemcpy(m.dev_params, m.host_params.data(), m.host_params.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&m.dev_work, m.work_floats * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(m.dev_work, 0, m.work_floats * sizeof(float));
+  if (e == hipSuccess) e = FullModel::allow_all_conv_lds();
+  std::vector<char>().swap(m.host_params);
+  if (e != hipSuccess) {
+    if (m.dev_params) (void)hipFree(m.dev_params);
+    if (m.dev_work) (void)hipFree(m.dev_work);
+    delete h;
+    return fail(THA4_ERR_HIP, std::string("tha4_full_create: ") + hipGetErrorString(e));
+  }
+  *out = h;
+  return THA4_OK;
+}
+
+int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev, int batch,
+                   float* const* outputs_dev, int reuse_decomposer, void* stream) {
+  if (!h || !image_dev || !pose_dev || !outputs_dev || !outputs_dev[0])
+    return fail(THA4_ERR_INVALID_ARGUMENT, "handle/image/pose/outputs[0] must not be NULL");
+  if (batch < 1) return fail(THA4_ERR_INVALID_ARGUMENT, "batch must be >= 1");
+  if (batch > h->model.max_batch) return fail(THA4_ERR_BATCH_TOO_LARGE, "batch exceeds max_batch given at create");
+  if (image_batch_stride != 0 && image_batch_stride < 4LL * 512 * 512)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "image_batch_stride must be 0 (shared) or >= 4*512*512");
+  DeviceGuard guard(h->device);
+  FullModel& m = h->model;
+  FullModel::Frame f{};
+  f.image = image_dev; f.image_stride = image_batch_stride; f.pose = pose_dev; f.batch = batch;
+  f.stream = static_cast<hipStream_t>(stream);
+  bool want_dec[6];
+  for (int i = 0; i < 33; ++i) f.out[i] = outputs_dev[i] ? outputs_dev[i] : m.Wk(m.scratch_out[i]);
+  for (int i = 0; i < 6; ++i) want_dec[i] = outputs_dev[27 + i] != nullptr;
+  const bool reuse = reuse_decomposer && h->decomposer_valid && h->last_batch == batch;
+  m.run(f, !reuse, want_dec);
+  h->decomposer_valid = true;
+  h->last_batch = batch;
+  HIP_TRY(hipGetLastError());
+  return THA4_OK;
+}
+
+void tha4_full_destroy(tha4_full* h) {
+  if (!h) return;
+  DeviceGuard guard(h->device);
+  if (h->model.dev_params) (void)hipFree(h->model.dev_params);
+  if (h->model.dev_work) (void)hipFree(h->model.dev_work);
+  delete h;
+}
+
+int tha4_full_max_batch(const tha4_full* h) { return h ? h->model.max_batch : THA4_ERR_INVALID_ARGUMENT; }
 
 }  // extern "C"

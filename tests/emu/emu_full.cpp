@@ -71,19 +71,20 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     ConvGeom g = kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1));
     std::vector<float> P = pack_conv_weight(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb);
     ConvArgs a{};
-    a.src[0] = ConvSrc{X0.data(), scale ? sc0.data() : nullptr, scale ? sh0.data() : nullptr, cb0, SRC_TENSOR};
+    a.src[0] = ConvSrc{X0.data(), scale ? sc0.data() : nullptr, scale ? sh0.data() : nullptr, cb0, SRC_TENSOR, act_in};
     a.nsrc = 1;
     if (c1 > 0) {
-      a.src[1] = ConvSrc{X1.data(), scale ? sc1.data() : nullptr, scale ? sh1.data() : nullptr, cb1, vec1 ? SRC_VECTOR : SRC_TENSOR};
+      a.src[1] = ConvSrc{X1.data(), (scale && !vec1) ? sc1.data() : nullptr, (scale && !vec1) ? sh1.data() : nullptr, cb1,
+                          vec1 ? SRC_VECTOR : SRC_TENSOR, vec1 ? ACT_NONE : act_in};   // the pose vector is concatenated raw
       a.nsrc = 2;
     }
-    a.in_h = h; a.in_w = w; a.in_mode = in_mode; a.act_in = act_in;
+    a.in_h = h; a.in_w = w; a.in_mode = in_mode;
     a.ntaps = g.ntaps;
     for (int t = 0; t < g.ntaps; ++t) { a.tap_dy[t] = g.dy[t]; a.tap_dx[t] = g.dx[t]; }
     a.in_stride = g.in_stride;
     a.tile_h = th; a.tile_w = tw; a.out_h = oh; a.out_w = ow;
     a.out_sy = g.out_sy; a.out_sx = g.out_sx; a.out_oy = g.out_oy; a.out_ox = g.out_ox;
-    a.w = P.data(); a.bias = bias ? B.data() : nullptr; a.residual = residual ? R.data() : nullptr;
+    a.w = P.data(); a.bias = bias ? B.data() : nullptr; a.residual = residual ? R.data() : nullptr; a.res_mode = IN_DIRECT;
     a.act_out = act_out ? A.data() : nullptr; a.out = O.data(); a.stats = ST.data();
     a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
     a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
@@ -125,6 +126,7 @@ int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float
   a.stats[1] = st1; a.tiles[1] = tiles1; a.cb[1] = cb1;
   a.nsrc = nsrc; a.channels = channels; a.groups = groups; a.inv_count = inv_count; a.eps = eps;
   a.gamma = gamma; a.beta = beta; a.film0 = film0; a.film1 = film1;
+  a.film0_stride = 2 * channels; a.film1_stride = 2 * channels;
   a.scale[0] = scale0; a.shift[0] = shift0; a.scale[1] = scale1; a.shift[1] = shift1;
   const size_t lds = (size_t)(cb0 + (nsrc > 1 ? cb1 : 0)) * 16 * 2 * sizeof(double);
   for (int i = 0; i < n; ++i) emu::run_block(norm_finalize_kernel, dim3(n), dim3(i), 256, lds, a);
@@ -132,7 +134,7 @@ int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float
 }
 
 int emu_gemv(int n, int rows, int k, const float* w, const float* bias, const float* x, int act_in, int act_out, float* y) {
-  GemvArgs a{w, bias, x, y, rows, k, act_in, act_out};
+  GemvArgs a{w, bias, x, y, rows, k, (long long)k, act_in, act_out};
   dim3 grid((rows + 3) / 4, n);
   for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) emu::run_block(gemv_kernel, grid, dim3(bx, by), 256, 0, a);

@@ -54,12 +54,18 @@ def ref_conv(kind, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, re
     x = t(x0)
     if x1 is not None:
         xx1 = t(x1)
-        if vec1:
-            xx1 = xx1[:, :, None, None].expand(-1, -1, x.shape[2], x.shape[3])
-        x = torch.cat([x, xx1], dim=1)
-    if scale is not None:
-        x = x * t(scale)[:, :, None, None] + t(shift)[:, :, None, None]
-    x = torch_act(x, act_in)
+    if x1 is not None and vec1:
+        # pose vector: concatenated raw AFTER the producer's norm + activation (poser_encoder_decoder_00.py:108-113)
+        c0 = x.shape[1]
+        if scale is not None:
+            x = x * t(scale)[:, :c0, None, None] + t(shift)[:, :c0, None, None]
+        x = torch.cat([torch_act(x, act_in), xx1[:, :, None, None].expand(-1, -1, x.shape[2], x.shape[3])], dim=1)
+    else:
+        if x1 is not None:
+            x = torch.cat([x, xx1], dim=1)
+        if scale is not None:
+            x = x * t(scale)[:, :, None, None] + t(shift)[:, :, None, None]
+        x = torch_act(x, act_in)
     if in_mode == 1:
         x = F.interpolate(x, scale_factor=2, mode="nearest")
     elif in_mode == 2:
