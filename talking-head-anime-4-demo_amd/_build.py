@@ -10,7 +10,10 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(CSRC, "libtha4_hip.so")
 SOURCES = ["tha4_capi.hip"]
-HEADERS = ["siren_kernels.h", "siren_layout.h", "tha4_platform.h"]
+
+
+def _headers():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 
 
 def _stale(target: str, deps) -> bool:
@@ -28,7 +31,7 @@ def hipcc_path() -> str:
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "tha4_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + _headers()] + [os.path.join(INCLUDE, "tha4_hip.h")]
     if not force and not _stale(LIB, deps):
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

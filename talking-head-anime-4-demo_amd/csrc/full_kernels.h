@@ -307,6 +307,155 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-K convolution for the small feature maps (16x16 .. 32x32, 256-512 channels): these layers hold
+// >25% of a frame's launches but only 16..64 pixel groups, so the pixel-tiled kernel above leaves most
+// CUs idle and each wave latency-bound.  Here a workgroup owns ONE pixel group and TMB output blocks; its
+// 4 waves take the (quad, tap) steps s = wave, wave+4, ... and read BOTH operands straight from L2
+// (weights are 1 KiB fragment-linear pieces, one coalesced load per lane), prefetching the next step under
+// the current MFMAs; partial fragments are combined through LDS in a fixed order (deterministic) and wave 0
+// runs the same epilogue.  grid = (pixel groups over the batch, output tiles).
+// ---------------------------------------------------------------------------------------------
+template <int TMB, int INMODE>
+__global__ void __launch_bounds__(256) conv_splitk_kernel(ConvArgs a) {
+  constexpr int NV = INMODE == IN_POOL2 ? 4 : 1;
+  THA4_DYN_LDS(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform_i32(threadIdx.x >> 6);
+  const int p = lane & 15, g4 = (lane >> 4) * 4;
+  const int pgs_per_frame = a.tile_h * a.tile_w / 16;
+  const int n = blockIdx.x / pgs_per_frame;
+  const int tile = blockIdx.x % pgs_per_frame;
+  const int mtile = blockIdx.y;
+  const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (INMODE == IN_POOL2 ? a.in_h / 2 : a.in_h);
+  const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (INMODE == IN_POOL2 ? a.in_w / 2 : a.in_w);
+  const int in_px = a.in_h * a.in_w;
+  const int pix = tile * 16 + p;
+  const int ty = pix / a.tile_w, tx = pix % a.tile_w;
+  int cbtot = 0;
+  for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
+  const int nsteps = cbtot * a.ntaps;
+  const float* gw = a.w + (size_t)mtile * cbtot * a.ntaps * TMB * 256;
+
+  struct Step { f32x4 b[NV]; f32x4 sc, sh; f32x4 w[TMB]; bool valid; int act; };
+  auto load_step = [&](int s, Step& st) {
+    const int q = s / a.ntaps, t = s - q * a.ntaps;
+    int si = 0, ql = q;
+    if (a.nsrc > 1 && q >= a.src[0].cb) { si = 1; ql = q - a.src[0].cb; }
+    const ConvSrc& S = a.src[si];
+    st.act = S.act;
+    if (S.scale) {
+      st.sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + g4);
+      st.sh = *reinterpret_cast<const f32x4*>(S.shift + ((size_t)n * S.cb + ql) * 16 + g4);
+    } else {
+      st.sc = f32x4{1.f, 1.f, 1.f, 1.f};
+      st.sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int vy = ty * a.in_stride + a.tap_dy[t], vx = tx * a.in_stride + a.tap_dx[t];
+    st.valid = (unsigned)vy < (unsigned)vh && (unsigned)vx < (unsigned)vw;
+    const int cy = min(max(vy, 0), vh - 1), cx = min(max(vx, 0), vw - 1);
+    if (S.kind == SRC_VECTOR) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) st.b[i] = *reinterpret_cast<const f32x4*>(S.data + ((size_t)n * S.cb + ql) * 16 + g4);
+    } else {
+      const float* base = S.data + (((size_t)n * S.cb + ql) * in_px) * 16 + g4;
+      if (INMODE == IN_DIRECT) {
+        st.b[0] = *reinterpret_cast<const f32x4*>(base + ((size_t)cy * a.in_w + cx) * 16);
+      } else if (INMODE == IN_UP2) {
+        st.b[0] = *reinterpret_cast<const f32x4*>(base + ((size_t)(cy >> 1) * a.in_w + (cx >> 1)) * 16);
+      } else {
+        const float* b00 = base + ((size_t)(2 * cy) * a.in_w + 2 * cx) * 16;
+        st.b[0] = *reinterpret_cast<const f32x4*>(b00);
+        st.b[NV > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(b00 + 16);
+        st.b[NV > 1 ? 2 : 0] = *reinterpret_cast<const f32x4*>(b00 + (size_t)a.in_w * 16);
+        st.b[NV > 1 ? 3 : 0] = *reinterpret_cast<const f32x4*>(b00 + (size_t)a.in_w * 16 + 16);
+      }
+    }
+    const f32x4* wp = reinterpret_cast<const f32x4*>(gw + (size_t)s * TMB * 256) + lane;
+#pragma unroll
+    for (int b = 0; b < TMB; ++b) st.w[b] = wp[b * 64];
+  };
+  auto operand = [&](const Step& st) -> f32x4 {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v;
+      if (NV == 4) {
+        v = ((apply_act(fmaf(st.b[0][j], st.sc[j], st.sh[j]), st.act) + apply_act(fmaf(st.b[NV > 1 ? 1 : 0][j], st.sc[j], st.sh[j]), st.act)) +
+             (apply_act(fmaf(st.b[NV > 1 ? 2 : 0][j], st.sc[j], st.sh[j]), st.act) + apply_act(fmaf(st.b[NV > 1 ? 3 : 0][j], st.sc[j], st.sh[j]), st.act))) * 0.25f;
+      } else {
+        v = apply_act(fmaf(st.b[0][j], st.sc[j], st.sh[j]), st.act);
+      }
+      o[j] = st.valid ? v : 0.0f;
+    }
+    return o;
+  };
+
+  f32x4 acc[TMB];
+#pragma unroll
+  for (int b = 0; b < TMB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Step nxt;
+  if (wave < nsteps) load_step(wave, nxt);
+  for (int s = wave; s < nsteps; s += 4) {
+    const Step cur = nxt;
+    if (s + 4 < nsteps) load_step(s + 4, nxt);
+    const f32x4 bf = operand(cur);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < TMB; ++b) acc[b] = mfma16(cur.w[b][j], bf[j], acc[b]);
+  }
+  // fixed-order combination of the four K slices
+  f32x4* red = reinterpret_cast<f32x4*>(smem);      // [4][TMB][64]
+#pragma unroll
+  for (int b = 0; b < TMB; ++b) red[(wave * TMB + b) * 64 + lane] = acc[b];
+  __syncthreads();
+  if (wave != 0) return;
+  const int out_px = a.out_h * a.out_w;
+  const int oy = ty * a.out_sy + a.out_oy, ox = tx * a.out_sx + a.out_ox;
+#pragma unroll
+  for (int b = 0; b < TMB; ++b) {
+    const int bo = mtile * TMB + b;
+    f32x4 v = (red[(0 * TMB + b) * 64 + lane] + red[(1 * TMB + b) * 64 + lane]) + (red[(2 * TMB + b) * 64 + lane] + red[(3 * TMB + b) * 64 + lane]);
+    if (a.bias) v = v + *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+    const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
+    if (a.residual) {
+      if (a.res_mode == IN_DIRECT) {
+        v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
+      } else if (a.res_mode == IN_UP2) {
+        const int rw = a.out_w >> 1, rpx = out_px >> 2;
+        v = v + *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
+      } else {
+        const int rw = a.out_w * 2;
+        const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
+        v = v + ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
+                 (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
+      }
+    }
+    if (a.act_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
+    }
+    *reinterpret_cast<f32x4*>(a.out + off) = v;
+    if (a.stats) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float su = v[j], sq = v[j] * v[j];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          su += lane_read(su, lane ^ m);
+          sq += lane_read(sq, lane ^ m);
+        }
+        if (p == 0) {
+          float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
+          dst[0] = su;
+          dst[1] = sq;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ResnetBlock output (resnet_block.py:63-67): out = actA(A*sa+ha) + (B*sb+hb) on C16 tensors of equal
 // shape; scale/shift are per (n, channel) vectors or null (identity).  One thread per 16-byte quad.
 // ---------------------------------------------------------------------------------------------
@@ -367,30 +516,42 @@ struct NormArgs {
   float* shift[2];
 };
 
-__global__ void __launch_bounds__(256) norm_finalize_kernel(NormArgs a) {
+constexpr int kNormThreads = 1024;
+__global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a) {
   THA4_DYN_LDS(smem);
-  double* csum = reinterpret_cast<double*>(smem);            // [ctot]
-  double* csq = csum + (a.cb[0] + (a.nsrc > 1 ? a.cb[1] : 0)) * 16;
   const int n = blockIdx.x;
   const int c0 = a.cb[0] * 16;
   const int ctot = c0 + (a.nsrc > 1 ? a.cb[1] * 16 : 0);
-  for (int c = threadIdx.x; c < ctot; c += 256) {
+  // thread (slice, c): channel c = t % ctot sums tiles slice, slice+S, ... in fp64; consecutive threads read
+  // consecutive channels of one tile row (coalesced).  Slices are then combined in a fixed order: deterministic.
+  const int S = max(1, kNormThreads / ctot);                 // tile slices (ctot <= 1024)
+  double* part = reinterpret_cast<double*>(smem);            // [S][ctot][2]
+  double* csum = part + (size_t)S * ctot * 2;                // [ctot]
+  double* csq = csum + ctot;
+  for (int c = threadIdx.x % ctot, sl = threadIdx.x / ctot; sl < S && c < ctot; sl += kNormThreads) {   // one pass (S*ctot <= threads)
     const int s = c < c0 ? 0 : 1;
     const int cl = c - (s ? c0 : 0);
     const int cw = a.cb[s] * 16;
     const float* ps = a.stats[s] + ((size_t)n * a.tiles[s] * cw + cl) * 2;
     double su = 0.0, sq = 0.0;
-    for (int t = 0; t < a.tiles[s]; ++t) {
+    for (int t = sl; t < a.tiles[s]; t += S) {
       su += (double)ps[(size_t)t * cw * 2];
       sq += (double)ps[(size_t)t * cw * 2 + 1];
     }
+    part[((size_t)sl * ctot + c) * 2] = su;
+    part[((size_t)sl * ctot + c) * 2 + 1] = sq;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ctot; c += kNormThreads) {
+    double su = 0.0, sq = 0.0;
+    for (int sl = 0; sl < S; ++sl) { su += part[((size_t)sl * ctot + c) * 2]; sq += part[((size_t)sl * ctot + c) * 2 + 1]; }
     csum[c] = su;
     csq[c] = sq;
   }
   __syncthreads();
   // logical channel index of padded channel c: source 0 holds channels [0, C0real), source 1 the rest.
   // Both sources are exact multiples of 16 whenever two are concatenated (unet.py skip widths).
-  for (int c = threadIdx.x; c < ctot; c += 256) {
+  for (int c = threadIdx.x; c < ctot; c += kNormThreads) {
     const int s = c < c0 ? 0 : 1;
     const int cl = c - (s ? c0 : 0);
     float sc = 0.f, sh = 0.f;
@@ -467,46 +628,59 @@ struct AttnArgs {
   int tokens;     // 256
 };
 
+constexpr int kAttnHeadDim = 32;     // 256 channels / 8 heads (mode_07.py:222-224,253-255)
 __global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
   THA4_DYN_LDS(smem);
-  const int ch = a.channels / a.heads;     // 32
+  constexpr int CH = kAttnHeadDim;
   const int L = a.tokens;
-  float* ks = reinterpret_cast<float*>(smem);   // [L][ch]
-  float* vs = ks + L * ch;                       // [L][ch]
+  f32x4* ks = reinterpret_cast<f32x4*>(smem);   // [L][CH/4]
+  f32x4* vs = ks + L * (CH / 4);                // [L][CH/4]
   const int n = blockIdx.y, h = blockIdx.x, t = threadIdx.x;
   const int cbq = a.channels / 16;
-  const float scale = 1.0f / sqrtf(sqrtf((float)ch));
-  auto at = [&](int c, int tok) -> float {   // channel c of the qkv tensor
-    return a.qkv[(((size_t)n * 3 * cbq + (c >> 4)) * L + tok) * 16 + (c & 15)];
-  };
-  float q[32];
-  for (int c = 0; c < ch; ++c) {
-    q[c] = at(h * ch + c, t) * scale;
-    ks[t * ch + c] = at(a.channels + h * ch + c, t) * scale;
-    vs[t * ch + c] = at(2 * a.channels + h * ch + c, t);
+  const float scale = 1.0f / sqrtf(sqrtf((float)CH));
+  // head h owns channels [h*32, h*32+32) of q, k and v = two C16 blocks each; a token's 16 channels are contiguous
+  const float* qp = a.qkv + (((size_t)n * 3 * cbq + 2 * h) * L + t) * 16;
+  const float* kp = a.qkv + (((size_t)n * 3 * cbq + cbq + 2 * h) * L + t) * 16;
+  const float* vp = a.qkv + (((size_t)n * 3 * cbq + 2 * cbq + 2 * h) * L + t) * 16;
+  f32x4 q[CH / 4];
+#pragma unroll
+  for (int i = 0; i < CH / 4; ++i) {
+    const size_t off = (size_t)(i / 4) * L * 16 + (i % 4) * 4;    // block i/4, floats (i%4)*4.. within the token's 16
+    q[i] = *reinterpret_cast<const f32x4*>(qp + off) * scale;
+    ks[t * (CH / 4) + i] = *reinterpret_cast<const f32x4*>(kp + off) * scale;
+    vs[t * (CH / 4) + i] = *reinterpret_cast<const f32x4*>(vp + off);
   }
   __syncthreads();
-  float m = -3.0e38f;
-  for (int s = 0; s < L; ++s) {
+  auto score = [&](int s) -> float {
     float d = 0.f;
-    for (int c = 0; c < ch; ++c) d = fmaf(q[c], ks[s * ch + c], d);
-    m = fmaxf(m, d);
-  }
-  float o[32];
-  for (int c = 0; c < ch; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) {
+      const f32x4 k4 = ks[s * (CH / 4) + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d = fmaf(q[i][j], k4[j], d);
+    }
+    return d;
+  };
+  float m = -3.0e38f;
+  for (int s = 0; s < L; ++s) m = fmaxf(m, score(s));
+  f32x4 o[CH / 4];
+#pragma unroll
+  for (int i = 0; i < CH / 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float den = 0.f;
   for (int s = 0; s < L; ++s) {
-    float d = 0.f;
-    for (int c = 0; c < ch; ++c) d = fmaf(q[c], ks[s * ch + c], d);
-    const float e = expf(d - m);
+    const float e = expf(score(s) - m);
     den += e;
-    for (int c = 0; c < ch; ++c) o[c] = fmaf(e, vs[s * ch + c], o[c]);
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) {
+      const f32x4 v4 = vs[s * (CH / 4) + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[i][j] = fmaf(e, v4[j], o[i][j]);
+    }
   }
   const float inv = 1.0f / den;
-  for (int c = 0; c < ch; ++c) {
-    const int cc = h * ch + c;
-    a.out[(((size_t)n * cbq + (cc >> 4)) * L + t) * 16 + (cc & 15)] = o[c] * inv;
-  }
+  float* op = a.out + (((size_t)n * cbq + 2 * h) * L + t) * 16;
+#pragma unroll
+  for (int i = 0; i < CH / 4; ++i) *reinterpret_cast<f32x4*>(op + (size_t)(i / 4) * L * 16 + (i % 4) * 4) = o[i] * inv;
 }
 
 }  // namespace tha4

@@ -155,10 +155,15 @@ class FullModel {
     const int tmb = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
     const int mtiles = nb / tmb;
     const int tile_px = th * tw;
+    int cbtot = 0;
+    for (auto& s : srcs) cbtot += (s.channels + 15) / 16;
+    const int ntaps_k = kind == K_SAME3 ? 9 : kind == K_SAME1 ? 1 : kind == K_S2K4 ? 16 : 4;
+    // small maps (<= 32x32): one pixel group per workgroup, K split over its 4 waves (conv_splitk_kernel)
+    const bool splitk = tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
     int pg = 1;
-    if (tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
-    if (tile_px % (64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of 64 pixels"; return FTensor(); }
-    const int tiles = tile_px / (64 * pg);
+    if (!splitk && tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
+    if (tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
+    const int tiles = splitk ? tile_px / 16 : tile_px / (64 * pg);
     FTensor out = new_tensor(nb, oh, ow);
     if (want_stats) {
       out.stats_tiles = tiles * nclass;
@@ -172,8 +177,6 @@ class FullModel {
     }
     size_t act_off = kNone;
     if (act_out) { std::vector<int> a(nb * 16, 0); for (int i = 0; i < cout; ++i) a[i] = (*act_out)[i]; act_off = add_param_i(a); }
-    int cbtot = 0;
-    for (auto& s : srcs) cbtot += (s.channels + 15) / 16;
     for (int cls = 0; cls < nclass; ++cls) {
       ConvGeom g = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1)
                  : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1);
@@ -214,7 +217,14 @@ class FullModel {
         c.out = Wk(outc.off);
         c.stats = outc.stats_tiles ? Wk(outc.stats_off) : nullptr;
         c.batch = f.batch;
-        dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
+        if (splitk) {
+          const dim3 grid(f.batch * tiles, mtiles);
+          if (in_mode == IN_DIRECT) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_DIRECT>), grid, dim3(256), 16 * 1024, f.stream, c);
+          else if (in_mode == IN_UP2) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_UP2>), grid, dim3(256), 16 * 1024, f.stream, c);
+          else hipLaunchKernelGGL((conv_splitk_kernel<4, IN_POOL2>), grid, dim3(256), 16 * 1024, f.stream, c);
+        } else {
+          dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
+        }
       });
     }
     return out;
@@ -248,7 +258,8 @@ class FullModel {
       a.gamma = P(g_off); a.beta = P(b_off);
       a.film0 = film0_off == kNone ? nullptr : P(film0_off); a.film0_stride = 0;
       a.film1 = film1_off == kNone ? nullptr : Wk(film1_off); a.film1_stride = film1_stride;
-      hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch), dim3(256), (size_t)cbt * 16 * 2 * sizeof(double), f.stream, a);
+      const int ctot = cbt * 16, S = std::max(1, kNormThreads / ctot);
+      hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch), dim3(kNormThreads), ((size_t)S * ctot * 2 + 2 * ctot) * sizeof(double), f.stream, a);
     });
     return out;
   }

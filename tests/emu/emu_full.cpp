@@ -59,8 +59,9 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   std::vector<int> A((size_t)nb * 16, 0);
   if (act_out) std::memcpy(A.data(), act_out, sizeof(int) * cout);
   std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
-  const int tiles_per_class = (th * tw / 16) / (4 * pg);
-  if (tiles_per_class * 4 * pg * 16 != th * tw) return -2;
+  const bool splitk = pg == 0;
+  const int tiles_per_class = splitk ? th * tw / 16 : (th * tw / 16) / (4 * pg);
+  if (!splitk && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
   const int stats_tiles = tiles_per_class * nclass;
   std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
   std::vector<ChannelSegment> segs = {{0, c0}};
@@ -88,7 +89,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     a.act_out = act_out ? A.data() : nullptr; a.out = O.data(); a.stats = ST.data();
     a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
     a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
-    const size_t lds = 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
+    const size_t lds = splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
     dim3 grid(n * tiles_per_class, mtiles);
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -99,6 +100,11 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     else emu::run_block(conv_mfma_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by), 256, lds, a);                       \
   }
         RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
+        if (splitk && tmb == 4) {
+          if (in_mode == IN_DIRECT) emu::run_block(conv_splitk_kernel<4, IN_DIRECT>, grid, dim3(bx, by), 256, lds, a);
+          else if (in_mode == IN_UP2) emu::run_block(conv_splitk_kernel<4, IN_UP2>, grid, dim3(bx, by), 256, lds, a);
+          else emu::run_block(conv_splitk_kernel<4, IN_POOL2>, grid, dim3(bx, by), 256, lds, a);
+        }
 #undef RUN
       }
   }
@@ -128,8 +134,9 @@ int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float
   a.gamma = gamma; a.beta = beta; a.film0 = film0; a.film1 = film1;
   a.film0_stride = 2 * channels; a.film1_stride = 2 * channels;
   a.scale[0] = scale0; a.shift[0] = shift0; a.scale[1] = scale1; a.shift[1] = shift1;
-  const size_t lds = (size_t)(cb0 + (nsrc > 1 ? cb1 : 0)) * 16 * 2 * sizeof(double);
-  for (int i = 0; i < n; ++i) emu::run_block(norm_finalize_kernel, dim3(n), dim3(i), 256, lds, a);
+  const int ctot = (cb0 + (nsrc > 1 ? cb1 : 0)) * 16, S = std::max(1, kNormThreads / ctot);
+  const size_t lds = ((size_t)S * ctot * 2 + 2 * ctot) * sizeof(double);
+  for (int i = 0; i < n; ++i) emu::run_block(norm_finalize_kernel, dim3(n), dim3(i), kNormThreads, lds, a);
   return 0;
 }
 

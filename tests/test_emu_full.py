@@ -96,6 +96,11 @@ CASES = [
     (0, 3, 2, 1, 1, "silu", 16, 0, False, 4, 8, 32, True, False, False, True, 1),     # nearest-up x2 on load
     (0, 3, 2, 1, 2, "silu", 16, 0, False, 16, 16, 32, True, False, False, True, 1),   # avg-pool 2x2 on load
     (0, 3, 1, 1, 0, "relu", 64, 0, False, 8, 8, 10, True, False, True, False, 4),     # head block: mixed sigmoid/tanh/none rows
+    (0, 3, 4, 0, 0, "relu", 48, 27, True, 12, 12, 64, False, False, False, True, 1),   # split-K kernel (pg=0): bottleneck entry with pose vector
+    (0, 3, 4, 0, 0, "silu", 32, 32, False, 8, 8, 64, True, True, False, True, 1),     # split-K: concat + residual (U-Net middle)
+    (0, 1, 4, 0, 0, "none", 64, 0, False, 8, 8, 192, True, False, False, True, 1),    # split-K: 1x1 qkv projection
+    (2, 4, 4, 0, 0, "relu", 32, 0, False, 8, 8, 64, False, False, False, True, 1),    # split-K: convT 4x4 s2
+    (0, 3, 4, 0, 2, "silu", 32, 0, False, 16, 16, 64, True, False, False, True, 1),   # split-K: avg-pool on load
     (0, 3, 2, 1, 0, "none", 4, 0, False, 24, 24, 32, True, False, False, False, 1),   # 4-channel image input, 24x24 (rows not a multiple of 16 px)
 ]
 
