@@ -161,6 +161,23 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
 void tha4_full_destroy(tha4_full* h);
 int tha4_full_max_batch(const tha4_full* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * Callers / data formats either side of the path.  Stateless, device pointers.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Replaces the on-device post-processing every puppeteer runs after pose()
+ * (src/tha4/app/character_model_ifacialmocap_puppeteer.py:325-349,377-381; src/tha4/image_util.py:56-58):
+ * clip((x+1)/2,0,1) -> linear->sRGB on RGB -> optional blend over an opaque background colour ->
+ * CHW->HWC -> *255 -> truncate to uint8.   frames_dev fp32 [B,4,H,W] -> out_dev uint8 [B,H,W,4].
+ * background_rgb: 3 host floats in [0,1] or NULL (keep the frame's alpha). */
+int tha4_display_rgba8(const float* frames_dev, int batch, int height, int width, const float* background_rgb,
+                       uint8_t* out_dev, void* stream);
+
+/* Replaces extract_pytorch_image_from_PIL_image (src/tha4/shion/base/image_util.py:127-149,194-198) for an
+ * RGBA8 image already on the device: /255 -> sRGB->linear on RGB -> premultiply alpha -> *2-1 -> HWC->CHW.
+ * rgba_dev uint8 [B,H,W,4] -> out_dev fp32 [B,4,H,W]. */
+int tha4_ingest_rgba8(const uint8_t* rgba_dev, int batch, int height, int width, float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.tha4_full_destroy.argtypes = [C.c_void_p]
     lib.tha4_full_max_batch.restype = C.c_int
     lib.tha4_full_max_batch.argtypes = [C.c_void_p]
+    lib.tha4_display_rgba8.restype = C.c_int
+    lib.tha4_display_rgba8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p, C.c_void_p, C.c_void_p]
+    lib.tha4_ingest_rgba8.restype = C.c_int
+    lib.tha4_ingest_rgba8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     v = lib.tha4_abi_version()
     if v != THA4_ABI_VERSION:
         raise Tha4Error(f"libtha4_hip.so ABI version {v} != expected {THA4_ABI_VERSION}")
@@ -183,6 +187,7 @@ EXPORTED_SYMBOLS = [
     "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_pose", "tha4_student_destroy",
     "tha4_student_max_batch", "tha4_student_device", "tha4_student_set_timing", "tha4_student_last_ms",
     "tha4_full_create", "tha4_full_pose", "tha4_full_destroy", "tha4_full_max_batch",
+    "tha4_display_rgba8", "tha4_ingest_rgba8",
 ]
 
 

@@ -1,0 +1,75 @@
+// §8(f) "next" rows either side of the poser path: the display epilogue every real-time caller runs
+// right after pose(), and the image ingest that produces the path's input.  Pointwise and HBM-bound:
+// 16-byte vector accesses, one thread per pixel, the RGBA8 side moves 4 bytes per pixel.
+//
+// Reference (paths relative to /root/reference/src/tha4):
+//   app/character_model_ifacialmocap_puppeteer.py:325-349,377-381  clip((x+1)/2) -> linear->sRGB -> optional
+//                                                                  background blend -> HWC -> *255 -> .byte()
+//   image_util.py:56-58, shion/base/image_util.py:31-33            convert_linear_to_srgb / torch_linear_to_srgb
+//   shion/base/image_util.py:10-12,127-149,194-198                 PIL RGBA8 -> sRGB->linear -> premultiply -> *2-1 -> CHW
+#pragma once
+#include "tha4_platform.h"
+
+namespace tha4 {
+
+THA4_DEV float linear_to_srgb(float x) {
+  x = fminf(fmaxf(x, 0.0f), 1.0f);
+  return x <= 0.003130804953560372f ? x * 12.92f : 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+}
+THA4_DEV float srgb_to_linear(float x) {
+  x = fminf(fmaxf(x, 0.0f), 1.0f);
+  return x <= 0.04045f ? x / 12.92f : powf((x + 0.055f) / 1.055f, 2.4f);
+}
+
+struct DisplayArgs {
+  const float* frames;     // [B][4][H*W] poser output, values in [-1,1]
+  unsigned char* out;      // [B][H*W][4] RGBA8 (HWC, what wx.ImageFromBuffer / a video encoder takes)
+  int pixels;
+  int has_background;      // 0: keep alpha | 1: blend over an opaque background colour (alpha becomes 1)
+  float bg[3];             // background colour in the SAME (sRGB-encoded, [0,1]) space the reference blends in
+};
+
+__global__ void __launch_bounds__(256) display_rgba8_kernel(DisplayArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (i >= a.pixels) return;
+  const float* f = a.frames + (size_t)n * 4 * a.pixels + i;
+  float c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = fminf(fmaxf((f[(size_t)k * a.pixels] + 1.0f) * 0.5f, 0.0f), 1.0f);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c[k] = linear_to_srgb(c[k]);
+  if (a.has_background) {      // blend_with_background (:377-381)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = c[k] * c[3] + (1.0f - c[3]) * a.bg[k];
+    c[3] = 1.0f;
+  }
+  uchar4 o;
+  o.x = (unsigned char)(255.0f * c[0]);    // torch .byte(): truncation
+  o.y = (unsigned char)(255.0f * c[1]);
+  o.z = (unsigned char)(255.0f * c[2]);
+  o.w = (unsigned char)(255.0f * c[3]);
+  reinterpret_cast<uchar4*>(a.out)[(size_t)n * a.pixels + i] = o;
+}
+
+struct IngestArgs {
+  const unsigned char* rgba;   // [B][H*W][4]
+  float* out;                  // [B][4][H*W]
+  int pixels;
+};
+
+__global__ void __launch_bounds__(256) ingest_rgba8_kernel(IngestArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (i >= a.pixels) return;
+  const uchar4 v = reinterpret_cast<const uchar4*>(a.rgba)[(size_t)n * a.pixels + i];
+  const float al = (float)v.w / 255.0f;
+  const float r = srgb_to_linear((float)v.x / 255.0f) * al;      // premultiplied, linear
+  const float g = srgb_to_linear((float)v.y / 255.0f) * al;
+  const float b = srgb_to_linear((float)v.z / 255.0f) * al;
+  float* o = a.out + (size_t)n * 4 * a.pixels + i;
+  o[0] = r * 2.0f - 1.0f;
+  o[(size_t)a.pixels] = g * 2.0f - 1.0f;
+  o[(size_t)2 * a.pixels] = b * 2.0f - 1.0f;
+  o[(size_t)3 * a.pixels] = al * 2.0f - 1.0f;
+}
+
+}  // namespace tha4

@@ -12,6 +12,7 @@
 
 #include "siren_kernels.h"
 #include "full_net.h"
+#include "image_io_kernels.h"
 
 using namespace tha4;
 
@@ -356,5 +357,27 @@ void tha4_full_destroy(tha4_full* h) {
 }
 
 int tha4_full_max_batch(const tha4_full* h) { return h ? h->model.max_batch : THA4_ERR_INVALID_ARGUMENT; }
+
+int tha4_display_rgba8(const float* frames_dev, int batch, int height, int width, const float* background_rgb,
+                       uint8_t* out_dev, void* stream) {
+  if (!frames_dev || !out_dev || batch < 1 || height < 1 || width < 1)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "frames/out must not be NULL and batch/size must be positive");
+  DisplayArgs a{};
+  a.frames = frames_dev; a.out = out_dev; a.pixels = height * width;
+  a.has_background = background_rgb != nullptr;
+  if (background_rgb) for (int k = 0; k < 3; ++k) a.bg[k] = background_rgb[k];
+  hipLaunchKernelGGL(display_rgba8_kernel, dim3((a.pixels + 255) / 256, batch), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  HIP_TRY(hipGetLastError());
+  return THA4_OK;
+}
+
+int tha4_ingest_rgba8(const uint8_t* rgba_dev, int batch, int height, int width, float* out_dev, void* stream) {
+  if (!rgba_dev || !out_dev || batch < 1 || height < 1 || width < 1)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "rgba/out must not be NULL and batch/size must be positive");
+  IngestArgs a{rgba_dev, out_dev, height * width};
+  hipLaunchKernelGGL(ingest_rgba8_kernel, dim3((a.pixels + 255) / 256, batch), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  HIP_TRY(hipGetLastError());
+  return THA4_OK;
+}
 
 }  // extern "C"

@@ -104,3 +104,30 @@ def test_state_dict_struct_rejects_wrong_architecture(golden_weights):
     del bad["last_linear.bias"]
     with pytest.raises(KeyError):
         _capi.build_student_weights(face, bad)
+
+
+def test_mode_07_surface_and_defaults():
+    from tha4_amd.poser.modes import mode_07
+    names = {}
+    poser = mode_07.create_poser(torch.device("cpu"), module_file_names=names)
+    assert names == {n: f"data/tha4/{n}.pt" for n in
+                     ["eyebrow_decomposer", "eyebrow_morphing_combiner", "face_morpher", "body_morpher", "upscaler"]}
+    assert [n.name for n in mode_07.Network] == list(names)
+    assert mode_07.Network.upscaler.outputs_key == "upscaler_outputs"
+    assert isinstance(poser, Poser)
+    assert poser.get_output_length() == 33 and poser.get_image_size() == 512 and poser.get_num_parameters() == 45
+    with pytest.raises(_capi.Tha4Error, match="no CPU path"):
+        poser.pose(torch.zeros(4, 512, 512), torch.zeros(45))
+
+
+def test_full_weight_struct_and_create_validation(built):
+    from tha4_amd import synthetic
+    shapes = synthetic.full_param_shapes()
+    tiny = {net: {k: np.zeros(s, np.float32) for k, s in list(d.items())[:3]} for net, d in shapes.items()}
+    ws, keep = _capi.build_full_weights(tiny)
+    assert [ws.counts[i] for i in range(5)] == [3] * 5
+    assert ws.tensors[0][0].name == b"body.downsample_blocks.0.0.weight" and ws.tensors[0][0].ndim == 4
+    lib = _capi.load_library()
+    assert lib.tha4_full_create(None, 2, 0, 1, None) == -1
+    assert lib.tha4_full_pose(None, None, 0, None, 1, None, 0, None) == -1
+    lib.tha4_full_destroy(None)

@@ -197,3 +197,16 @@ def test_wrong_shapes_raise_like_the_reference(poser, dev):
         poser.pose(torch.zeros(4, 512, 512, device=dev), torch.zeros(44, device=dev))
     with pytest.raises(AssertionError):
         poser.pose(torch.zeros(4, 512, 512, device=dev).double(), torch.zeros(45, device=dev))
+
+
+def test_config4_batch32_shared_image(poser, dev, golden_io, golden_weights):
+    """BASELINE configs[3] shape: one character instance, batches of 32 poses."""
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    poses_np = so.random_poses(32, seed=2024)
+    poses = torch.from_numpy(poses_np).to(dev)
+    out = poser.pose(image, poses)
+    assert out.shape == (32, 4, 512, 512)
+    for i in (0, 13, 31):
+        assert torch.equal(out[i], poser.pose(image, poses[i])[0])
+    ref = so.student_forward_torch(golden_weights, golden_io["image_f32"], poses_np[[0, 31]], "float32")[0].numpy()
+    assert np.abs(out[[0, 31]].cpu().numpy() - ref).max() <= TOL_OUT0

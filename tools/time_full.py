@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import tha4_amd  # noqa
 from tha4_amd.poser.modes import mode_07
-from oracle import full_oracle as fo   # weights synthesis only (test/bench infrastructure)
+from tha4_amd import synthetic as fo
 dev = torch.device("cuda:0")
 w = fo.synth_full_weights()
 p = mode_07.create_poser_from_state_dicts(dev, w)
