@@ -231,7 +231,7 @@ def main():
                     "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
                     "whole_frame_frac": round(fps / world * GFLOP_FRAME / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "algorithmic_gflop_per_frame": GFLOP_FRAME, "executed_gflop_per_frame": GFLOP_EXECUTED_FRAME}
-        cpu = cpu_baseline(w, image_np, poses_cpu, args.cpu_seconds) if args.cpu_seconds > 0 else None
+        cpu = cpu_baseline(w, image_np, poses_cpu, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
         full = None
         if args.full_frames > 0 and world == 1:
             try:
