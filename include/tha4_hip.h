@@ -93,6 +93,15 @@ const char* tha4_last_error(void);
 int tha4_student_create(const tha4_student_weights* weights, const tha4_position_axes* axes,
                         int device, int max_batch, tha4_student** out);
 
+/* Same with options.  flags:
+ *   THA4_STUDENT_EXACT_FP32  run the contractions on v_mfma_f32_16x16x4_f32 (exact fp32 products, csrc/siren_kernels.h)
+ *                            instead of the default 3-pass fp16 hi/lo split on v_mfma_f32_16x16x32_f16
+ *                            (csrc/siren16_kernels.h: 22-bit operands, fp32 accumulate; same distance to the fp64
+ *                            reference, ~3x faster).  Both stay inside the 1e-3 gate; this flag is the A/B switch. */
+#define THA4_STUDENT_EXACT_FP32 1
+int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_position_axes* axes,
+                           int device, int max_batch, int flags, tha4_student** out);
+
 /* Replaces: GeneralPoser02.get_posing_outputs -> TwoStepPoserComputationProtocol "all_outputs"
  * (general_poser_02.py:63-79, mode_14.py:58-90) for a batch of `batch` frames.
  *   image_dev          fp32 [B,4,512,512] (values in [-1,1], linear RGB premultiplied by alpha)

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtha4_hip.so")
 
 THA4_ABI_VERSION = 1
+STUDENT_EXACT_FP32 = 1
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -149,6 +150,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.tha4_student_create.restype = C.c_int
     lib.tha4_student_create.argtypes = [C.POINTER(Tha4StudentWeights), C.POINTER(Tha4PositionAxes), C.c_int, C.c_int,
                                         C.POINTER(C.c_void_p)]
+    lib.tha4_student_create_ex.restype = C.c_int
+    lib.tha4_student_create_ex.argtypes = [C.POINTER(Tha4StudentWeights), C.POINTER(Tha4PositionAxes), C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p)]
     lib.tha4_student_pose.restype = C.c_int
     lib.tha4_student_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                       C.POINTER(Tha4StudentAux), C.c_void_p]
@@ -184,7 +188,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_pose", "tha4_student_destroy",
+    "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_create_ex", "tha4_student_pose", "tha4_student_destroy",
     "tha4_student_max_batch", "tha4_student_device", "tha4_student_set_timing", "tha4_student_last_ms",
     "tha4_full_create", "tha4_full_pose", "tha4_full_destroy", "tha4_full_max_batch",
     "tha4_display_rgba8", "tha4_ingest_rgba8",

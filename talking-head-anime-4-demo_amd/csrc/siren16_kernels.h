@@ -1,0 +1,630 @@
+// Second-generation student kernels: the SIREN contractions run on v_mfma_f32_16x16x32_f16 with BOTH
+// operands split into fp16 hi + scaled fp16 lo halves (x = hi + lo/2048, 22 significant bits):
+//     W x  ~=  W_hi x_hi  +  (W_hi x_lo + W_lo x_hi) / 2048          (3 MFMAs, fp32 accumulate)
+// fp16 products are exact in the fp32 accumulator; what is dropped is the lo*lo term (2^-22 relative) and the
+// rounding of the lo halves (2^-22), i.e. about two bits less than an exact-fp32 product.  End to end the posed
+// frame moves by < 3e-4 against the exact-fp32 kernels and sits at the SAME distance from the fp64 reference
+// (1.5e-4, tests/test_split_precision.py simulates the scheme in numpy; GPU parity gates on 1e-3 as before) -
+// single-pass fp16/bf16 weights would be off by 0.25 / 1.6.  Per 32-channel K group the matrix
+// pipe spends 3 x 16 cycles instead of 8 x 32 (v_mfma_f32_16x16x4_f32): 5.3x fewer MFMA cycles, which moves the
+// bottleneck to the VALU (sin + split) and LDS; everything else (fused level chains, LDS-resident activations,
+// streamed fragment-linear weights, z hand-off, warp epilogue) is the design of siren_kernels.h.
+//
+// Images.  K group Q = 32 channels = output blocks 2Q, 2Q+1 of the producing layer.  k-slot (g, j) of lane group
+// g = lane>>4, j = 0..7 is channel 32Q + 16(j>>2) + 4g + (j&3), so the 4 rows a lane holds of block 2Q (j<4) and
+// of block 2Q+1 (j>=4) ARE its B fragment for the next layer (C/D layout: row 4g+r, col lane&15).
+//   weights     piece (Q, b) = 2 KiB: [hi: lane x 8 halves | lo: lane x 8 halves], W[16b+(lane&15)][k-slot channel]
+//   activations per pixel group and K group: 2 KiB: [hi: lane x 8 halves | lo: lane x 8 halves]
+#pragma once
+#include "siren_kernels.h"
+
+namespace tha4 {
+namespace v2 {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+#ifndef THA4_EMU
+THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#else
+THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
+  float af[8], bf[8], r[4] = {c[0], c[1], c[2], c[3]};
+  for (int j = 0; j < 8; ++j) { af[j] = (float)a[j]; bf[j] = (float)b[j]; }
+  emu::mfma_f32_16x16x32(af, bf, r);
+  return f32x4{r[0], r[1], r[2], r[3]};
+}
+#endif
+
+// ---- host/device shared layout helpers ---------------------------------------------------------
+// order of the pieces of one K group in the weight stream when a chunk is 1/HB of the group's blocks and MS waves
+// split the rows: piece index of wave-local block bl of row split ms
+constexpr int piece_index(int NB, int MS, int HB, int ms, int bl) {
+  const int NBW = NB / MS, per = NBW / HB;
+  return (bl / per) * (NB / HB) + ms * per + (bl % per);
+}
+constexpr int piece_block(int NB, int MS, int HB, int idx) {   // inverse: global block stored at piece idx
+  const int NBW = NB / MS, per = NBW / HB;
+  const int h = idx / (NB / HB), r = idx % (NB / HB);
+  return (r / per) * NBW + h * per + (r % per);
+}
+
+// split 4 fp32 values into fp16 hi / scaled lo
+THA4_DEV void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (_Float16)v[j];
+    lo[j] = (_Float16)((v[j] - (float)hi[j]) * kLoScale);
+  }
+}
+
+// act image of one pixel slot: [pg][Q][hi|lo][lane][8 halves]; block b -> (Q = b>>1, half = b&1)
+template <class G>
+THA4_DEV void store_block(char* act, int pg, int b, int lane, const f32x4& v) {
+  f16x4 hi, lo;
+  split4(v, hi, lo);
+  char* base = act + ((size_t)(pg * G::ACTQ + (b >> 1)) * 2) * 1024 + lane * 16 + (b & 1) * 8;
+  *reinterpret_cast<f16x4*>(base) = hi;
+  *reinterpret_cast<f16x4*>(base + 1024) = lo;
+}
+
+// Geometry: ACTQ counts K groups (2 KiB each) here; SLOT pieces are 2 KiB.
+template <int NS_, int MS_, int PG_, int ACTG_, int SLOT_PIECES_>
+struct Geo16 {
+  static constexpr int NS = NS_, MS = MS_, PG = PG_, ACTQ = ACTG_;
+  static constexpr int WAVES = NS * MS, THREADS = WAVES * 64;
+  static constexpr int SLOT = SLOT_PIECES_ * 2048;
+  static constexpr int ACT_BYTES = PG * ACTG_ * 2048;
+  static constexpr int LDS = 2 * SLOT + NS * ACT_BYTES;
+  static constexpr int PX = NS * PG * 16;
+  static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
+};
+
+template <int PIECES, int WAVES>
+THA4_DEV void fetch2k(const char* g, char* l, int wave, int lane) {   // PIECES x 2 KiB = 2*PIECES x 1 KiB copies
+  fetch_pieces<2 * PIECES, WAVES>(g, l, wave, lane);
+}
+
+// MFMAs of one resident chunk: CQ K groups x BPC of this wave's blocks (pieces [qq][ROW pieces per group] at wv,
+// activations [pg][group] at av), accumulating into acc[bo0 + ...].  Software pipelined: the next block group's
+// fragments are read from LDS under the last two thirds of the current group's MFMAs.
+template <class G, int ROW, int BPC, int CQ, int NBW>
+THA4_DEV void mma_chunk(const char* wv, const char* av, f32x4 (&acc1)[NBW][G::PG], f32x4 (&acc2)[NBW][G::PG], int bo0) {
+  constexpr int PG = G::PG;
+  constexpr int GB = group_blocks(BPC), NGB = BPC / GB, T = CQ * NGB;
+  f16x8 ah[2][GB], al[2][GB], bh[2][PG], bl[2][PG];
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    bh[0][pg] = *reinterpret_cast<const f16x8*>(av + (size_t)pg * G::ACTQ * 2048);
+    bl[0][pg] = *reinterpret_cast<const f16x8*>(av + (size_t)pg * G::ACTQ * 2048 + 1024);
+  }
+#pragma unroll
+  for (int b = 0; b < GB; ++b) {
+    ah[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048);
+    al[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048 + 1024);
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int qq = t / NGB, g = t % NGB;
+    const int bo = bo0 + g * GB;                            // first wave-local block of this group (compile-time after inlining)
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc1[bo + b][pg] = mfma16h(ah[t & 1][b], bh[qq & 1][pg], acc1[bo + b][pg]);
+    THA4_SCHED_FENCE();
+    if (t + 1 < T) {
+      const int nq = (t + 1) / NGB, ng = (t + 1) % NGB;
+      if (ng == 0) {
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+          bh[nq & 1][pg] = *reinterpret_cast<const f16x8*>(av + ((size_t)pg * G::ACTQ + nq) * 2048);
+          bl[nq & 1][pg] = *reinterpret_cast<const f16x8*>(av + ((size_t)pg * G::ACTQ + nq) * 2048 + 1024);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < GB; ++b) {
+        const char* pc = wv + ((size_t)nq * ROW + ng * GB + b) * 2048;
+        ah[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc);
+        al[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc + 1024);
+      }
+    }
+    THA4_SCHED_FENCE();
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(ah[t & 1][b], bl[qq & 1][pg], acc2[bo + b][pg]);
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(al[t & 1][b], bh[qq & 1][pg], acc2[bo + b][pg]);
+    THA4_SCHED_FENCE();
+  }
+}
+
+// One linear layer, this wave's share (NBW of the NB output blocks) for its PG pixel groups.
+//   KG K groups of 32 channels; chunk = CQ whole groups (HB == 1) or one 1/HB slice of a group's blocks (HB > 1, CQ == 1)
+//   acc1 += Whi Xhi;  acc2 += Whi Xlo + Wlo Xhi;   result = acc1 + acc2/2048
+template <class G, int NB, int NBW, int KG, int HB, int CQ, int NEXT_PIECES>
+THA4_DEV void gemm16_stream(const char*& gw, char* ring, int& slot, const char* act, f32x4 (&acc1)[NBW][G::PG],
+                            f32x4 (&acc2)[NBW][G::PG], const WaveCtx& w, bool active) {
+  static_assert(HB == 1 || CQ == 1, "block slicing and multi-group chunks are exclusive");
+  static_assert(NBW % HB == 0 && KG % CQ == 0, "bad chunking");
+  constexpr int PG = G::PG;
+  constexpr int CHUNK_PIECES = (NB / HB) * CQ;
+  constexpr int NC = (KG / CQ) * HB;
+  constexpr int CHUNK = CHUNK_PIECES * 2048;
+  constexpr int BPC = NBW / HB;                               // this wave's blocks per chunk (per group)
+  static_assert(CHUNK <= G::SLOT && NEXT_PIECES * 2048 <= G::SLOT, "chunk exceeds ring slot");
+#pragma unroll 1
+  for (int cg = 0; cg < KG / CQ; ++cg) {
+#pragma unroll
+  for (int h = 0; h < HB; ++h) {      // block slice: compile-time, so accumulator indices stay static
+    const int c = cg * HB + h;
+    const int nslot = slot ^ 1;
+    if (c + 1 < NC) {
+      fetch2k<CHUNK_PIECES, G::WAVES>(gw + (size_t)(c + 1) * CHUNK, ring + nslot * G::SLOT, w.wave, w.lane);
+    } else if (NEXT_PIECES > 0) {
+      fetch2k<NEXT_PIECES, G::WAVES>(gw + (size_t)NC * CHUNK, ring + nslot * G::SLOT, w.wave, w.lane);
+    }
+    if (active) {
+      // this wave's pieces inside the slot: slice-local index = ms*BPC + i  (see piece_index)
+      const char* wv = ring + slot * G::SLOT + (size_t)(w.ms * BPC) * 2048 + w.lane * 16;
+      const char* av = act + (size_t)(cg * CQ) * 2048 + w.lane * 16;
+      mma_chunk<G, NB / HB, BPC, CQ, NBW>(wv, av, acc1, acc2, h * BPC);
+    }
+#ifndef THA4_ABLATE_BARRIER
+    __syncthreads();
+#endif
+    slot = nslot;
+  }
+  }
+  gw += (size_t)NC * CHUNK;
+}
+
+template <int NBW, int PG>
+THA4_DEV void zero2(f32x4 (&a)[NBW][PG], f32x4 (&b)[NBW][PG]) {
+  zero_acc<NBW, PG>(a);
+  zero_acc<NBW, PG>(b);
+}
+
+// sine hidden layer: act <- split(sin(30 (W act + b)))
+template <class G, int NB, int KG, int HB, int CQ, int NEXT_PIECES>
+THA4_DEV void sine16_layer(const char*& gw, const float*& bias, char* ring, int& slot, char* act, const WaveCtx& w) {
+  static_assert(NB % G::MS == 0, "row split must divide the block count");
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int mbase = w.ms * NBW;
+  f32x4 acc1[NBW][PG], acc2[NBW][PG];
+  zero2<NBW, PG>(acc1, acc2);
+  gemm16_stream<G, NB, NBW, KG, HB, CQ, NEXT_PIECES>(gw, ring, slot, act, acc1, acc2, w, true);
+  const int g4 = (w.lane >> 4) * 4;
+#pragma unroll
+  for (int b = 0; b < NBW; ++b) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + (mbase + b) * 16 + g4);
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      f32x4 v = acc1[b][pg] + acc2[b][pg] * kLoInv + bb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
+      store_block<G>(act, pg, mbase + b, w.lane, v);
+    }
+  }
+  bias += NB * 16;
+  if (G::MS > 1) __syncthreads();
+}
+
+// z layer: z = W act (fp32) -> global z[n][b][pix][16]
+template <class G, int NB, int KG, int HB, int CQ>
+THA4_DEV void z16_layer(const char*& gw, char* ring, int& slot, const char* act, float* zframe, int npix,
+                        const int (&pix0)[G::PG], const WaveCtx& w) {
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int mbase = w.ms * NBW;
+  f32x4 acc1[NBW][PG], acc2[NBW][PG];
+  zero2<NBW, PG>(acc1, acc2);
+  gemm16_stream<G, NB, NBW, KG, HB, CQ, 0>(gw, ring, slot, act, acc1, acc2, w, true);
+  const int p = w.lane & 15, g4 = (w.lane >> 4) * 4;
+#pragma unroll
+  for (int b = 0; b < NBW; ++b)
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg)
+      *reinterpret_cast<f32x4*>(zframe + ((size_t)(mbase + b) * npix + pix0[pg] + p) * 16 + g4) = acc1[b][pg] + acc2[b][pg] * kLoInv;
+}
+
+template <class G, int NB>
+THA4_DEV void first16_pos(const float* wx, const float* wy, const float* pb, const float (&x)[G::PG], const float (&y)[G::PG],
+                          char* act, const WaveCtx& w) {
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int g4 = (w.lane >> 4) * 4, mbase = w.ms * NBW;
+#pragma unroll
+  for (int bb = 0; bb < NBW; ++bb) {
+    const int b = mbase + bb;
+    const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
+    const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = sin_omega(fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));
+      store_block<G>(act, pg, b, w.lane, v);
+    }
+  }
+}
+
+template <class G, int NB>
+THA4_DEV void first16_up(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb,
+                         const int (&X0)[G::PG], const int (&Y)[G::PG], const float (&x)[G::PG], const float (&y)[G::PG],
+                         char* act, const WaveCtx& w) {
+  constexpr int NBW = NB / G::MS, PG = G::PG;
+  const int p = w.lane & 15, g4 = (w.lane >> 4) * 4, mbase = w.ms * NBW;
+  const int npix = lowS * lowS;
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    int x0, x1, y0, y1;
+    float lx0, lx1, ly0, ly1;
+    up2_taps(X0[pg] + p, lowS, x0, x1, lx0, lx1);
+    up2_taps(Y[pg], lowS, y0, y1, ly0, ly1);
+    const float* z00 = zframe + ((size_t)y0 * lowS + x0) * 16 + g4;
+    const float* z01 = zframe + ((size_t)y0 * lowS + x1) * 16 + g4;
+    const float* z10 = zframe + ((size_t)y1 * lowS + x0) * 16 + g4;
+    const float* z11 = zframe + ((size_t)y1 * lowS + x1) * 16 + g4;
+#pragma unroll
+    for (int bb = 0; bb < NBW; ++bb) {
+      const int b = mbase + bb;
+      const size_t off = (size_t)b * npix * 16;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(z00 + off);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(z01 + off);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(z10 + off);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(z11 + off);
+      const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
+      const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float up = ly0 * (lx0 * a[j] + lx1 * bq[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
+        v[j] = sin_omega(up + fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));
+      }
+      store_block<G>(act, pg, b, w.lane, v);
+    }
+  }
+}
+
+// K groups / block counts of the four networks in this generation (channels padded to 32 for K)
+constexpr int kKGF = 4;    // face 128
+constexpr int kKG0 = 12;   // 360 -> 384
+constexpr int kKG1 = 6;    // 180 -> 192
+constexpr int kKG2 = 3;    // 90 -> 96
+
+// ---- face ------------------------------------------------------------------------------------------
+template <int NS, int MS, int PG, int CQ>
+struct Face16Cfg {
+  static constexpr int kHB = 1;
+  static constexpr int kSlotPieces = CQ * kNBF > kKGF ? CQ * kNBF : kKGF;
+  using G = Geo16<NS, MS, PG, kKGF, kSlotPieces>;
+};
+
+template <int NS, int MS, int PG, int CQ>
+__global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
+  using G = typename Face16Cfg<NS, MS, PG, CQ>::G;
+  constexpr int S = kFaceSize, NPIX = S * S;
+  THA4_DYN_LDS(smem);
+  const WaveCtx w = wave_ctx<G>();
+  char* ring = smem;
+  char* act = smem + 2 * G::SLOT + w.ns * G::ACT_BYTES;
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
+  const char* gw = reinterpret_cast<const char*>(d.w_face);
+  const float* bias = d.b_face;
+  int slot = 0;
+  fetch2k<CQ * kNBF, G::WAVES>(gw, ring, w.wave, w.lane);
+  first16_pos<G, kNBF>(d.wx[0], d.wy[0], d.pbias + (size_t)n * kPbStride + kPbFace, px, py, act, w);
+  __syncthreads();
+#pragma unroll 1
+  for (int l = 0; l < 6; ++l) sine16_layer<G, kNBF, kKGF, 1, CQ, CQ * kNBF>(gw, bias, ring, slot, act, w);
+  sine16_layer<G, kNBF, kKGF, 1, CQ, kKGF>(gw, bias, ring, slot, act, w);
+  f32x4 a1[1][PG], a2[1][PG];
+  zero2<1, PG>(a1, a2);
+  // head: ONE block; only row-split 0 computes, its piece is the first of every group (MS folded: NB = 1)
+  gemm16_stream<Geo16<NS, 1, PG, kKGF, Face16Cfg<NS, MS, PG, CQ>::kSlotPieces>, 1, 1, kKGF, 1, kKGF, 0>(gw, ring, slot, act, a1, a2,
+                                                                                                   WaveCtx{w.lane, w.wave, w.ns, 0}, w.ms == 0);
+  if (w.ms == 0 && w.lane < 16) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias);
+    float* fo = d.face + (size_t)n * 4 * NPIX;
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      const f32x4 v = a1[0][pg] + a2[0][pg] * kLoInv + bb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fo[(size_t)j * NPIX + pix0[pg] + w.lane] = v[j];
+    }
+  }
+}
+
+// ---- level 0 ----------------------------------------------------------------------------------------
+template <int NS, int MS, int PG, int HBA, int CQB>
+struct Level016Cfg {   // HBA: block slices per group of the 24/12-block layers; CQB: groups per chunk of the z layer
+  static constexpr int kP1 = kNB0 / HBA, kP2 = kNB1 / HBA, kP3 = CQB * kNB1;
+  static constexpr int kSlotPieces = kP1 > kP3 ? kP1 : kP3;
+  using G = Geo16<NS, MS, PG, kKG0, kSlotPieces>;
+};
+
+template <int NS, int MS, int PG, int HBA, int CQB>
+__global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
+  using Cfg = Level016Cfg<NS, MS, PG, HBA, CQB>;
+  using G = typename Cfg::G;
+  constexpr int S = 128, NPIX = S * S;
+  THA4_DYN_LDS(smem);
+  const WaveCtx w = wave_ctx<G>();
+  char* ring = smem;
+  char* act = smem + 2 * G::SLOT + w.ns * G::ACT_BYTES;
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
+  const char* gw = reinterpret_cast<const char*>(d.w_l0);
+  const float* bias = d.b_l0;
+  int slot = 0;
+  fetch2k<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
+  first16_pos<G, kNB0>(d.wx[1], d.wy[1], d.pbias + (size_t)n * kPbStride + kPbL0, px, py, act, w);
+  __syncthreads();
+  sine16_layer<G, kNB0, kKG0, HBA, 1, Cfg::kP2>(gw, bias, ring, slot, act, w);
+  sine16_layer<G, kNB1, kKG0, HBA, 1, Cfg::kP3>(gw, bias, ring, slot, act, w);
+  z16_layer<G, kNB1, kKG1, 1, CQB>(gw, ring, slot, act, d.z1 + (size_t)n * kNB1 * NPIX * 16, NPIX, pix0, w);
+}
+
+// ---- level 1 ----------------------------------------------------------------------------------------
+template <int NS, int MS, int PG, int CQA, int CQB>
+struct Level116Cfg {
+  static constexpr int kP1 = CQA * kNB1, kP2 = CQA * kNB2, kP3 = CQB * kNB2;
+  static constexpr int kSlotPieces = kP1 > kP3 ? kP1 : kP3;
+  using G = Geo16<NS, MS, PG, kKG1, kSlotPieces>;
+};
+
+template <int NS, int MS, int PG, int CQA, int CQB>
+__global__ void __launch_bounds__(NS* MS * 64) level1_16_kernel(StudentDev d) {
+  using Cfg = Level116Cfg<NS, MS, PG, CQA, CQB>;
+  using G = typename Cfg::G;
+  constexpr int S = 256, NPIX = S * S;
+  THA4_DYN_LDS(smem);
+  const WaveCtx w = wave_ctx<G>();
+  char* ring = smem;
+  char* act = smem + 2 * G::SLOT + w.ns * G::ACT_BYTES;
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos256, pix0, X0, Y, px, py);
+  const char* gw = reinterpret_cast<const char*>(d.w_l1);
+  const float* bias = d.b_l1;
+  int slot = 0;
+  fetch2k<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
+  first16_up<G, kNB1>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, d.wx[2], d.wy[2],
+                      d.pbias + (size_t)n * kPbStride + kPbL1, X0, Y, px, py, act, w);
+  __syncthreads();
+  sine16_layer<G, kNB1, kKG1, 1, CQA, Cfg::kP2>(gw, bias, ring, slot, act, w);
+  sine16_layer<G, kNB2, kKG1, 1, CQA, Cfg::kP3>(gw, bias, ring, slot, act, w);
+  z16_layer<G, kNB2, kKG2, 1, CQB>(gw, ring, slot, act, d.z2 + (size_t)n * kNB2 * NPIX * 16, NPIX, pix0, w);
+}
+
+// last_linear rows -> grid_sample warp of (image with the face patch) -> alpha blend -> NCHW outputs
+// (siren_morpher_03.py:125-131, image_processing_util.py:33-54, mode_14.py:72-78).  Rows 0..3 (dx, dy, alpha,
+// colour R) live in lane group 0, rows 4..6 (G, B, A) in group 1; lane group g then handles image channel g.
+template <int PG>
+THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bias, const int (&pix0)[PG], const float (&px)[PG],
+                               const float (&py)[PG], f32x4 (&a1)[1][PG], f32x4 (&a2)[1][PG], const WaveCtx& w) {
+  constexpr int S = kImg, NPIX = S * S;
+  const int p = w.lane & 15, g = w.lane >> 4;
+  const f32x4 bb = *reinterpret_cast<const f32x4*>(head_bias + g * 4);
+  const float* img = d.image + (size_t)n * d.image_stride;
+  const float* face = d.face + (size_t)n * 4 * kFaceSize * kFaceSize;
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    const f32x4 v = a1[0][pg] + a2[0][pg] * kLoInv + bb;
+    const float dx = lane_read(v[0], p), dy = lane_read(v[1], p), al = lane_read(v[2], p);
+    const float c0 = lane_read(v[3], p), c1 = lane_read(v[0], p + 16), c2 = lane_read(v[1], p + 16),
+                c3 = lane_read(v[2], p + 16);
+    const float col = g == 0 ? c0 : (g == 1 ? c1 : (g == 2 ? c2 : c3));
+    const float gx = px[pg] + dx, gy = py[pg] + dy;
+    float ix = ((gx + 1.0f) * (float)S - 1.0f) * 0.5f;
+    float iy = ((gy + 1.0f) * (float)S - 1.0f) * 0.5f;
+    ix = fminf((float)(S - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(S - 1), fmaxf(iy, 0.0f));
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float tx = ix - fx0, ty = iy - fy0;
+    const float wnw = (1.0f - tx) * (1.0f - ty), wne = tx * (1.0f - ty), wsw = (1.0f - tx) * ty, wse = tx * ty;
+    const int x1 = min(x0 + 1, S - 1), y1 = min(y0 + 1, S - 1);
+    float wv = body_source(img, face, g, y0, x0) * wnw;
+    wv += body_source(img, face, g, y0, x1) * wne;
+    wv += body_source(img, face, g, y1, x0) * wsw;
+    wv += body_source(img, face, g, y1, x1) * wse;
+    const float blended = (1.0f - al) * wv + al * col;
+    const size_t pix = (size_t)pix0[pg] + p;
+    d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
+    if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
+    if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = wv;
+    if (d.out_alpha && g == 0) d.out_alpha[(size_t)n * NPIX + pix] = al;
+    if (d.out_grid && g < 2) d.out_grid[((size_t)n * 2 + g) * NPIX + pix] = (g == 0 ? dx : dy);
+  }
+}
+
+// ---- level 2 ----------------------------------------------------------------------------------------
+template <int NS, int MS, int PG, int CQ>
+struct Level216Cfg {
+  static constexpr int kSlotPieces = CQ * kNB2 > kKG2 ? CQ * kNB2 : kKG2;
+  using G = Geo16<NS, MS, PG, kKG2, kSlotPieces>;
+};
+
+template <int NS, int MS, int PG, int CQ>
+__global__ void __launch_bounds__(NS* MS * 64) level2_16_kernel(StudentDev d) {
+  using G = typename Level216Cfg<NS, MS, PG, CQ>::G;
+  static_assert(MS == 1, "level 2 keeps whole rows per wave");
+  constexpr int S = kImg, NPIX = S * S;
+  THA4_DYN_LDS(smem);
+  const WaveCtx w = wave_ctx<G>();
+  char* ring = smem;
+  char* act = smem + 2 * G::SLOT + w.ns * G::ACT_BYTES;
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos512, pix0, X0, Y, px, py);
+  const char* gw = reinterpret_cast<const char*>(d.w_l2);
+  const float* bias = d.b_l2;
+  int slot = 0;
+  fetch2k<CQ * kNB2, G::WAVES>(gw, ring, w.wave, w.lane);
+  first16_up<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
+                      d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, act, w);
+  __syncthreads();
+  sine16_layer<G, kNB2, kKG2, 1, CQ, CQ * kNB2>(gw, bias, ring, slot, act, w);
+  sine16_layer<G, kNB2, kKG2, 1, CQ, kKG2>(gw, bias, ring, slot, act, w);
+  f32x4 a1[1][PG], a2[1][PG];
+  zero2<1, PG>(a1, a2);
+  gemm16_stream<G, 1, 1, kKG2, 1, kKG2, 0>(gw, ring, slot, act, a1, a2, w, true);
+
+  warp_blend_store<PG>(d, n, bias, pix0, px, py, a1, a2, w);
+}
+
+// ---- level 2, weights-resident variant -------------------------------------------------------------
+// The three level-2 layers are only 78 KiB of fp16 hi/lo pieces: instead of re-streaming them through a ring for
+// every 64-pixel workgroup (4096 workgroups, 320 MB of L2->LDS traffic and a barrier per chunk per frame), a
+// workgroup loads them ONCE and its WAVES waves then walk PGW pixel groups each with NO further barrier: a wave's
+// activation image is private, so waves drift apart and one wave's sin()/warp phase overlaps another's MFMAs.
+template <int WAVES, int PGW>
+struct Level2PCfg {
+  static constexpr int kHidden = kNB2 * kKG2;                         // pieces of one 96->96 layer
+  static constexpr int kPieces = 2 * kHidden + kKG2;                  // + head (1 block x 3 groups)
+  static constexpr int kWeightBytes = kPieces * 2048;
+  static constexpr int kActBytes = kKG2 * 2048;
+  static constexpr int LDS = kWeightBytes + WAVES * kActBytes;
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int PX = WAVES * PGW * 16;
+  using G = Geo16<WAVES, 1, 1, kKG2, 1>;
+  static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
+};
+
+template <int WAVES, int PGW>
+__global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
+  using Cfg = Level2PCfg<WAVES, PGW>;
+  using G = typename Cfg::G;
+  constexpr int S = kImg, PGS = S * S / 16;
+  THA4_DYN_LDS(smem);
+  const WaveCtx w = wave_ctx<G>();
+  char* act = smem + Cfg::kWeightBytes + w.wave * Cfg::kActBytes;
+  fetch_pieces<2 * Cfg::kPieces, WAVES>(reinterpret_cast<const char*>(d.w_l2), smem, w.wave, w.lane);
+  __syncthreads();
+  const char* w1 = smem + w.lane * 16;
+  const char* w2 = w1 + (size_t)Cfg::kHidden * 2048;
+  const char* w3 = w2 + (size_t)Cfg::kHidden * 2048;
+  const int g4 = (w.lane >> 4) * 4;
+#pragma unroll 1
+  for (int k = 0; k < PGW; ++k) {
+    const int pgid = (blockIdx.x * PGW + k) * WAVES + w.wave;          // the WAVES waves work on adjacent strips
+    const int n = pgid / PGS;
+    int pix0[1], X0[1], Y[1];
+    float px[1], py[1];
+    pix0[0] = (pgid % PGS) * 16;
+    X0[0] = pix0[0] % S;
+    Y[0] = pix0[0] / S;
+    px[0] = d.pos512[X0[0] + (w.lane & 15)];
+    py[0] = d.pos512[Y[0]];
+    first16_up<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
+                        d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, act, w);
+    const float* bias = d.b_l2;
+#pragma unroll
+    for (int layer = 0; layer < 2; ++layer) {
+      f32x4 acc1[kNB2][1], acc2[kNB2][1];
+      zero2<kNB2, 1>(acc1, acc2);
+      mma_chunk<G, kNB2, kNB2, kKG2, kNB2>(layer == 0 ? w1 : w2, act + w.lane * 16, acc1, acc2, 0);
+#pragma unroll
+      for (int b = 0; b < kNB2; ++b) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + b * 16 + g4);
+        f32x4 v = acc1[b][0] + acc2[b][0] * kLoInv + bb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
+        store_block<G>(act, 0, b, w.lane, v);
+      }
+      bias += kNB2 * 16;
+    }
+    f32x4 a1[1][1], a2[1][1];
+    zero2<1, 1>(a1, a2);
+    mma_chunk<G, 1, 1, kKG2, 1>(w3, act + w.lane * 16, a1, a2, 0);
+    warp_blend_store<1>(d, n, bias, pix0, px, py, a1, a2, w);
+  }
+}
+
+// ---- launch configuration ------------------------------------------------------------------------------
+namespace cfg {
+#ifndef THA4_FACE16_CFG
+#define THA4_FACE16_CFG 4, 2, 1, 4          // NS, MS, PG, CQ (groups per chunk; 4 = whole layer)
+#endif
+#ifndef THA4_L016_CFG
+#define THA4_L016_CFG 4, 2, 1, 2, 1         // NS, MS, PG, HBA (block slices per group), CQB
+#endif
+#ifndef THA4_L116_CFG
+#define THA4_L116_CFG 8, 1, 1, 1, 1         // NS, MS, PG, CQA, CQB
+#endif
+#ifndef THA4_L216_CFG
+#define THA4_L216_CFG 4, 1, 1, 1            // NS, MS, PG, CQ
+#endif
+#ifndef THA4_L216P_CFG
+#define THA4_L216P_CFG 8, 8                 // WAVES, pixel groups per wave (weights-resident level 2)
+#endif
+#ifndef THA4_L2_RESIDENT
+#define THA4_L2_RESIDENT 1                  // 1: level2_16p_kernel, 0: streamed level2_16_kernel
+#endif
+using L2P = Level2PCfg<THA4_L216P_CFG>;
+#define THA4_L216P_KERNEL v2::level2_16p_kernel<THA4_L216P_CFG>
+using FaceG = Face16Cfg<THA4_FACE16_CFG>::G;
+using L0G = Level016Cfg<THA4_L016_CFG>::G;
+using L1G = Level116Cfg<THA4_L116_CFG>::G;
+using L2G = Level216Cfg<THA4_L216_CFG>::G;
+constexpr int kL0HBA = Level016Cfg<THA4_L016_CFG>::kP1 == kNB0 ? 1 : kNB0 / Level016Cfg<THA4_L016_CFG>::kP1;
+constexpr int kFaceMS = FaceG::MS, kL0MS = L0G::MS, kL1MS = L1G::MS, kL2MS = L2G::MS;
+#define THA4_FACE16_KERNEL v2::face16_kernel<THA4_FACE16_CFG>
+#define THA4_L016_KERNEL v2::level0_16_kernel<THA4_L016_CFG>
+#define THA4_L116_KERNEL v2::level1_16_kernel<THA4_L116_CFG>
+#define THA4_L216_KERNEL v2::level2_16_kernel<THA4_L216_CFG>
+template <class G>
+constexpr int blocks_for(int batch, int side) { return batch * (side * side) / G::PX; }
+}  // namespace cfg
+
+// ---- host packer -------------------------------------------------------------------------------------
+// One layer [O x I] -> pieces [Q][piece idx][hi 1 KiB | lo 1 KiB] with the block order of (MS, HB).
+inline void pack_layer16(const float* W, int ldw, int col0, int O, int I, int NB, int KG, int MS, int HB, std::vector<char>& dst) {
+  const size_t at = dst.size();
+  dst.resize(at + (size_t)KG * NB * 2048);
+  for (int Q = 0; Q < KG; ++Q)
+    for (int idx = 0; idx < NB; ++idx) {
+      const int b = piece_block(NB, MS, HB, idx);
+      _Float16* hi = reinterpret_cast<_Float16*>(dst.data() + at + ((size_t)Q * NB + idx) * 2048);
+      _Float16* lo = hi + 512;
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int o = 16 * b + (lane & 15);
+          const int i = 32 * Q + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+          const float v = (o < O && i < I) ? W[(size_t)o * ldw + col0 + i] : 0.0f;
+          const _Float16 h = (_Float16)v;
+          hi[lane * 8 + j] = h;
+          lo[lane * 8 + j] = (_Float16)((v - (float)h) * kLoScale);
+        }
+    }
+}
+
+struct StudentPacked16 {
+  std::vector<char> w_face, w_l0, w_l1, w_l2;
+};
+
+// mirrors pack_student (siren_layout.h) for the weight streams only; biases / first layers are shared with generation 1
+inline void pack_student16(const StudentWeightsView& v, StudentPacked16& p) {
+  p = StudentPacked16();
+  for (int i = 1; i < 8; ++i) pack_layer16(v.face_sine[i].weight, kCF, 0, kCF, kCF, kNBF, kKGF, cfg::kFaceMS, 1, p.w_face);
+  pack_layer16(v.face_last.weight, kCF, 0, 4, kCF, 1, kKGF, 1, 1, p.w_face);
+  pack_layer16(v.body_sine[0][1].weight, kC0, 0, kC0, kC0, kNB0, kKG0, cfg::kL0MS, cfg::kL0HBA, p.w_l0);
+  pack_layer16(v.body_sine[0][2].weight, kC0, 0, kC1, kC0, kNB1, kKG0, cfg::kL0MS, cfg::kL0HBA, p.w_l0);
+  pack_layer16(v.body_sine[1][0].weight, kC1 + 2 + kPose, 0, kC1, kC1, kNB1, kKG1, cfg::kL0MS, 1, p.w_l0);
+  pack_layer16(v.body_sine[1][1].weight, kC1, 0, kC1, kC1, kNB1, kKG1, cfg::kL1MS, 1, p.w_l1);
+  pack_layer16(v.body_sine[1][2].weight, kC1, 0, kC2, kC1, kNB2, kKG1, cfg::kL1MS, 1, p.w_l1);
+  pack_layer16(v.body_sine[2][0].weight, kC2 + 2 + kPose, 0, kC2, kC2, kNB2, kKG2, cfg::kL1MS, 1, p.w_l1);
+  pack_layer16(v.body_sine[2][1].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, p.w_l2);
+  pack_layer16(v.body_sine[2][2].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, p.w_l2);
+  pack_layer16(v.body_last.weight, kC2, 0, kHeadC, kC2, 1, kKG2, 1, 1, p.w_l2);
+}
+
+}  // namespace v2
+}  // namespace tha4

@@ -63,6 +63,14 @@ THA4_DEV float sin_omega(float z) {
   return z;
 #endif
   const float u = kOmega * z;
+#if defined(THA4_HW_SIN) && !defined(THA4_EMU)
+  // v_sin_f32 variant (input in revolutions): same reference rounding of u, 2-term Cody-Waite by 2 pi,
+  // 3.8e-7 max abs error on the device (tools/microbench/sin_test.hip) instead of 1.3e-7, 10 issue slots instead of 15
+  const float kr = rintf(u * 0x1.45f306p-3f);
+  float rr = fmaf(-kr, 6.28125f, u);
+  rr = fmaf(-kr, 0x1.fb5444p-10f, rr);
+  return __builtin_amdgcn_sinf(rr * 0x1.45f306p-3f);
+#endif
   const float k = rintf(u * 0x1.45f306p-2f);
   float r = fmaf(-k, 0x1.92p+1f, u);
   r = fmaf(-k, 0x1.fb4p-11f, r);

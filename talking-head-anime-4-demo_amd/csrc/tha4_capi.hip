@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "siren_kernels.h"
+#include "siren16_kernels.h"
 #include "full_net.h"
 #include "image_io_kernels.h"
 
@@ -53,6 +53,7 @@ struct tha4_student {
   char* blob = nullptr;       // packed parameters, one allocation
   char* workspace = nullptr;  // pbias | face | z1 | z2
   StudentDev dev{};           // parameter + workspace pointers filled at create
+  bool exact_fp32 = false;    // generation 1 kernels (v_mfma_f32_16x16x4_f32) instead of the fp16 hi/lo split
   bool timing = false;
   hipEvent_t ev[kNumKernels + 1] = {};
   bool ev_valid = false;
@@ -70,6 +71,12 @@ struct BlobBuilder {
     size_t at = align_up(host.size(), 256);
     host.resize(at + v.size() * sizeof(float));
     std::memcpy(host.data() + at, v.data(), v.size() * sizeof(float));
+    return at;
+  }
+  size_t add(const std::vector<char>& v) {
+    size_t at = align_up(host.size(), 256);
+    host.resize(at + v.size());
+    std::memcpy(host.data() + at, v.data(), v.size());
     return at;
   }
 };
@@ -100,6 +107,11 @@ const char* tha4_last_error(void) { return g_last_error.c_str(); }
 
 int tha4_student_create(const tha4_student_weights* weights, const tha4_position_axes* axes, int device,
                         int max_batch, tha4_student** out) {
+  return tha4_student_create_ex(weights, axes, device, max_batch, 0, out);
+}
+
+int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_position_axes* axes, int device,
+                           int max_batch, int flags, tha4_student** out) {
   if (!weights || !out) return fail(THA4_ERR_INVALID_ARGUMENT, "weights/out must not be NULL");
   *out = nullptr;
   if (max_batch < 1 || max_batch > 4096) return fail(THA4_ERR_INVALID_ARGUMENT, "max_batch must be in [1, 4096]");
@@ -125,8 +137,16 @@ int tha4_student_create(const tha4_student_weights* weights, const tha4_position
     if (axes->axis512) std::memcpy(pos512.data(), axes->axis512, 512 * sizeof(float));
   }
 
+  const bool exact = (flags & THA4_STUDENT_EXACT_FP32) != 0;
   BlobBuilder bb;
-  const size_t o_wf = bb.add(p.w_face), o_w0 = bb.add(p.w_l0), o_w1 = bb.add(p.w_l1), o_w2 = bb.add(p.w_l2);
+  size_t o_wf, o_w0, o_w1, o_w2;
+  if (exact) {
+    o_wf = bb.add(p.w_face); o_w0 = bb.add(p.w_l0); o_w1 = bb.add(p.w_l1); o_w2 = bb.add(p.w_l2);
+  } else {
+    v2::StudentPacked16 p16;
+    v2::pack_student16(to_view(weights), p16);
+    o_wf = bb.add(p16.w_face); o_w0 = bb.add(p16.w_l0); o_w1 = bb.add(p16.w_l1); o_w2 = bb.add(p16.w_l2);
+  }
   const size_t o_bf = bb.add(p.b_face), o_b0 = bb.add(p.b_l0), o_b1 = bb.add(p.b_l1), o_b2 = bb.add(p.b_l2);
   const FirstLayerPack* fl[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
   size_t o_wx[4], o_wy[4], o_b[4], o_wp[4];
@@ -142,6 +162,7 @@ int tha4_student_create(const tha4_student_weights* weights, const tha4_position
   auto* h = new tha4_student();
   h->device = device;
   h->max_batch = max_batch;
+  h->exact_fp32 = exact;
   auto cleanup = [&]() {
     if (h->blob) (void)hipFree(h->blob);
     if (h->workspace) (void)hipFree(h->workspace);
@@ -159,6 +180,11 @@ int tha4_student_create(const tha4_student_weights* weights, const tha4_position
   if (e == hipSuccess) e = allow_lds(THA4_L0_KERNEL, cfg::L0G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L1_KERNEL, cfg::L1G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L2_KERNEL, cfg::L2G::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_FACE16_KERNEL, v2::cfg::FaceG::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_L016_KERNEL, v2::cfg::L0G::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_L116_KERNEL, v2::cfg::L1G::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_L216_KERNEL, v2::cfg::L2G::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_L216P_KERNEL, v2::cfg::L2P::LDS);
   if (e != hipSuccess) {
     cleanup();
     return fail(THA4_ERR_HIP, std::string("tha4_student_create: ") + hipGetErrorString(e));
@@ -208,17 +234,35 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
   if (t) HIP_TRY(hipEventRecord(h->ev[0], s));
   hipLaunchKernelGGL(posebias_kernel, dim3(cfg::posebias_blocks(), batch), dim3(kPoseBiasBlock), 0, s, d);
   if (t) HIP_TRY(hipEventRecord(h->ev[1], s));
-  hipLaunchKernelGGL((THA4_FACE_KERNEL), dim3(cfg::blocks_for<cfg::FaceG>(batch, 128)), dim3(cfg::FaceG::THREADS),
-                     cfg::FaceG::LDS, s, d);
-  if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
-  hipLaunchKernelGGL((THA4_L0_KERNEL), dim3(cfg::blocks_for<cfg::L0G>(batch, 128)), dim3(cfg::L0G::THREADS),
-                     cfg::L0G::LDS, s, d);
-  if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
-  hipLaunchKernelGGL((THA4_L1_KERNEL), dim3(cfg::blocks_for<cfg::L1G>(batch, 256)), dim3(cfg::L1G::THREADS),
-                     cfg::L1G::LDS, s, d);
-  if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
-  hipLaunchKernelGGL((THA4_L2_KERNEL), dim3(cfg::blocks_for<cfg::L2G>(batch, 512)), dim3(cfg::L2G::THREADS),
-                     cfg::L2G::LDS, s, d);
+  if (h->exact_fp32) {
+    hipLaunchKernelGGL((THA4_FACE_KERNEL), dim3(cfg::blocks_for<cfg::FaceG>(batch, 128)), dim3(cfg::FaceG::THREADS),
+                       cfg::FaceG::LDS, s, d);
+    if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
+    hipLaunchKernelGGL((THA4_L0_KERNEL), dim3(cfg::blocks_for<cfg::L0G>(batch, 128)), dim3(cfg::L0G::THREADS),
+                       cfg::L0G::LDS, s, d);
+    if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
+    hipLaunchKernelGGL((THA4_L1_KERNEL), dim3(cfg::blocks_for<cfg::L1G>(batch, 256)), dim3(cfg::L1G::THREADS),
+                       cfg::L1G::LDS, s, d);
+    if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
+    hipLaunchKernelGGL((THA4_L2_KERNEL), dim3(cfg::blocks_for<cfg::L2G>(batch, 512)), dim3(cfg::L2G::THREADS),
+                       cfg::L2G::LDS, s, d);
+  } else {
+    hipLaunchKernelGGL((THA4_FACE16_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::FaceG>(batch, 128)), dim3(v2::cfg::FaceG::THREADS),
+                       v2::cfg::FaceG::LDS, s, d);
+    if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
+    hipLaunchKernelGGL((THA4_L016_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L0G>(batch, 128)), dim3(v2::cfg::L0G::THREADS),
+                       v2::cfg::L0G::LDS, s, d);
+    if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
+    hipLaunchKernelGGL((THA4_L116_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L1G>(batch, 256)), dim3(v2::cfg::L1G::THREADS),
+                       v2::cfg::L1G::LDS, s, d);
+    if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
+    if (THA4_L2_RESIDENT)
+      hipLaunchKernelGGL((THA4_L216P_KERNEL), dim3(batch * (512 * 512) / v2::cfg::L2P::PX), dim3(v2::cfg::L2P::THREADS),
+                         v2::cfg::L2P::LDS, s, d);
+    else
+      hipLaunchKernelGGL((THA4_L216_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L2G>(batch, 512)), dim3(v2::cfg::L2G::THREADS),
+                         v2::cfg::L2G::LDS, s, d);
+  }
   if (t) {
     HIP_TRY(hipEventRecord(h->ev[5], s));
     h->ev_recorded = true;

@@ -38,7 +38,8 @@ def create_poser(device: torch.device,
                  module_file_names: Optional[Dict[str, str]] = None,
                  default_output_index: int = 0,
                  max_batch: int = 1,
-                 match_aten_positions: bool = True) -> HipStudentPoser:
+                 match_aten_positions: bool = True,
+                 exact_fp32: bool = False) -> HipStudentPoser:
     """Same contract as the reference factory; ``max_batch`` (workspace pre-sizing, grows on demand)
     and ``match_aten_positions`` (use the local ATen affine_grid fp32 axes instead of the exact dyadic
     ones, see include/tha4_hip.h) are additions with reference-compatible defaults."""
@@ -58,7 +59,8 @@ def create_poser(device: torch.device,
         pose_parameters=get_pose_parameters().get_pose_parameter_groups(),
         default_output_index=default_output_index,
         max_batch=max_batch,
-        position_axes=aten_position_axes() if match_aten_positions else None)
+        position_axes=aten_position_axes() if match_aten_positions else None,
+        exact_fp32=exact_fp32)
 
 
 def create_poser_from_state_dicts(device: torch.device,
@@ -66,7 +68,8 @@ def create_poser_from_state_dicts(device: torch.device,
                                   body_state_dict: Dict[str, np.ndarray],
                                   default_output_index: int = 0,
                                   max_batch: int = 1,
-                                  match_aten_positions: bool = True) -> HipStudentPoser:
+                                  match_aten_positions: bool = True,
+                                  exact_fp32: bool = False) -> HipStudentPoser:
     """Same poser from in-memory state_dicts (numpy or torch values, reference key layout)."""
     face = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in face_state_dict.items()}
     body = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in body_state_dict.items()}
@@ -77,4 +80,5 @@ def create_poser_from_state_dicts(device: torch.device,
         pose_parameters=get_pose_parameters().get_pose_parameter_groups(),
         default_output_index=default_output_index,
         max_batch=max_batch,
-        position_axes=aten_position_axes() if match_aten_positions else None)
+        position_axes=aten_position_axes() if match_aten_positions else None,
+        exact_fp32=exact_fp32)

@@ -54,6 +54,7 @@ class HipStudentPoser(Poser):
                  default_output_index: int = 0,
                  max_batch: int = 1,
                  position_axes: Optional[Dict[int, np.ndarray]] = None,
+                 exact_fp32: bool = False,
                  dtype: torch.dtype = torch.float):
         self.state_dict_loaders = state_dict_loaders
         self.device = torch.device(device)
@@ -64,6 +65,7 @@ class HipStudentPoser(Poser):
         self.dtype = dtype
         self.num_parameters = sum(p.get_arity() for p in pose_parameters)
         self.position_axes = position_axes
+        self.exact_fp32 = bool(exact_fp32)   # A/B switch: fp32-product MFMA kernels instead of the fp16 hi/lo split
         self._max_batch = max(1, int(max_batch))
         self._state_dicts = None
         self._lib = None
@@ -142,9 +144,10 @@ class HipStudentPoser(Poser):
         weights, keep = _capi.build_student_weights(self._state_dicts["face_morpher"], self._state_dicts["body_morpher"])
         axes, keep2 = _capi.build_position_axes(self.position_axes)
         handle = C.c_void_p()
-        st = self._lib.tha4_student_create(C.byref(weights), C.byref(axes) if axes is not None else None, dev,
-                                           self._max_batch, C.byref(handle))
-        _capi.check(self._lib, st, "tha4_student_create")
+        st = self._lib.tha4_student_create_ex(C.byref(weights), C.byref(axes) if axes is not None else None, dev,
+                                              self._max_batch, _capi.STUDENT_EXACT_FP32 if self.exact_fp32 else 0,
+                                              C.byref(handle))
+        _capi.check(self._lib, st, "tha4_student_create_ex")
         del keep, keep2
         self._handle = handle
 

@@ -43,6 +43,7 @@ inline char* g_lds = nullptr;
 
 struct WaveState {
   float a[64], b[64], c[64][4], d[64][4];
+  float a8[64][8], b8[64][8];
   float sh_in[64], sh_out[64];
   int sh_src[64];
   int arrived = 0;
@@ -111,6 +112,25 @@ inline void mfma_f32_16x16x4(float a, float b, float (&cd)[4]) {
         const int dl = 16 * (i / 4) + j, dr = i % 4;
         float acc = W.c[dl][dr];
         for (int k = 0; k < 4; ++k) acc = std::fmaf(W.a[16 * k + i], W.b[16 * k + j], acc);
+        W.d[dl][dr] = acc;
+      }
+  });
+  for (int r = 0; r < 4; ++r) cd[r] = W.d[lane][r];
+}
+
+// v_mfma_f32_16x16x32_f16: A[i][k] = lane 16*(k/8)+i element k%8, B[k][j] = lane 16*(k/8)+j element k%8,
+// D[i][j] in lane 16*(i/4)+j register i%4; fp16 products are exact in fp32, accumulated in fp32.
+inline void mfma_f32_16x16x32(const float (&a)[8], const float (&b)[8], float (&cd)[4]) {
+  WaveState& W = my_wave();
+  const int lane = g_threadIdx.x & 63;
+  for (int j = 0; j < 8; ++j) { W.a8[lane][j] = a[j]; W.b8[lane][j] = b[j]; }
+  for (int r = 0; r < 4; ++r) W.c[lane][r] = cd[r];
+  wave_rendezvous(W, [&W]() {
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) {
+        const int dl = 16 * (i / 4) + j, dr = i % 4;
+        float acc = W.c[dl][dr];
+        for (int k = 0; k < 32; ++k) acc = std::fmaf(W.a8[16 * (k / 8) + i][k % 8], W.b8[16 * (k / 8) + j][k % 8], acc);
         W.d[dl][dr] = acc;
       }
   });

@@ -2,7 +2,7 @@
 // Builds the unmodified kernel source against emu_hip.h and exposes a tiny C API for pytest
 // (tests/test_emu_kernels.py): host buffers stand in for HBM, selected workgroups are executed.
 #define THA4_EMU 1
-#include "siren_kernels.h"
+#include "siren16_kernels.h"
 #include "tha4_hip.h"
 
 #include <map>
@@ -12,6 +12,8 @@ using namespace tha4;
 
 namespace {
 struct EmuStudent {
+  int gen = 1;
+  v2::StudentPacked16 packed16;
   StudentPacked packed;
   std::vector<float> pos128, pos256, pos512;
   std::map<std::string, std::vector<float>> buf;
@@ -32,8 +34,12 @@ StudentWeightsView to_view(const tha4_student_weights* w) {
 
 extern "C" {
 
-void* emu_student_create(const tha4_student_weights* w, const tha4_position_axes* axes) {
+void* emu_student_create_gen(const tha4_student_weights* w, const tha4_position_axes* axes, int gen);
+void* emu_student_create(const tha4_student_weights* w, const tha4_position_axes* axes) { return emu_student_create_gen(w, axes, 1); }
+
+void* emu_student_create_gen(const tha4_student_weights* w, const tha4_position_axes* axes, int gen) {
   auto* e = new EmuStudent();
+  e->gen = gen;
   std::string err = pack_student(to_view(w), e->packed);
   if (!err.empty()) {
     std::fprintf(stderr, "emu_student_create: %s\n", err.c_str());
@@ -64,6 +70,13 @@ void* emu_student_create(const tha4_student_weights* w, const tha4_position_axes
   StudentDev& d = e->dev;
   const StudentPacked& p = e->packed;
   d.w_face = p.w_face.data(); d.w_l0 = p.w_l0.data(); d.w_l1 = p.w_l1.data(); d.w_l2 = p.w_l2.data();
+  if (gen == 2) {
+    v2::pack_student16(to_view(w), e->packed16);
+    d.w_face = reinterpret_cast<const float*>(e->packed16.w_face.data());
+    d.w_l0 = reinterpret_cast<const float*>(e->packed16.w_l0.data());
+    d.w_l1 = reinterpret_cast<const float*>(e->packed16.w_l1.data());
+    d.w_l2 = reinterpret_cast<const float*>(e->packed16.w_l2.data());
+  }
   d.b_face = p.b_face.data(); d.b_l0 = p.b_l0.data(); d.b_l1 = p.b_l1.data(); d.b_l2 = p.b_l2.data();
   const FirstLayerPack* f[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
   for (int i = 0; i < 4; ++i) {
@@ -88,7 +101,17 @@ float* emu_student_buffer(void* h, const char* name, int64_t* nfloats) {
 }
 
 // number of workgroups of kernel k (0 posebias, 1 face, 2 level0, 3 level1, 4 level2) at batch 1
-int emu_student_grid(int kernel) {
+int emu_student_grid_gen(int kernel, int gen) {
+  if (gen == 2) {
+    switch (kernel) {
+      case 0: return cfg::posebias_blocks();
+      case 1: return v2::cfg::blocks_for<v2::cfg::FaceG>(1, 128);
+      case 2: return v2::cfg::blocks_for<v2::cfg::L0G>(1, 128);
+      case 3: return v2::cfg::blocks_for<v2::cfg::L1G>(1, 256);
+      case 4: return THA4_L2_RESIDENT ? (512 * 512) / v2::cfg::L2P::PX : v2::cfg::blocks_for<v2::cfg::L2G>(1, 512);
+    }
+    return -1;
+  }
   switch (kernel) {
     case 0: return cfg::posebias_blocks();
     case 1: return cfg::blocks_for<cfg::FaceG>(1, 128);
@@ -98,10 +121,27 @@ int emu_student_grid(int kernel) {
   }
   return -1;
 }
+int emu_student_grid(int kernel) { return emu_student_grid_gen(kernel, 1); }
 
 int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
   auto* e = static_cast<EmuStudent*>(h);
-  const int grid = emu_student_grid(kernel);
+  const int grid = emu_student_grid_gen(kernel, e->gen);
+  if (e->gen == 2) {
+    if (grid < 0 || first_block < 0 || first_block + nblocks > grid) return -1;
+    for (int b = first_block; b < first_block + nblocks; ++b) {
+      switch (kernel) {
+        case 0: emu::run_block(posebias_kernel, dim3(grid, 1), dim3(b, 0), kPoseBiasBlock, 0, e->dev); break;
+        case 1: emu::run_block(THA4_FACE16_KERNEL, dim3(grid), dim3(b), v2::cfg::FaceG::THREADS, v2::cfg::FaceG::LDS, e->dev); break;
+        case 2: emu::run_block(THA4_L016_KERNEL, dim3(grid), dim3(b), v2::cfg::L0G::THREADS, v2::cfg::L0G::LDS, e->dev); break;
+        case 3: emu::run_block(THA4_L116_KERNEL, dim3(grid), dim3(b), v2::cfg::L1G::THREADS, v2::cfg::L1G::LDS, e->dev); break;
+        case 4:
+          if (THA4_L2_RESIDENT) emu::run_block(THA4_L216P_KERNEL, dim3(grid), dim3(b), v2::cfg::L2P::THREADS, v2::cfg::L2P::LDS, e->dev);
+          else emu::run_block(THA4_L216_KERNEL, dim3(grid), dim3(b), v2::cfg::L2G::THREADS, v2::cfg::L2G::LDS, e->dev);
+          break;
+      }
+    }
+    return 0;
+  }
   if (grid < 0 || first_block < 0 || first_block + nblocks > grid) return -1;
   for (int b = first_block; b < first_block + nblocks; ++b) {
     switch (kernel) {
@@ -116,10 +156,15 @@ int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
 }
 
 // pixels [first, first+count) (row-major index at the kernel's resolution) covered by workgroup b
-void emu_student_block_pixels(int kernel, int block, int* first, int* count) {
-  *count = kernel == 1 ? cfg::FaceG::PX : kernel == 2 ? cfg::L0G::PX : kernel == 3 ? cfg::L1G::PX : cfg::L2G::PX;
+void emu_student_block_pixels_gen(int kernel, int block, int gen, int* first, int* count) {
+  if (gen == 2)
+    *count = kernel == 1 ? v2::cfg::FaceG::PX : kernel == 2 ? v2::cfg::L0G::PX : kernel == 3 ? v2::cfg::L1G::PX
+             : (THA4_L2_RESIDENT ? v2::cfg::L2P::PX : v2::cfg::L2G::PX);
+  else
+    *count = kernel == 1 ? cfg::FaceG::PX : kernel == 2 ? cfg::L0G::PX : kernel == 3 ? cfg::L1G::PX : cfg::L2G::PX;
   *first = block * (*count);
 }
+void emu_student_block_pixels(int kernel, int block, int* first, int* count) { emu_student_block_pixels_gen(kernel, block, 1, first, count); }
 
 float emu_sin_omega(float z) { return sin_omega(z); }
 

@@ -12,11 +12,14 @@ K_POSEBIAS, K_FACE, K_L0, K_L1, K_L2 = range(5)
 
 
 class EmuStudent:
-    def __init__(self, flat_weights, axes=None):
+    def __init__(self, flat_weights, axes=None, gen=1):
+        self.gen = gen
         self.lib = C.CDLL(os.path.join(HERE, "emu", "libtha4_emu.so"))
         L = self.lib
-        L.emu_student_create.restype = C.c_void_p
-        L.emu_student_create.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_student_create_gen.restype = C.c_void_p
+        L.emu_student_create_gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.emu_student_grid_gen.argtypes = [C.c_int, C.c_int]
+        L.emu_student_block_pixels_gen.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.emu_student_buffer.restype = C.POINTER(C.c_float)
         L.emu_student_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         L.emu_student_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -28,7 +31,7 @@ class EmuStudent:
         face_sd, body_sd = split_flat_weights(flat_weights)
         ws, self._keep = _capi.build_student_weights(face_sd, body_sd)
         ax, self._keep2 = _capi.build_position_axes(axes)
-        self.h = L.emu_student_create(C.byref(ws), C.byref(ax) if ax is not None else None)
+        self.h = L.emu_student_create_gen(C.byref(ws), C.byref(ax) if ax is not None else None, gen)
         assert self.h
 
     def buf(self, name):
@@ -38,14 +41,14 @@ class EmuStudent:
         return np.ctypeslib.as_array(p, shape=(n.value,))
 
     def grid(self, kernel):
-        return self.lib.emu_student_grid(kernel)
+        return self.lib.emu_student_grid_gen(kernel, self.gen)
 
     def run(self, kernel, first, count=1):
         assert self.lib.emu_student_run(self.h, kernel, first, count) == 0
 
     def block_pixels(self, kernel, block):
         f, c = C.c_int(), C.c_int()
-        self.lib.emu_student_block_pixels(kernel, block, C.byref(f), C.byref(c))
+        self.lib.emu_student_block_pixels_gen(kernel, block, self.gen, C.byref(f), C.byref(c))
         return slice(f.value, f.value + c.value)
 
     def sin_omega(self, z):

@@ -9,10 +9,11 @@ from oracle import student_oracle as so
 from tests.emu_util import K_FACE, K_L0, K_L1, K_L2, K_POSEBIAS, EmuStudent, pack_z, unpack_z
 
 
-@pytest.fixture(scope="module")
-def ctx(built, golden_weights, golden_io):
+@pytest.fixture(scope="module", params=[1, 2], ids=["fp32-mfma", "fp16x3-mfma"])
+def ctx(request, built, golden_weights, golden_io):
+    """Both kernel generations: 1 = exact-fp32 v_mfma_f32_16x16x4_f32, 2 = fp16 hi/lo split on v_mfma_f32_16x16x32_f16."""
     pose = golden_io["poses"][0]
-    emu = EmuStudent(golden_weights)
+    emu = EmuStudent(golden_weights, gen=request.param)
     emu.buf("pose")[:] = pose
     emu.buf("image")[:] = golden_io["image_f32"].reshape(-1)
     it = so.student_intermediates(golden_weights, pose)
@@ -85,7 +86,9 @@ def test_level2_kernel_blocks(ctx, golden_weights, golden_io):
     ref = so.student_forward_numpy(golden_weights, golden_io["image_f32"], pose)
     tol = {"out_blended": 5e-4, "out_alpha": 1e-5, "out_color": 2e-5, "out_warped": 5e-4, "out_grid": 5e-6}
     # 288/289: row 144 (inside the pasted face rows), 160..: row 80 = first face row
-    for b in (0, 1, 160, 288, 289, 400, emu.grid(K_L2) - 1):
+    g = emu.grid(K_L2)
+    # rows 0, 80 (first face row), 144 (inside the pasted face), 200 and the last one
+    for b in sorted({0, 1, g * 80 // 512, g * 144 // 512, g * 144 // 512 + 1, g * 200 // 512, g - 1}):
         emu.run(K_L2, b)
         px = emu.block_pixels(K_L2, b)
         for name, k, c in (("out_blended", 0, 4), ("out_alpha", 1, 1), ("out_color", 2, 4), ("out_warped", 3, 4),

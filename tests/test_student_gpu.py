@@ -55,6 +55,7 @@ def test_output0_parity_vs_oracle_and_reference_fixture(poser, dev, golden_io, o
         assert out.shape == (1, 4, 512, 512) and out.dtype == torch.float32 and out.device == image.device
         got = out[0].cpu().numpy()
         err = np.abs(got - oracle32[0][i]).max(axis=(1, 2))
+        print(f"PARITY pose {i} out0 max-abs vs oracle fp32 {err.max():.3e}")
         assert err.max() <= TOL_OUT0, f"pose {i}: per-channel max-abs {err}"
         if i == 0:
             assert np.abs(got - golden_io["ref32_full_out0"][0]).max() <= TOL_OUT0
@@ -140,6 +141,20 @@ def test_random_weights_and_synthetic_image(dev):
     assert np.abs(outs[5].cpu().numpy() - ref[5].numpy()).max() <= 2e-4
     assert np.abs(outs[4].cpu().numpy() - ref[4].numpy()).max() <= 5e-5
     p.free()
+
+
+def test_exact_fp32_generation_and_split_agree(poser, dev, golden_weights, golden_io, oracle32):
+    """A/B of the two kernel generations: exact-fp32 MFMA vs the default fp16 hi/lo split."""
+    face, body = split_flat_weights(golden_weights)
+    exact = mode_14.create_poser_from_state_dicts(dev, face, body, exact_fp32=True)
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    for i in range(2):
+        pose = torch.from_numpy(golden_io["poses"][i]).to(dev)
+        a = exact.pose(image, pose)[0].cpu().numpy()
+        b = poser.pose(image, pose)[0].cpu().numpy()
+        assert np.abs(a - oracle32[0][i]).max() <= TOL_OUT0
+        assert np.abs(a - b).max() <= 6e-4          # the split drops ~2 of fp32's 24 product bits
+    exact.free()
 
 
 def test_exact_position_axes_variant(dev, golden_weights, golden_io):

@@ -17,13 +17,9 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "x_nosin": ["-DTHA4_ABLATE_SIN"],
-    "x_nofetch": ["-DTHA4_ABLATE_FETCH"],
-    "x_nobarrier": ["-DTHA4_ABLATE_BARRIER"],
-    "x_nosin_nobar": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_BARRIER"],
-    "x_all": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_BARRIER", "-DTHA4_ABLATE_FETCH"],
-    "l2_pg2_72k": ["-DTHA4_L2_CFG=4,1,2,2"],
-    "l1_ms2": ["-DTHA4_L1_CFG=4,2,2,2,3"],
+    "hwsin": ["-DTHA4_HW_SIN"],
+    "l1_ms2pg2": ["-DTHA4_L116_CFG=4,2,2,1,1"],
+    "hwsin_l1ms2": ["-DTHA4_HW_SIN", "-DTHA4_L116_CFG=4,2,2,1,1"],
 }
 
 
@@ -55,6 +51,10 @@ def run(steps):
         km = j["roofline"]["kernel_ms"]
         rows.append((name, j["value"], km))
         print(f"{name:10s} fps {j['value']:8.1f}  " + "  ".join(f"{k} {v*1000:6.1f}us" for k, v in km.items()), flush=True)
+        if "--parity" in sys.argv:
+            r2 = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_student_gpu.py"), "-x", "-q", "-k",
+                                 "output0_parity or all_six", "-s"], capture_output=True, text=True, env=env, timeout=600)
+            print("   parity:", [l for l in r2.stdout.splitlines() if "passed" in l or "failed" in l or "PARITY" in l][-3:], flush=True)
     return rows
 
 
