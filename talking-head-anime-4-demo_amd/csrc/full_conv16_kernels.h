@@ -1,0 +1,296 @@
+// Tiled implicit-GEMM convolution, second generation (feature maps >= 64x64 of the full THA4 system).
+//
+// conv_mfma_kernel (full_kernels.h) re-forms its im2col operand for EVERY tap and output tile - scale/shift,
+// activation, padding select and 64-bit address arithmetic per 16-byte load - and multiplies with exact-fp32
+// v_mfma_f32_16x16x4_f32 (32 cycles per 4-deep k step).  Here
+//   * a workgroup (8 waves) owns a TH x TW block of output positions and TMB output blocks; per 32-channel K group
+//     it stages the (TH*s + halo) x (TW*s + halo) input window ONCE into LDS, already normalised, activated,
+//     resampled (nearest-up / avg-pool), zero padded and split into fp16 hi + fp16 lo (v = hi + lo, 22 bits);
+//   * all taps then read their B fragments from that window at a constant LDS offset per tap, the weights stream
+//     through a 2-slot LDS ring as fp16 hi/lo fragment pieces (pre-scaled by a power of two so small weights keep
+//     their low half out of the fp16 subnormal range), and every 32-deep k step costs three
+//     v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, 48 cycles instead of 256) into one fp32 accumulator;
+//   * the window of K group Q+1 is loaded into registers under the MFMAs of group Q.
+// Numerics: products are exact in fp32; dropped lo*lo terms and the rounding of the lo halves are ~2^-22 relative,
+// four times the fp32 rounding the reference itself commits per product (tests: 2e-5 abs on O(1) outputs).
+//
+// K-slot permutation: lane group g = lane>>4 holds, in its 8 k-slots, channels 4g..4g+3 of quad 2Q (j<4) and of quad
+// 2Q+1 (j>=4), i.e. exactly the two 16-byte C16 loads a staging thread makes for one (pixel, g); the weight
+// pieces use the same permutation (full_layout.h pack_conv_weight16).
+#pragma once
+#include "full_kernels.h"
+
+namespace tha4 {
+
+constexpr int kTileWaves = 8;
+constexpr int kTileThreads = kTileWaves * 64;
+constexpr int kTileMaxItems = 5;     // staging items (pixel, g) per thread and K group: window <= 640 pixels
+
+// bytes of one lane-group plane of the window image; planes are skewed by 32 B so that the staging writes
+// (4 consecutive lanes = 4 planes of one pixel) hit distinct banks
+constexpr int tile_plane_bytes(int win_px) { return (win_px * 16 + 127) / 128 * 128 + 32; }
+
+template <int TMB, int PG, int INMODE>
+__global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
+  constexpr bool kPool = INMODE == IN_POOL2;
+  THA4_DYN_LDS(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform_i32(tid >> 6);
+  const int p = lane & 15, g = lane >> 4, g4 = g * 4;
+
+  // ---- tile decomposition -------------------------------------------------------------------
+  const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (kTileWaves * PG * 16) >> twl;
+  const int tiles_x = a.tile_w >> twl;
+  const int tiles_per_frame = tiles_x * (a.tile_h / TWH);
+  const int n = blockIdx.x / tiles_per_frame;
+  const int tile = blockIdx.x % tiles_per_frame;
+  const int tile_y0 = (tile / tiles_x) * TWH, tile_x0 = (tile % tiles_x) << twl;
+  const int mtile = blockIdx.y;
+  const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (kPool ? a.in_h / 2 : a.in_h);
+  const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (kPool ? a.in_w / 2 : a.in_w);
+  const int in_px = a.in_h * a.in_w;
+  const int WW = a.win_w, NPX = a.win_h * a.win_w;
+  const int PLANE = tile_plane_bytes(NPX);
+  const int vy0 = tile_y0 * a.in_stride + a.win_dy0, vx0 = tile_x0 * a.in_stride + a.win_dx0;
+
+  int cbtot = 0;
+  for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
+  const int NQ = (cbtot + 1) >> 1;                       // 32-channel K groups
+  const int ntc = a.ntaps / a.taps_per_chunk;            // weight chunks per K group
+  const int slot_bytes = a.taps_per_chunk * TMB * 2048;
+  char* win_hi = smem;
+  char* win_lo = smem + 4 * PLANE;
+  char* ring = smem + 8 * PLANE;
+  float* red = reinterpret_cast<float*>(ring + 2 * slot_bytes);          // [8 waves][TMB*16][2]
+  const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
+
+  // ---- per-lane output pixels ------------------------------------------------------------------
+  int ly[PG], lx[PG], boff[PG];
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    const int i = (wave * PG + pg) * 16 + p;
+    ly[pg] = i >> twl;
+    lx[pg] = i & (TWW - 1);
+    boff[pg] = ((ly[pg] * a.in_stride) * WW + lx[pg] * a.in_stride) * 16 + g * PLANE;
+  }
+
+  // ---- staging items of this thread (geometry is the same for every K group) --------------------
+  const int sg = tid & 3;                                 // lane group plane this thread stages
+  const int nitems = NPX * 4;
+  int gofs[kTileMaxItems];                                // source pixel index (clamped); < 0: zero padding
+#pragma unroll
+  for (int k = 0; k < kTileMaxItems; ++k) {
+    const int item = tid + k * kTileThreads;
+    const int px = item >> 2;
+    const int wy = px / WW, wx = px - wy * WW;
+    const int vy = vy0 + wy, vx = vx0 + wx;
+    const bool ok = item < nitems && (unsigned)vy < (unsigned)vh && (unsigned)vx < (unsigned)vw;
+    int o;
+    if (INMODE == IN_DIRECT) o = vy * a.in_w + vx;
+    else if (INMODE == IN_UP2) o = (vy >> 1) * a.in_w + (vx >> 1);
+    else o = (2 * vy) * a.in_w + 2 * vx;
+    gofs[k] = ok ? o : -1;
+  }
+
+  auto fetch = [&](int chunk, int slot) {
+    const char* src = gw + (size_t)chunk * slot_bytes;
+    char* dst = ring + slot * slot_bytes;
+    const int pieces = a.taps_per_chunk * TMB * 2;
+    for (int pc = wave; pc < pieces; pc += kTileWaves) glds16(src + pc * 1024 + lane * 16, dst + pc * 1024);
+  };
+
+  // one quad of one K group: which source, its scale/shift/activation for lane group sg
+  struct QuadCtx { const float* base; f32x4 sc, sh; int act; int kind; };
+  auto quad_ctx = [&](int q) -> QuadCtx {
+    QuadCtx c;
+    c.base = nullptr; c.act = ACT_NONE; c.kind = SRC_TENSOR;
+    c.sc = f32x4{1.f, 1.f, 1.f, 1.f};
+    c.sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q >= cbtot) return c;                             // phantom quad of an odd channel-block count
+    int s = 0, ql = q;
+    if (a.nsrc > 1 && q >= a.src[0].cb) { s = 1; ql = q - a.src[0].cb; }
+    const ConvSrc& S = a.src[s];
+    c.act = S.act; c.kind = S.kind;
+    if (S.scale) {
+      c.sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + sg * 4);
+      c.sh = *reinterpret_cast<const f32x4*>(S.shift + ((size_t)n * S.cb + ql) * 16 + sg * 4);
+    }
+    c.base = S.kind == SRC_VECTOR ? S.data + ((size_t)n * S.cb + ql) * 16 + sg * 4
+                                  : S.data + ((size_t)n * S.cb + ql) * (size_t)in_px * 16 + sg * 4;
+    return c;
+  };
+  auto activate = [&](const f32x4& r, const QuadCtx& c) -> f32x4 {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = apply_act(fmaf(r[j], c.sc[j], c.sh[j]), c.act);
+    return o;
+  };
+  // raw (IN_DIRECT / IN_UP2) or finished (IN_POOL2: the 2x2 mean of the activated samples) values of one item
+  auto load_quad = [&](const QuadCtx& c, int o) -> f32x4 {
+    if (!c.base || o < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c.kind == SRC_VECTOR) return *reinterpret_cast<const f32x4*>(c.base);
+    const float* ptr = c.base + (size_t)o * 16;
+    if (!kPool) return *reinterpret_cast<const f32x4*>(ptr);
+    const f32x4 v00 = activate(*reinterpret_cast<const f32x4*>(ptr), c);
+    const f32x4 v01 = activate(*reinterpret_cast<const f32x4*>(ptr + 16), c);
+    const f32x4 v10 = activate(*reinterpret_cast<const f32x4*>(ptr + (size_t)a.in_w * 16), c);
+    const f32x4 v11 = activate(*reinterpret_cast<const f32x4*>(ptr + (size_t)a.in_w * 16 + 16), c);
+    return ((v00 + v01) + (v10 + v11)) * 0.25f;           // AvgPool2d(2,2) of the activated tensor (unet.py:58)
+  };
+
+  f32x4 rawA[kTileMaxItems], rawB[kTileMaxItems];
+  QuadCtx cA, cB;
+  auto load_window = [&](int Q) {
+    cA = quad_ctx(2 * Q);
+    cB = quad_ctx(2 * Q + 1);
+#pragma unroll
+    for (int k = 0; k < kTileMaxItems; ++k) {
+      rawA[k] = load_quad(cA, gofs[k]);
+      rawB[k] = load_quad(cB, gofs[k]);
+    }
+  };
+  auto write_window = [&]() {
+#pragma unroll
+    for (int k = 0; k < kTileMaxItems; ++k) {
+      const int item = tid + k * kTileThreads;
+      if (item >= nitems) continue;
+      f32x4 va = rawA[k], vb = rawB[k];
+      if (gofs[k] < 0) {                                   // zero padding is applied AFTER normalisation + activation
+        va = f32x4{0.f, 0.f, 0.f, 0.f};
+        vb = va;
+      } else if (!kPool) {
+        if (cA.base) va = activate(va, cA);
+        if (cB.base) vb = activate(vb, cB);
+      }
+      f16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = (_Float16)va[j];
+        lo[j] = (_Float16)(va[j] - (float)hi[j]);
+        hi[4 + j] = (_Float16)vb[j];
+        lo[4 + j] = (_Float16)(vb[j] - (float)hi[4 + j]);
+      }
+      const int off = sg * PLANE + (item >> 2) * 16;
+      *reinterpret_cast<f16x8*>(win_hi + off) = hi;
+      *reinterpret_cast<f16x8*>(win_lo + off) = lo;
+    }
+  };
+
+  f32x4 acc[TMB][PG];
+#pragma unroll
+  for (int b = 0; b < TMB; ++b)
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(0, 0);
+  load_window(0);
+  write_window();
+  __syncthreads();
+  int slot = 0, chunk = 0;
+  const int nchunks = NQ * ntc;
+  for (int Q = 0; Q < NQ; ++Q) {
+    if (Q + 1 < NQ) load_window(Q + 1);
+    for (int tc = 0; tc < ntc; ++tc) {
+      if (chunk + 1 < nchunks) fetch(chunk + 1, slot ^ 1);
+      const char* wsl = ring + slot * slot_bytes + lane * 16;
+      for (int tt = 0; tt < a.taps_per_chunk; ++tt) {
+        const int t = tc * a.taps_per_chunk + tt;
+        const int toff = ((a.tap_dy[t] - a.win_dy0) * WW + (a.tap_dx[t] - a.win_dx0)) * 16;
+        f16x8 bh[PG], bl[PG];
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+          bh[pg] = *reinterpret_cast<const f16x8*>(win_hi + boff[pg] + toff);
+          bl[pg] = *reinterpret_cast<const f16x8*>(win_lo + boff[pg] + toff);
+        }
+#pragma unroll
+        for (int b = 0; b < TMB; ++b) {
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
+#pragma unroll
+          for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah, bh[pg], acc[b][pg]);
+#pragma unroll
+          for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah, bl[pg], acc[b][pg]);
+#pragma unroll
+          for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(al, bh[pg], acc[b][pg]);
+        }
+      }
+      __syncthreads();
+      slot ^= 1;
+      ++chunk;
+    }
+    if (Q + 1 < NQ) {
+      write_window();                                      // every wave has finished reading window Q (barrier above)
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: 1/scale, bias, residual, activation, store, deterministic per-tile statistics ----
+  const int out_px = a.out_h * a.out_w;
+  float ssum[TMB][4], ssq[TMB][4];
+#pragma unroll
+  for (int b = 0; b < TMB; ++b) {
+    const int bo = mtile * TMB + b;
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[b][j] = 0.f; ssq[b][j] = 0.f; }
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
+      const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
+      f32x4 v = acc[b][pg] * a.w16_inv_scale + bias;
+      if (a.residual) {
+        if (a.res_mode == IN_DIRECT) {
+          v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
+        } else if (a.res_mode == IN_UP2) {      // ResBlock x_resample = Upsample (unet.py:46): nearest
+          const int rw = a.out_w >> 1, rpx = out_px >> 2;
+          v = v + *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
+        } else {                                // x_resample = Downsample = AvgPool2d(2,2) (unet.py:58)
+          const int rw = a.out_w * 2;
+          const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
+          const f32x4 r = ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
+                           (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
+          v = v + r;
+        }
+      }
+      if (a.act_out) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
+      }
+      *reinterpret_cast<f32x4*>(a.out + off) = v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ssum[b][j] += v[j]; ssq[b][j] = fmaf(v[j], v[j], ssq[b][j]); }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = ssum[b][j], q = ssq[b][j];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          s += lane_read(s, lane ^ m);
+          q += lane_read(q, lane ^ m);
+        }
+        if (p == 0) {
+          red[((wave * TMB + b) * 16 + g4 + j) * 2 + 0] = s;
+          red[((wave * TMB + b) * 16 + g4 + j) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < TMB * 16; i += kTileThreads) {
+      float s = 0.f, q = 0.f;
+      for (int wv2 = 0; wv2 < kTileWaves; ++wv2) {
+        s += red[((wv2 * TMB) * 16 + i) * 2 + 0];
+        q += red[((wv2 * TMB) * 16 + i) * 2 + 1];
+      }
+      float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + mtile * TMB) * 16 + i) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+}
+
+}  // namespace tha4

@@ -56,6 +56,13 @@ struct ConvArgs {
   int nb;                // output channel blocks
   int chunk_quads;       // input quads per streamed weight chunk
   int batch;
+  // conv_tile_kernel (full_conv16_kernels.h) only
+  const void* w16;       // fp16 hi/lo pieces [mtile][K group][tap][TMB][hi 1 KiB | lo 1 KiB] (full_layout.h pack_conv_weight16)
+  float w16_inv_scale;   // 1 / (power-of-two scale folded into the fp16 weights)
+  int wg_tw_log2;        // log2 of the workgroup tile width (tile positions)
+  int win_h, win_w;      // staged input window (virtual input pixels)
+  int win_dy0, win_dx0;  // window origin relative to (tile origin * in_stride)
+  int taps_per_chunk;    // taps per streamed weight chunk (divides ntaps)
 };
 
 THA4_DEV float apply_act(float v, int act) {

@@ -1,7 +1,10 @@
 // Host-side layout helpers for the full-model kernels (plain C++, shared with the CPU unit tests).
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace tha4 {
@@ -94,6 +97,89 @@ inline std::vector<float> pack_conv_weight(const float* W, int cout, int cin, in
     }
   }
   return P;
+}
+
+// fp16 hi/lo weight image for conv_tile_kernel<TMB,...>: 2 KiB pieces [mtile][Q][tap][b<TMB][hi: lane x 8 | lo: lane x 8],
+// K group Q = quads 2Q, 2Q+1 of the concatenated sources; k-slot j of lane group g = lane>>4 is channel
+// 4g + (j&3) of quad 2Q + (j>>2).  Weights are multiplied by a power of two S (max |W| S in [8192, 16384)) before the
+// split so that the low halves of small weights stay clear of the fp16 subnormal range; *inv_scale = 1/S.
+inline std::vector<char> pack_conv_weight16(const float* W, int cout, int cin, int kh, int kw, bool transposed, const ConvGeom& g,
+                                            const std::vector<ChannelSegment>& segs, int TMB, float* inv_scale) {
+  const int nb = (cout + 15) / 16;
+  const int mtiles = (nb + TMB - 1) / TMB;
+  std::vector<std::pair<int, int>> quads;     // (segment, local quad)
+  for (size_t s = 0; s < segs.size(); ++s)
+    for (int ql = 0; ql < (segs[s].count + 15) / 16; ++ql) quads.push_back({(int)s, ql});
+  const int NQ = ((int)quads.size() + 1) / 2;
+  float mx = 0.f;
+  for (size_t i = 0; i < (size_t)cout * cin * kh * kw; ++i) mx = std::max(mx, std::fabs(W[i]));
+  int e = 0;
+  if (mx > 0.f) { std::frexp(16384.0f / mx, &e); e -= 1; }     // 2^e <= 16384 / mx < 2^(e+1)
+  e = std::min(std::max(e, -24), 24);
+  const float S = std::ldexp(1.0f, e);
+  *inv_scale = std::ldexp(1.0f, -e);
+  std::vector<char> P((size_t)mtiles * NQ * g.ntaps * TMB * 2048, 0);
+  for (int mt = 0; mt < mtiles; ++mt)
+    for (int Q = 0; Q < NQ; ++Q)
+      for (int t = 0; t < g.ntaps; ++t)
+        for (int b = 0; b < TMB; ++b) {
+          _Float16* hi = reinterpret_cast<_Float16*>(P.data() + ((((size_t)mt * NQ + Q) * g.ntaps + t) * TMB + b) * 2048);
+          _Float16* lo = hi + 512;
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int q = 2 * Q + (j >> 2);
+              float v = 0.f;
+              if (q < (int)quads.size()) {
+                const ChannelSegment& sg = segs[quads[q].first];
+                const int il = 16 * quads[q].second + 4 * (lane >> 4) + (j & 3);
+                const int o = 16 * (mt * TMB + b) + (lane & 15);
+                if (o < cout && il < sg.count) {
+                  const int i = sg.offset + il;
+                  const size_t idx = transposed ? (((size_t)i * cout + o) * kh + g.ky[t]) * kw + g.kx[t]
+                                                : (((size_t)o * cin + i) * kh + g.ky[t]) * kw + g.kx[t];
+                  v = W[idx] * S;
+                }
+              }
+              const _Float16 h = (_Float16)v;
+              hi[lane * 8 + j] = h;
+              lo[lane * 8 + j] = (_Float16)(v - (float)h);
+            }
+        }
+  return P;
+}
+
+// Workgroup tiling of conv_tile_kernel<TMB, PG>: 8 waves x PG pixel groups of 16 positions.
+struct TileGeom {
+  bool ok = false;
+  int tw_log2 = 4, th = 0;       // workgroup tile: th x (1 << tw_log2) positions
+  int win_h = 0, win_w = 0, dy0 = 0, dx0 = 0;
+  int taps_per_chunk = 1;
+  size_t lds = 0;
+};
+inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB) {
+  TileGeom t;
+  const int px = 8 * PG * 16;
+  t.tw_log2 = (PG >= 4 && tile_w % 32 == 0) ? 5 : 4;
+  const int tw = 1 << t.tw_log2;
+  t.th = px / tw;
+  if (tile_w % tw != 0 || tile_h % t.th != 0) return t;
+  int dy_lo = g.dy[0], dy_hi = g.dy[0], dx_lo = g.dx[0], dx_hi = g.dx[0];
+  for (int i = 1; i < g.ntaps; ++i) {
+    dy_lo = std::min(dy_lo, g.dy[i]); dy_hi = std::max(dy_hi, g.dy[i]);
+    dx_lo = std::min(dx_lo, g.dx[i]); dx_hi = std::max(dx_hi, g.dx[i]);
+  }
+  t.dy0 = dy_lo; t.dx0 = dx_lo;
+  t.win_h = (t.th - 1) * g.in_stride + (dy_hi - dy_lo) + 1;
+  t.win_w = (tw - 1) * g.in_stride + (dx_hi - dx_lo) + 1;
+  const int npx = t.win_h * t.win_w;
+  if (npx * 4 > 5 * 512) return t;                     // kTileMaxItems staging items per thread
+  t.taps_per_chunk = 1;
+  for (int d = 1; d <= g.ntaps; ++d)
+    if (g.ntaps % d == 0 && d * TMB * 2048 <= 32 * 1024) t.taps_per_chunk = d;
+  const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
+  t.lds = 8 * plane + 2 * (size_t)t.taps_per_chunk * TMB * 2048 + 8 * (size_t)TMB * 16 * 2 * sizeof(float);
+  t.ok = t.lds <= 160 * 1024;
+  return t;
 }
 
 // NCHW [c][h*w] <-> C16 [cb][h*w][16] for one frame

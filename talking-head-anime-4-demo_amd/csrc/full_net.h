@@ -11,12 +11,15 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "full_image_kernels.h"
+#include "full_conv16_kernels.h"
 #include "full_kernels.h"
 #include "full_layout.h"
 
@@ -121,6 +124,18 @@ class FullModel {
     THA4_CASE(4, 2) THA4_CASE(4, 1) THA4_CASE(2, 2) THA4_CASE(2, 1) THA4_CASE(1, 1)
 #undef THA4_CASE
   }
+  template <int TMB, int PG>
+  static void launch_tile(int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    if (inmode == IN_DIRECT) hipLaunchKernelGGL((conv_tile_kernel<TMB, PG, IN_DIRECT>), grid, dim3(kTileThreads), lds, s, a);
+    else if (inmode == IN_UP2) hipLaunchKernelGGL((conv_tile_kernel<TMB, PG, IN_UP2>), grid, dim3(kTileThreads), lds, s, a);
+    else hipLaunchKernelGGL((conv_tile_kernel<TMB, PG, IN_POOL2>), grid, dim3(kTileThreads), lds, s, a);
+  }
+  static void dispatch_tile(int tmb, int pg, int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+#define THA4_TCASE(TM, PGV) if (tmb == TM && pg == PGV) return launch_tile<TM, PGV>(inmode, a, grid, lds, s);
+    THA4_TCASE(4, 4) THA4_TCASE(4, 2) THA4_TCASE(4, 1) THA4_TCASE(2, 4) THA4_TCASE(2, 2) THA4_TCASE(2, 1)
+    THA4_TCASE(1, 4) THA4_TCASE(1, 2) THA4_TCASE(1, 1)
+#undef THA4_TCASE
+  }
   static hipError_t allow_all_conv_lds() {
     hipError_t e = hipSuccess;
     auto set = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
@@ -130,6 +145,13 @@ class FullModel {
   set(reinterpret_cast<const void*>(conv_mfma_kernel<TM, PGV, IN_POOL2>));
     THA4_ALLOW(4, 2) THA4_ALLOW(4, 1) THA4_ALLOW(2, 2) THA4_ALLOW(2, 1) THA4_ALLOW(1, 1)
 #undef THA4_ALLOW
+#define THA4_TALLOW(TM, PGV)                                                       \
+  set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_DIRECT>));        \
+  set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_UP2>));           \
+  set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_POOL2>));
+    THA4_TALLOW(4, 4) THA4_TALLOW(4, 2) THA4_TALLOW(4, 1) THA4_TALLOW(2, 4) THA4_TALLOW(2, 2) THA4_TALLOW(2, 1)
+    THA4_TALLOW(1, 4) THA4_TALLOW(1, 2) THA4_TALLOW(1, 1)
+#undef THA4_TALLOW
     set(reinterpret_cast<const void*>(attention_kernel));
     return e;
   }
@@ -162,8 +184,24 @@ class FullModel {
     const bool splitk = tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
     int pg = 1;
     if (!splitk && tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
-    if (tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
-    const int tiles = splitk ? tile_px / 16 : tile_px / (64 * pg);
+    // maps >= 64x64: LDS-staged window + fp16 hi/lo MFMA (conv_tile_kernel); largest pixel tile that still fills the chip
+    bool tiled = false;
+    TileGeom tgeom;
+    if (!splitk && kind != K_SAME1 && !std::getenv("THA4_NO_TILE_CONV")) {
+      const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
+      for (int cand : {4, 2, 1}) {
+        const TileGeom tg = tile_geom(g0, th, tw, cand, tmb);
+        if (!tg.ok) continue;
+        const int wgs = tile_px / (128 * cand) * mtiles;
+        if (!tiled || wgs >= 256 || cand == 1) { tiled = true; tgeom = tg; pg = cand; }
+        if (wgs >= 256) break;
+      }
+    }
+    if (!tiled && tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
+    const int tiles = tiled ? tile_px / (128 * pg) : splitk ? tile_px / 16 : tile_px / (64 * pg);
+    if (std::getenv("THA4_DUMP_SCHEDULE"))
+      std::fprintf(stderr, "conv kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d\n", (int)kind, ih,
+                   iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles, (int)tiled);
     FTensor out = new_tensor(nb, oh, ow);
     if (want_stats) {
       out.stats_tiles = tiles * nclass;
@@ -180,11 +218,24 @@ class FullModel {
     for (int cls = 0; cls < nclass; ++cls) {
       ConvGeom g = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1)
                  : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1);
-      const size_t w_off = add_param(pack_conv_weight(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb));
-      int cq = std::max(1, 32 / (g.ntaps * tmb));
-      cq = std::min(cq, cbtot);
-      const size_t lds = 2 * (size_t)cq * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
+      size_t w_off = 0, lds = 0;
+      int cq = 1;
       ConvArgs a{};
+      if (tiled) {
+        const TileGeom tg = tile_geom(g, th, tw, pg, tmb);
+        float inv = 1.f;
+        const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb, &inv);
+        w_off = add_param(p16.data(), p16.size());
+        lds = tg.lds;
+        a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
+        a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk;
+        if (!tg.ok) { if (error.empty()) error = "conv tile geometry differs between parity classes"; return FTensor(); }
+      } else {
+        w_off = add_param(pack_conv_weight(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb));
+        cq = std::max(1, 32 / (g.ntaps * tmb));
+        cq = std::min(cq, cbtot);
+        lds = 2 * (size_t)cq * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
+      }
       a.nsrc = (int)srcs.size();
       a.in_h = ih; a.in_w = iw; a.in_mode = in_mode;
       a.ntaps = g.ntaps;
@@ -211,6 +262,7 @@ class FullModel {
           c.src[i].shift = s.pend.has() ? Wk(s.pend.shift_off) : nullptr;
         }
         c.w = P(w_off);
+        c.w16 = P<char>(w_off);
         c.bias = bias_off == kNone ? nullptr : P(bias_off);
         c.act_out = act_off == kNone ? nullptr : P<int>(act_off);
         c.residual = has_res ? Wk(resc.off) : nullptr;
@@ -222,6 +274,8 @@ class FullModel {
           if (in_mode == IN_DIRECT) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_DIRECT>), grid, dim3(256), 16 * 1024, f.stream, c);
           else if (in_mode == IN_UP2) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_UP2>), grid, dim3(256), 16 * 1024, f.stream, c);
           else hipLaunchKernelGGL((conv_splitk_kernel<4, IN_POOL2>), grid, dim3(256), 16 * 1024, f.stream, c);
+        } else if (tiled) {
+          dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
         } else {
           dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
         }

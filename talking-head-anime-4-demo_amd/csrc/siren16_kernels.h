@@ -21,20 +21,7 @@
 namespace tha4 {
 namespace v2 {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
-
-#ifndef THA4_EMU
-THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-#else
-THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
-  float af[8], bf[8], r[4] = {c[0], c[1], c[2], c[3]};
-  for (int j = 0; j < 8; ++j) { af[j] = (float)a[j]; bf[j] = (float)b[j]; }
-  emu::mfma_f32_16x16x32(af, bf, r);
-  return f32x4{r[0], r[1], r[2], r[3]};
-}
-#endif
 
 // ---- host/device shared layout helpers ---------------------------------------------------------
 // order of the pieces of one K group in the weight stream when a chunk is 1/HB of the group's blocks and MS waves
@@ -226,7 +213,7 @@ THA4_DEV void z16_layer(const char*& gw, char* ring, int& slot, const char* act,
   for (int b = 0; b < NBW; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg)
-      *reinterpret_cast<f32x4*>(zframe + ((size_t)(mbase + b) * npix + pix0[pg] + p) * 16 + g4) = acc1[b][pg] + acc2[b][pg] * kLoInv;
+      *reinterpret_cast<f32x4*>(zframe + z_offset(mbase + b, w.lane >> 4, pix0[pg] + p, npix)) = acc1[b][pg] + acc2[b][pg] * kLoInv;
 }
 
 template <class G, int NB>
@@ -250,10 +237,11 @@ THA4_DEV void first16_pos(const float* wx, const float* wy, const float* pb, con
   }
 }
 
-template <class G, int NB>
-THA4_DEV void first16_up(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb,
-                         const int (&X0)[G::PG], const int (&Y)[G::PG], const float (&x)[G::PG], const float (&y)[G::PG],
-                         char* act, const WaveCtx& w) {
+// sink(pg, block, v): where the layer's output rows go (the LDS activation image, or registers)
+template <class G, int NB, class Sink>
+THA4_DEV void first16_up_to(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb,
+                            const int (&X0)[G::PG], const int (&Y)[G::PG], const float (&x)[G::PG], const float (&y)[G::PG],
+                            Sink&& sink, const WaveCtx& w) {
   constexpr int NBW = NB / G::MS, PG = G::PG;
   const int p = w.lane & 15, g4 = (w.lane >> 4) * 4, mbase = w.ms * NBW;
   const int npix = lowS * lowS;
@@ -263,19 +251,23 @@ THA4_DEV void first16_up(const float* zframe, int lowS, const float* wx, const f
     float lx0, lx1, ly0, ly1;
     up2_taps(X0[pg] + p, lowS, x0, x1, lx0, lx1);
     up2_taps(Y[pg], lowS, y0, y1, ly0, ly1);
-    const float* z00 = zframe + ((size_t)y0 * lowS + x0) * 16 + g4;
-    const float* z01 = zframe + ((size_t)y0 * lowS + x1) * 16 + g4;
-    const float* z10 = zframe + ((size_t)y1 * lowS + x0) * 16 + g4;
-    const float* z11 = zframe + ((size_t)y1 * lowS + x1) * 16 + g4;
+    const float* z00 = zframe + z_offset(0, w.lane >> 4, y0 * lowS + x0, npix);
+    const float* z01 = zframe + z_offset(0, w.lane >> 4, y0 * lowS + x1, npix);
+    const float* z10 = zframe + z_offset(0, w.lane >> 4, y1 * lowS + x0, npix);
+    const float* z11 = zframe + z_offset(0, w.lane >> 4, y1 * lowS + x1, npix);
 #pragma unroll
     for (int bb = 0; bb < NBW; ++bb) {
       const int b = mbase + bb;
       const size_t off = (size_t)b * npix * 16;
+      const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
+#ifdef THA4_ABLATE_ZLOAD   // timing ablation only: results are wrong
+      const f32x4 a = vx, bq = vx, c = vx, d = vx;
+#else
       const f32x4 a = *reinterpret_cast<const f32x4*>(z00 + off);
       const f32x4 bq = *reinterpret_cast<const f32x4*>(z01 + off);
       const f32x4 c = *reinterpret_cast<const f32x4*>(z10 + off);
       const f32x4 d = *reinterpret_cast<const f32x4*>(z11 + off);
-      const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
+#endif
       const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
       const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
       f32x4 v;
@@ -284,9 +276,17 @@ THA4_DEV void first16_up(const float* zframe, int lowS, const float* wx, const f
         const float up = ly0 * (lx0 * a[j] + lx1 * bq[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
         v[j] = sin_omega(up + fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));
       }
-      store_block<G>(act, pg, b, w.lane, v);
+      sink(pg, b, v);
     }
   }
+}
+
+template <class G, int NB>
+THA4_DEV void first16_up(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb,
+                         const int (&X0)[G::PG], const int (&Y)[G::PG], const float (&x)[G::PG], const float (&y)[G::PG],
+                         char* act, const WaveCtx& w) {
+  first16_up_to<G, NB>(zframe, lowS, wx, wy, pb, X0, Y, x, y,
+                       [&](int pg, int b, const f32x4& v) { store_block<G>(act, pg, b, w.lane, v); }, w);
 }
 
 // K groups / block counts of the four networks in this generation (channels padded to 32 for K)
@@ -483,29 +483,79 @@ __global__ void __launch_bounds__(NS* MS * 64) level2_16_kernel(StudentDev d) {
 // ---- level 2, weights-resident variant -------------------------------------------------------------
 // The three level-2 layers are only 78 KiB of fp16 hi/lo pieces: instead of re-streaming them through a ring for
 // every 64-pixel workgroup (4096 workgroups, 320 MB of L2->LDS traffic and a barrier per chunk per frame), a
-// workgroup loads them ONCE and its WAVES waves then walk PGW pixel groups each with NO further barrier: a wave's
-// activation image is private, so waves drift apart and one wave's sin()/warp phase overlaps another's MFMAs.
-template <int WAVES, int PGW>
+// workgroup loads them ONCE and its WAVES waves then walk PGW strips of PG pixel groups each with NO further
+// barrier.  Because a wave owns whole rows here, the k-slot permutation (see "Images" above) makes the C/D rows a
+// lane holds exactly its B fragment of the next layer: the activations never leave the wave's registers, LDS
+// carries weights only, and one A fragment read feeds PG pixel groups.
+template <int PG>
+THA4_DEV void put_rows(f16x8 (&xh)[kKG2][PG], f16x8 (&xl)[kKG2][PG], int pg, int b, const f32x4& v) {
+  f16x4 hi, lo;
+  split4(v, hi, lo);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xh[b >> 1][pg][(b & 1) * 4 + j] = hi[j];
+    xl[b >> 1][pg][(b & 1) * 4 + j] = lo[j];
+  }
+}
+
+// acc += W x for one resident layer: pieces [Q][NB] at wv (lane offset applied), x in registers
+template <int NB, int KG, int PG>
+THA4_DEV void mma_resident(const char* wv, const f16x8 (&xh)[KG][PG], const f16x8 (&xl)[KG][PG], f32x4 (&acc1)[NB][PG],
+                           f32x4 (&acc2)[NB][PG]) {
+  constexpr int GB = group_blocks(NB), NGB = NB / GB, T = KG * NGB;
+  f16x8 ah[2][GB], al[2][GB];
+#pragma unroll
+  for (int b = 0; b < GB; ++b) {
+    ah[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048);
+    al[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048 + 1024);
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int qq = t / NGB, bo = (t % NGB) * GB;
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc1[bo + b][pg] = mfma16h(ah[t & 1][b], xh[qq][pg], acc1[bo + b][pg]);
+    THA4_SCHED_FENCE();
+    if (t + 1 < T) {
+#pragma unroll
+      for (int b = 0; b < GB; ++b) {
+        const char* pc = wv + ((size_t)((t + 1) / NGB) * NB + ((t + 1) % NGB) * GB + b) * 2048;
+        ah[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc);
+        al[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc + 1024);
+      }
+    }
+    THA4_SCHED_FENCE();
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(ah[t & 1][b], xl[qq][pg], acc2[bo + b][pg]);
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(al[t & 1][b], xh[qq][pg], acc2[bo + b][pg]);
+    THA4_SCHED_FENCE();
+  }
+}
+
+template <int WAVES, int PGW, int PG>
 struct Level2PCfg {
   static constexpr int kHidden = kNB2 * kKG2;                         // pieces of one 96->96 layer
   static constexpr int kPieces = 2 * kHidden + kKG2;                  // + head (1 block x 3 groups)
-  static constexpr int kWeightBytes = kPieces * 2048;
-  static constexpr int kActBytes = kKG2 * 2048;
-  static constexpr int LDS = kWeightBytes + WAVES * kActBytes;
+  static constexpr int LDS = kPieces * 2048;
   static constexpr int THREADS = WAVES * 64;
-  static constexpr int PX = WAVES * PGW * 16;
-  using G = Geo16<WAVES, 1, 1, kKG2, 1>;
-  static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
+  static constexpr int PX = WAVES * PGW * PG * 16;
+  using G = Geo16<WAVES, 1, PG, kKG2, 1>;
+  static_assert((kImg * kImg) % PX == 0, "a frame must be a whole number of workgroups");
 };
 
-template <int WAVES, int PGW>
+template <int WAVES, int PGW, int PG>
 __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
-  using Cfg = Level2PCfg<WAVES, PGW>;
+  using Cfg = Level2PCfg<WAVES, PGW, PG>;
   using G = typename Cfg::G;
-  constexpr int S = kImg, PGS = S * S / 16;
+  constexpr int S = kImg, STRIPS = S * S / (16 * PG);
   THA4_DYN_LDS(smem);
   const WaveCtx w = wave_ctx<G>();
-  char* act = smem + Cfg::kWeightBytes + w.wave * Cfg::kActBytes;
   fetch_pieces<2 * Cfg::kPieces, WAVES>(reinterpret_cast<const char*>(d.w_l2), smem, w.wave, w.lane);
   __syncthreads();
   const char* w1 = smem + w.lane * 16;
@@ -514,37 +564,45 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   const int g4 = (w.lane >> 4) * 4;
 #pragma unroll 1
   for (int k = 0; k < PGW; ++k) {
-    const int pgid = (blockIdx.x * PGW + k) * WAVES + w.wave;          // the WAVES waves work on adjacent strips
-    const int n = pgid / PGS;
-    int pix0[1], X0[1], Y[1];
-    float px[1], py[1];
-    pix0[0] = (pgid % PGS) * 16;
-    X0[0] = pix0[0] % S;
-    Y[0] = pix0[0] / S;
-    px[0] = d.pos512[X0[0] + (w.lane & 15)];
-    py[0] = d.pos512[Y[0]];
-    first16_up<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
-                        d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, act, w);
+    const int strip = (blockIdx.x * PGW + k) * WAVES + w.wave;         // the WAVES waves work on adjacent strips
+    const int n = strip / STRIPS;
+    int pix0[PG], X0[PG], Y[PG];
+    float px[PG], py[PG];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      pix0[pg] = ((strip % STRIPS) * PG + pg) * 16;
+      X0[pg] = pix0[pg] % S;
+      Y[pg] = pix0[pg] / S;
+      px[pg] = d.pos512[X0[pg] + (w.lane & 15)];
+      py[pg] = d.pos512[Y[pg]];
+    }
+    f16x8 xh[kKG2][PG], xl[kKG2][PG];
+    first16_up_to<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
+                           d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py,
+                           [&](int pg, int b, const f32x4& v) { put_rows<PG>(xh, xl, pg, b, v); }, w);
     const float* bias = d.b_l2;
 #pragma unroll
     for (int layer = 0; layer < 2; ++layer) {
-      f32x4 acc1[kNB2][1], acc2[kNB2][1];
-      zero2<kNB2, 1>(acc1, acc2);
-      mma_chunk<G, kNB2, kNB2, kKG2, kNB2>(layer == 0 ? w1 : w2, act + w.lane * 16, acc1, acc2, 0);
+      f32x4 acc1[kNB2][PG], acc2[kNB2][PG];
+      zero2<kNB2, PG>(acc1, acc2);
+      mma_resident<kNB2, kKG2, PG>(layer == 0 ? w1 : w2, xh, xl, acc1, acc2);
 #pragma unroll
       for (int b = 0; b < kNB2; ++b) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + b * 16 + g4);
-        f32x4 v = acc1[b][0] + acc2[b][0] * kLoInv + bb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
-        store_block<G>(act, 0, b, w.lane, v);
+        for (int pg = 0; pg < PG; ++pg) {
+          f32x4 v = acc1[b][pg] + acc2[b][pg] * kLoInv + bb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
+          put_rows<PG>(xh, xl, pg, b, v);
+        }
       }
       bias += kNB2 * 16;
     }
-    f32x4 a1[1][1], a2[1][1];
-    zero2<1, 1>(a1, a2);
-    mma_chunk<G, 1, 1, kKG2, 1>(w3, act + w.lane * 16, a1, a2, 0);
-    warp_blend_store<1>(d, n, bias, pix0, px, py, a1, a2, w);
+    f32x4 a1[1][PG], a2[1][PG];
+    zero2<1, PG>(a1, a2);
+    mma_resident<1, kKG2, PG>(w3, xh, xl, a1, a2);
+    warp_blend_store<PG>(d, n, bias, pix0, px, py, a1, a2, w);
   }
 }
 
@@ -563,7 +621,7 @@ namespace cfg {
 #define THA4_L216_CFG 4, 1, 1, 1            // NS, MS, PG, CQ
 #endif
 #ifndef THA4_L216P_CFG
-#define THA4_L216P_CFG 8, 8                 // WAVES, pixel groups per wave (weights-resident level 2)
+#define THA4_L216P_CFG 8, 4, 2              // WAVES, strips per wave, pixel groups per strip (weights-resident level 2)
 #endif
 #ifndef THA4_L2_RESIDENT
 #define THA4_L2_RESIDENT 1                  // 1: level2_16p_kernel, 0: streamed level2_16_kernel

@@ -38,8 +38,8 @@ struct StudentDev {
   const float *pos128, *pos256, *pos512;             // affine_grid axes
   // workspace (device)
   float* pbias;   // [B][kPbStride]
-  float* z1;      // [B][kNB1][128*128][16]
-  float* z2;      // [B][kNB2][256*256][16]
+  float* z1;      // [B][kNB1][4][128*128][4]   (z_offset, siren_layout.h)
+  float* z2;      // [B][kNB2][4][256*256][4]
   float* face;    // [B][4][128][128]
   // i/o (device)
   const float* image;        // [B or 1][4][512][512]
@@ -110,7 +110,7 @@ THA4_DEV WaveCtx wave_ctx() {
   c.lane = threadIdx.x & 63;
   c.wave = uniform_i32(threadIdx.x >> 6);
   c.ns = c.wave % G::NS;
-  c.ms = c.wave / G::NS;
+  c.ms = G::MS == 1 ? 0 : c.wave / G::NS;   // compile-time 0 keeps block indices static when rows are not split
   return c;
 }
 
@@ -243,7 +243,7 @@ THA4_DEV void sine_layer(const char*& gw, const float*& bias, char* ring, int& s
   if (G::MS > 1) __syncthreads();   // the slot's other row-split wave reads these blocks next
 }
 
-// z layer: z = W act, written to global as z[n][b][pix][16] (one 1 KiB run per (block, pixel group))
+// z layer: z = W act, written to global as z[n][b][g][pix][4] (one 256 B run per (block, lane group, pixel group))
 template <class G, int NB, int KQ, int CQ>
 THA4_DEV void z_layer(const char*& gw, char* ring, int& slot, const f32x4* actv, float* zframe, int npix,
                       const int (&pix0)[G::PG], const WaveCtx& w) {
@@ -258,7 +258,7 @@ THA4_DEV void z_layer(const char*& gw, char* ring, int& slot, const f32x4* actv,
   for (int b = 0; b < NBW; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg)
-      *reinterpret_cast<f32x4*>(zframe + ((size_t)(mbase + b) * npix + pix0[pg] + p) * 16 + g4) = acc[b][pg];
+      *reinterpret_cast<f32x4*>(zframe + z_offset(mbase + b, w.lane >> 4, pix0[pg] + p, npix)) = acc[b][pg];
 }
 
 // first layer from position only: act <- sin(30 (wx x + wy y + pb))      (pose folded into pb)
@@ -308,10 +308,10 @@ THA4_DEV void first_layer_up(const float* zframe, int lowS, const float* wx, con
     float lx0, lx1, ly0, ly1;
     up2_taps(X0[pg] + p, lowS, x0, x1, lx0, lx1);
     up2_taps(Y[pg], lowS, y0, y1, ly0, ly1);
-    const float* z00 = zframe + ((size_t)y0 * lowS + x0) * 16 + g4;
-    const float* z01 = zframe + ((size_t)y0 * lowS + x1) * 16 + g4;
-    const float* z10 = zframe + ((size_t)y1 * lowS + x0) * 16 + g4;
-    const float* z11 = zframe + ((size_t)y1 * lowS + x1) * 16 + g4;
+    const float* z00 = zframe + z_offset(0, w.lane >> 4, y0 * lowS + x0, npix);
+    const float* z01 = zframe + z_offset(0, w.lane >> 4, y0 * lowS + x1, npix);
+    const float* z10 = zframe + z_offset(0, w.lane >> 4, y1 * lowS + x0, npix);
+    const float* z11 = zframe + z_offset(0, w.lane >> 4, y1 * lowS + x1, npix);
 #pragma unroll
     for (int bb = 0; bb < NBW; ++bb) {
       const int b = mbase + bb;

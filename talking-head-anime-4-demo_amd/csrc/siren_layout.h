@@ -25,6 +25,13 @@ constexpr int kFaceTop = 80;       // mode_14.py:61-63: centre (256,144) +- 64
 constexpr int kFaceLeft = 192;
 constexpr float kOmega = 30.0f;    // siren.py:17
 
+// z hand-off image between levels: z[n][block][g][pixel][4] - rows 4g..4g+3 of a 16-row block are what lane group g
+// of an MFMA C/D fragment holds, so a quarter wave (fixed g, 16 consecutive pixels) writes one 256 B run and the x2
+// upsample taps of the next level read a contiguous ~144 B span per quarter wave instead of sixteen 64 B-strided pieces.
+constexpr size_t z_offset(int block, int g, int pixel, int npix) {
+  return (((size_t)block * 4 + g) * npix + pixel) * 4;
+}
+
 // channel widths and their padding to 16-row MFMA blocks ("blocks") / 16-channel K groups ("quads")
 constexpr int kCF = 128, kNBF = 8;    // face hidden width
 constexpr int kC0 = 360, kNB0 = 24;   // body level 0 hidden width: 23 blocks, padded to 24 so two waves can split the rows

@@ -19,6 +19,8 @@
 namespace tha4 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #ifndef THA4_EMU
 // 16-byte async global -> LDS copy (global_load_lds_dwordx4).  The LDS destination is
@@ -31,6 +33,14 @@ THA4_DEV void glds16(const void* gsrc_lane, void* lds_base_uniform) {
 THA4_DEV f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_f16: A[i][k] = lane 16*(k/8)+i element k%8, B[k][j] = lane 16*(k/8)+j element k%8
+THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
+#ifdef THA4_ABLATE_MFMA   // timing ablation only (tools/sweep.py): results are wrong
+  c[0] += (float)a[0] * (float)b[0];
+  return c;
+#endif
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 THA4_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 THA4_DEV float lane_read(float v, int src_lane) { return __shfl(v, src_lane, 64); }
 #else
@@ -40,6 +50,12 @@ THA4_DEV f32x4 mfma16(float a, float b, f32x4 c) {
   emu::mfma_f32_16x16x4(a, b, r);
   f32x4 o = {r[0], r[1], r[2], r[3]};
   return o;
+}
+THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
+  float af[8], bf[8], r[4] = {c[0], c[1], c[2], c[3]};
+  for (int j = 0; j < 8; ++j) { af[j] = (float)a[j]; bf[j] = (float)b[j]; }
+  emu::mfma_f32_16x16x32(af, bf, r);
+  return f32x4{r[0], r[1], r[2], r[3]};
 }
 THA4_DEV int uniform_i32(int v) { return v; }
 THA4_DEV float lane_read(float v, int src_lane) { return emu::shfl(v, src_lane); }

@@ -1,7 +1,7 @@
 // CPU emulation harness for the full-model kernels (TEST INFRASTRUCTURE ONLY): runs conv_mfma /
 // norm_finalize / gemv / attention workgroup by workgroup on host buffers for tests/test_emu_full.py.
 #define THA4_EMU 1
-#include "full_kernels.h"
+#include "full_conv16_kernels.h"
 #include "full_layout.h"
 
 using namespace tha4;
@@ -60,8 +60,10 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   if (act_out) std::memcpy(A.data(), act_out, sizeof(int) * cout);
   std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
   const bool splitk = pg == 0;
-  const int tiles_per_class = splitk ? th * tw / 16 : (th * tw / 16) / (4 * pg);
-  if (!splitk && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
+  const bool tiled = pg >= 10;              // conv_tile_kernel<tmb, pg - 10>
+  const int tpg = pg - 10;
+  const int tiles_per_class = splitk ? th * tw / 16 : (tiled ? th * tw / (8 * tpg * 16) : (th * tw / 16) / (4 * pg));
+  if (!splitk && !tiled && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
   const int stats_tiles = tiles_per_class * nclass;
   std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
   std::vector<ChannelSegment> segs = {{0, c0}};
@@ -89,7 +91,17 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     a.act_out = act_out ? A.data() : nullptr; a.out = O.data(); a.stats = ST.data();
     a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
     a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
-    const size_t lds = splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
+    std::vector<char> P16;
+    TileGeom tg;
+    if (tiled) {
+      tg = tile_geom(g, th, tw, tpg, tmb);
+      if (!tg.ok) return -4;
+      float inv = 1.f;
+      P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb, &inv);
+      a.w16 = P16.data(); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
+      a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk;
+    }
+    const size_t lds = tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
     dim3 grid(n * tiles_per_class, mtiles);
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -100,6 +112,14 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     else emu::run_block(conv_mfma_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by), 256, lds, a);                       \
   }
         RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
+#define RUNT(TM, PGV)                                                                                                          \
+  if (tiled && tmb == TM && tpg == PGV) {                                                                                       \
+    if (in_mode == IN_DIRECT) emu::run_block(conv_tile_kernel<TM, PGV, IN_DIRECT>, grid, dim3(bx, by), kTileThreads, lds, a);    \
+    else if (in_mode == IN_UP2) emu::run_block(conv_tile_kernel<TM, PGV, IN_UP2>, grid, dim3(bx, by), kTileThreads, lds, a);     \
+    else emu::run_block(conv_tile_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by), kTileThreads, lds, a);                          \
+  }
+        RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 2) RUNT(1, 1)
+#undef RUNT
         if (splitk && tmb == 4) {
           if (in_mode == IN_DIRECT) emu::run_block(conv_splitk_kernel<4, IN_DIRECT>, grid, dim3(bx, by), 256, lds, a);
           else if (in_mode == IN_UP2) emu::run_block(conv_splitk_kernel<4, IN_UP2>, grid, dim3(bx, by), 256, lds, a);

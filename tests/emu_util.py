@@ -61,12 +61,12 @@ class EmuStudent:
 
 
 def pack_z(z, nb):
-    """[C, npix] fp64/fp32 -> the kernels' z image [nb][npix][16] (flat fp32)."""
+    """[C, npix] fp64/fp32 -> the kernels' z image [nb][4][npix][4] (flat fp32; siren_layout.h z_offset)."""
     c, npix = z.shape
     zp = np.zeros((nb * 16, npix), np.float32)
     zp[:c] = z
-    return zp.reshape(nb, 16, npix).transpose(0, 2, 1).reshape(-1)
+    return zp.reshape(nb, 4, 4, npix).transpose(0, 1, 3, 2).reshape(-1)
 
 
 def unpack_z(flat, nb, npix, c):
-    return flat.reshape(nb, npix, 16).transpose(0, 2, 1).reshape(nb * 16, npix)[:c]
+    return flat.reshape(nb, 4, npix, 4).transpose(0, 1, 3, 2).reshape(nb * 16, npix)[:c]

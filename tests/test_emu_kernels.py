@@ -61,7 +61,7 @@ def test_level0_kernel_blocks(ctx):
         px = emu.block_pixels(K_L0, b)
         got = unpack_z(emu.buf("z1"), 12, 128 * 128, 180)[:, px]
         assert np.abs(got - ref[:, px]).max() < 5e-4       # fp32 through 2x360-wide sine layers
-        pad = emu.buf("z1").reshape(12, 128 * 128, 16)[11, px, 4:]
+        pad = emu.buf("z1").reshape(12, 4, 128 * 128, 4)[11, 1:, px, :]
         assert not pad.any()                                # channels 180..191 are exact zeros
 
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Join the conv schedule dump (THA4_DUMP_SCHEDULE=1, stderr of poser creation) with a rocprofv3 kernel trace:
+per-layer time of the LAST cold frame.  usage: conv_breakdown.py <schedule.txt> <kernel_trace.csv>"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+sched = []
+for line in open(sys.argv[1]):
+    if line.startswith("conv kind="):
+        kv = dict(re.findall(r"(\w+)=([\w()x ]+?)(?= \w+=|$)", line.strip()[5:]))
+        sched.append(kv)
+launches = []
+for kv in sched:
+    for c in range(int(kv["classes"])):
+        launches.append(kv)
+rows = [r for r in csv.DictReader(open(sys.argv[2]))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+convs = [r for r in rows if "conv_mfma_kernel" in r["Kernel_Name"] or "conv_splitk_kernel" in r["Kernel_Name"] or "conv_tile_kernel" in r["Kernel_Name"]]
+n = len(launches)
+last = convs[-n:]
+print(f"{len(sched)} convs, {n} launches per cold frame, {len(convs)} conv launches in trace")
+agg = defaultdict(lambda: [0, 0.0, 0.0])
+tot = 0.0
+for kv, r in zip(launches, last):
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    taps = int(kv["taps"]) // (4 if int(kv["classes"]) == 4 else 1)
+    th, tw = map(int, kv["tile"].split("x"))
+    cin = int(kv["cin"].split("(")[0])
+    gflop = 2.0 * th * tw * cin * int(kv["cout"]) * taps / 1e9
+    key = (kv["kind"], kv["tile"], kv["mode"], cin, kv["cout"], kv["splitk"], kv["tmb"], kv["pg"], kv["wgs"])
+    agg[key][0] += 1
+    agg[key][1] += us
+    agg[key][2] += gflop
+    tot += us
+print(f"total conv time {tot / 1e3:.2f} ms")
+for key, (cnt, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"kind={key[0]} tile={key[1]:8s} mode={key[2]} cin={key[3]:4d} cout={key[4]:>4s} splitk={key[5]} tmb={key[6]} pg={key[7]} wgs={key[8]:>5s}  "
+          f"launches={cnt:3d}  total={us:8.1f} us  avg={us / cnt:7.1f} us  {gf / (us * 1e-6) / 1e3:6.1f} TFLOP/s")

@@ -17,9 +17,11 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "hwsin": ["-DTHA4_HW_SIN"],
-    "l1_ms2pg2": ["-DTHA4_L116_CFG=4,2,2,1,1"],
-    "hwsin_l1ms2": ["-DTHA4_HW_SIN", "-DTHA4_L116_CFG=4,2,2,1,1"],
+    "nosin": ["-DTHA4_ABLATE_SIN"],
+    "nozload": ["-DTHA4_ABLATE_ZLOAD"],
+    "nomfma": ["-DTHA4_ABLATE_MFMA"],
+    "nosin_nozload": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_ZLOAD"],
+    "nothing": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_ZLOAD", "-DTHA4_ABLATE_MFMA"],
 }
 
 
