@@ -10,7 +10,14 @@
 //     through a 2-slot LDS ring as fp16 hi/lo fragment pieces (pre-scaled by a power of two so small weights keep
 //     their low half out of the fp16 subnormal range), and every 32-deep k step costs three
 //     v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, 48 cycles instead of 256) into one fp32 accumulator;
-//   * the window of K group Q+1 is loaded into registers under the MFMAs of group Q.
+//   * the window of K group Q+1 is loaded into registers under the MFMAs of group Q;
+//   * small maps (16x16 .. 48x48 with 256-512 channels) do not have enough output tiles to fill 256 CUs, and a
+//     pixel-tiled grid would re-read every weight once per tile: there blockIdx.z splits the K groups instead
+//     (phase 1: every workgroup writes its fp32 partial fragments to a workspace) and a second launch of the same
+//     kernel (phase 2, one workgroup per output tile) adds the partials in split order and runs the epilogue.
+//     Every weight is read exactly once per frame.  (A single-launch "last workgroup reduces" variant was measured
+//     slower: the agent-scope release/acquire it needs writes back and invalidates the per-XCD L2s.)
+//   * tile grids need not divide the map: positions outside it are computed on zero padding and masked at the store.
 // Numerics: products are exact in fp32; dropped lo*lo terms and the rounding of the lo halves are ~2^-22 relative,
 // four times the fp32 rounding the reference itself commits per product (tests: 2e-5 abs on O(1) outputs).
 //
@@ -41,8 +48,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 
   // ---- tile decomposition -------------------------------------------------------------------
   const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (kTileWaves * PG * 16) >> twl;
-  const int tiles_x = a.tile_w >> twl;
-  const int tiles_per_frame = tiles_x * (a.tile_h / TWH);
+  const int tiles_x = (a.tile_w + TWW - 1) >> twl;
+  const int tiles_per_frame = tiles_x * ((a.tile_h + TWH - 1) / TWH);
   const int n = blockIdx.x / tiles_per_frame;
   const int tile = blockIdx.x % tiles_per_frame;
   const int tile_y0 = (tile / tiles_x) * TWH, tile_x0 = (tile % tiles_x) << twl;
@@ -57,6 +64,10 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   int cbtot = 0;
   for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
   const int NQ = (cbtot + 1) >> 1;                       // 32-channel K groups
+  const int ksplit = a.phase == 0 ? 1 : a.ksplit, ks = a.phase == 1 ? (int)blockIdx.z : 0;
+  const int q_per = (NQ + ksplit - 1) / ksplit;
+  int q_begin = ks * q_per;
+  const int q_end = min(NQ, q_begin + q_per);              // this workgroup's K groups
   const int ntc = a.ntaps / a.taps_per_chunk;            // weight chunks per K group
   const int slot_bytes = a.taps_per_chunk * TMB * 2048;
   char* win_hi = smem;
@@ -67,12 +78,14 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 
   // ---- per-lane output pixels ------------------------------------------------------------------
   int ly[PG], lx[PG], boff[PG];
+  bool inside[PG];
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) {
     const int i = (wave * PG + pg) * 16 + p;
     ly[pg] = i >> twl;
     lx[pg] = i & (TWW - 1);
     boff[pg] = ((ly[pg] * a.in_stride) * WW + lx[pg] * a.in_stride) * 16 + g * PLANE;
+    inside[pg] = tile_y0 + ly[pg] < a.tile_h && tile_x0 + lx[pg] < a.tile_w;
   }
 
   // ---- staging items of this thread (geometry is the same for every K group) --------------------
@@ -183,14 +196,18 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  fetch(0, 0);
-  load_window(0);
-  write_window();
+  int slot = 0, chunk = q_begin * ntc;
+  const int nchunks = q_end * ntc;
+  const bool reduce_phase = a.phase == 2;
+  if (reduce_phase) q_begin = q_end;                       // nothing to multiply: partials come from the workspace
+  if (q_begin < q_end) {
+    fetch(chunk, 0);
+    load_window(q_begin);
+    write_window();
+  }
   __syncthreads();
-  int slot = 0, chunk = 0;
-  const int nchunks = NQ * ntc;
-  for (int Q = 0; Q < NQ; ++Q) {
-    if (Q + 1 < NQ) load_window(Q + 1);
+  for (int Q = q_begin; Q < q_end; ++Q) {
+    if (Q + 1 < q_end) load_window(Q + 1);
     for (int tc = 0; tc < ntc; ++tc) {
       if (chunk + 1 < nchunks) fetch(chunk + 1, slot ^ 1);
       const char* wsl = ring + slot * slot_bytes + lane * 16;
@@ -219,10 +236,44 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       slot ^= 1;
       ++chunk;
     }
-    if (Q + 1 < NQ) {
+    if (Q + 1 < q_end) {
       write_window();                                      // every wave has finished reading window Q (barrier above)
       __syncthreads();
     }
+  }
+
+  // ---- split-K: phase 1 publishes the partial fragments, phase 2 adds them in split order ----------------
+  if (a.phase != 0) {
+    const int mtiles = gridDim.y;
+    const size_t frag = (size_t)kTileWaves * PG * 64;                         // f32x4 fragments per output block
+    const size_t tile_id = ((size_t)n * mtiles + mtile) * tiles_per_frame + tile;
+    const size_t ntile_ids = (size_t)a.batch * mtiles * tiles_per_frame;
+    f32x4* part = reinterpret_cast<f32x4*>(a.partial);
+    if (a.phase == 1) {
+#pragma unroll
+      for (int b = 0; b < TMB; ++b)
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg)
+          part[(((size_t)ks * ntile_ids + tile_id) * TMB + b) * frag + (size_t)(wave * PG + pg) * 64 + lane] = acc[b][pg];
+      return;
+    }
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        // up to 16 splits: all loads of a fragment in flight at once, added in split order
+        f32x4 v[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+          v[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (k2 < a.ksplit)
+            v[k2] = part[(((size_t)k2 * ntile_ids + tile_id) * TMB + b) * frag + (size_t)(wave * PG + pg) * 64 + lane];
+        }
+        f32x4 s = v[0];
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) s = s + v[k2];
+        acc[b][pg] = s;
+      }
   }
 
   // ---- epilogue: 1/scale, bias, residual, activation, store, deterministic per-tile statistics ----
@@ -237,6 +288,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     for (int j = 0; j < 4; ++j) { ssum[b][j] = 0.f; ssq[b][j] = 0.f; }
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
+      if (!inside[pg]) continue;                            // ragged tile: position outside the map
       const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
       const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
       f32x4 v = acc[b][pg] * a.w16_inv_scale + bias;

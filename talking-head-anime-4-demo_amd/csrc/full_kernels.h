@@ -63,6 +63,9 @@ struct ConvArgs {
   int win_h, win_w;      // staged input window (virtual input pixels)
   int win_dy0, win_dx0;  // window origin relative to (tile origin * in_stride)
   int taps_per_chunk;    // taps per streamed weight chunk (divides ntaps)
+  float* partial;        // split-K workspace [ksplit][batch][mtile][tile][TMB][8*PG][64] f32x4, or null
+  int ksplit;            // K splits (phase 1 grid z)
+  int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue
 };
 
 THA4_DEV float apply_act(float v, int act) {
@@ -624,8 +627,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(GemvArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // attention core (unet.py:192-202, new attention order): per (frame, head) workgroup, 256 tokens,
-// head dim 32.  qkv in C16 [n][3C/16][256][16]; out C16 [n][C/16][256][16].  One thread per query
-// token; K/V broadcast from LDS.  (0.4 GFLOP per network: VALU is adequate.)
+// head dim 32.  qkv in C16 [n][3C/16][L][16]; out C16 [n][C/16][L][16], L <= 256 a multiple of 32.  K/V of the head
+// sit in LDS; 8 lanes share a query token.  (0.4 GFLOP per network: VALU is adequate.)
 // ---------------------------------------------------------------------------------------------
 struct AttnArgs {
   const float* qkv;
@@ -636,58 +639,94 @@ struct AttnArgs {
 };
 
 constexpr int kAttnHeadDim = 32;     // 256 channels / 8 heads (mode_07.py:222-224,253-255)
+constexpr int kAttnQueries = 32;     // query tokens per workgroup
+constexpr int kAttnSlices = 8;       // key slices per query (8 consecutive lanes share a query)
+constexpr int kAttnRow = kAttnHeadDim / 4 + 1;   // f32x4 per K/V row in LDS (+1: slices 8 rows apart would share banks)
+constexpr int kAttnMaxKeys = 32;     // keys per slice held in registers: tokens <= 256
+
+// grid (heads, frames, tokens / 32), 256 threads: thread (query ql = t>>3, slice sl = t&7) scores keys sl, sl+8, ...
+// against its query, takes the slice maximum, accumulates exp-weighted values, and the 8 slices of a query are merged
+// with lane shuffles (max first, then one rescale per slice) - a fixed order.
 __global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
   THA4_DYN_LDS(smem);
-  constexpr int CH = kAttnHeadDim;
+  constexpr int CH = kAttnHeadDim, Q4 = CH / 4;
   const int L = a.tokens;
-  f32x4* ks = reinterpret_cast<f32x4*>(smem);   // [L][CH/4]
-  f32x4* vs = ks + L * (CH / 4);                // [L][CH/4]
+  f32x4* ks = reinterpret_cast<f32x4*>(smem);   // [L][kAttnRow]
+  f32x4* vs = ks + L * kAttnRow;                // [L][kAttnRow]
   const int n = blockIdx.y, h = blockIdx.x, t = threadIdx.x;
+  const int ql = t >> 3, sl = t & 7;
+  const int tq = blockIdx.z * kAttnQueries + ql;
   const int cbq = a.channels / 16;
   const float scale = 1.0f / sqrtf(sqrtf((float)CH));
   // head h owns channels [h*32, h*32+32) of q, k and v = two C16 blocks each; a token's 16 channels are contiguous
-  const float* qp = a.qkv + (((size_t)n * 3 * cbq + 2 * h) * L + t) * 16;
-  const float* kp = a.qkv + (((size_t)n * 3 * cbq + cbq + 2 * h) * L + t) * 16;
-  const float* vp = a.qkv + (((size_t)n * 3 * cbq + 2 * cbq + 2 * h) * L + t) * 16;
-  f32x4 q[CH / 4];
+  const float* qbase = a.qkv + (((size_t)n * 3 * cbq + 2 * h) * L) * 16;
+  const float* kbase = a.qkv + (((size_t)n * 3 * cbq + cbq + 2 * h) * L) * 16;
+  const float* vbase = a.qkv + (((size_t)n * 3 * cbq + 2 * cbq + 2 * h) * L) * 16;
+  for (int tok = t; tok < L; tok += 256) {
 #pragma unroll
-  for (int i = 0; i < CH / 4; ++i) {
-    const size_t off = (size_t)(i / 4) * L * 16 + (i % 4) * 4;    // block i/4, floats (i%4)*4.. within the token's 16
-    q[i] = *reinterpret_cast<const f32x4*>(qp + off) * scale;
-    ks[t * (CH / 4) + i] = *reinterpret_cast<const f32x4*>(kp + off) * scale;
-    vs[t * (CH / 4) + i] = *reinterpret_cast<const f32x4*>(vp + off);
+    for (int i = 0; i < Q4; ++i) {
+      const size_t off = (size_t)(i / 4) * L * 16 + (size_t)tok * 16 + (i % 4) * 4;   // block i/4, floats (i%4)*4.. of the token's 16
+      ks[tok * kAttnRow + i] = *reinterpret_cast<const f32x4*>(kbase + off) * scale;
+      vs[tok * kAttnRow + i] = *reinterpret_cast<const f32x4*>(vbase + off);
+    }
   }
+  f32x4 q[Q4];
+#pragma unroll
+  for (int i = 0; i < Q4; ++i)
+    q[i] = *reinterpret_cast<const f32x4*>(qbase + (size_t)(i / 4) * L * 16 + (size_t)tq * 16 + (i % 4) * 4) * scale;
   __syncthreads();
-  auto score = [&](int s) -> float {
-    float d = 0.f;
-#pragma unroll
-    for (int i = 0; i < CH / 4; ++i) {
-      const f32x4 k4 = ks[s * (CH / 4) + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d = fmaf(q[i][j], k4[j], d);
-    }
-    return d;
-  };
+  const int nk = L / kAttnSlices;               // keys of this slice (<= kAttnMaxKeys)
+  float sc[kAttnMaxKeys];
   float m = -3.0e38f;
-  for (int s = 0; s < L; ++s) m = fmaxf(m, score(s));
-  f32x4 o[CH / 4];
 #pragma unroll
-  for (int i = 0; i < CH / 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < kAttnMaxKeys; ++it) {
+    float d = -3.0e38f;
+    if (it < nk) {
+      const f32x4* kr = ks + (size_t)(sl + it * kAttnSlices) * kAttnRow;
+      d = 0.f;
+#pragma unroll
+      for (int i = 0; i < Q4; ++i) {
+        const f32x4 k4 = kr[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d = fmaf(q[i][j], k4[j], d);
+      }
+    }
+    sc[it] = d;
+    m = fmaxf(m, d);
+  }
+#pragma unroll
+  for (int x = 1; x < kAttnSlices; x <<= 1) m = fmaxf(m, lane_read(m, (t & 63) ^ x));    // row maximum over the 8 slices
+  f32x4 o[Q4];
+#pragma unroll
+  for (int i = 0; i < Q4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float den = 0.f;
-  for (int s = 0; s < L; ++s) {
-    const float e = expf(score(s) - m);
-    den += e;
 #pragma unroll
-    for (int i = 0; i < CH / 4; ++i) {
-      const f32x4 v4 = vs[s * (CH / 4) + i];
+  for (int it = 0; it < kAttnMaxKeys; ++it) {
+    if (it < nk) {
+      const float e = expf(sc[it] - m);
+      den += e;
+      const f32x4* vr = vs + (size_t)(sl + it * kAttnSlices) * kAttnRow;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[i][j] = fmaf(e, v4[j], o[i][j]);
+      for (int i = 0; i < Q4; ++i) {
+        const f32x4 v4 = vr[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[i][j] = fmaf(e, v4[j], o[i][j]);
+      }
     }
   }
-  const float inv = 1.0f / den;
-  float* op = a.out + (((size_t)n * cbq + 2 * h) * L + t) * 16;
 #pragma unroll
-  for (int i = 0; i < CH / 4; ++i) *reinterpret_cast<f32x4*>(op + (size_t)(i / 4) * L * 16 + (i % 4) * 4) = o[i] * inv;
+  for (int x = 1; x < kAttnSlices; x <<= 1) {
+    den += lane_read(den, (t & 63) ^ x);
+#pragma unroll
+    for (int i = 0; i < Q4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[i][j] += lane_read(o[i][j], (t & 63) ^ x);
+  }
+  if (sl != 0) return;
+  const float inv = 1.0f / den;
+  float* op = a.out + (((size_t)n * cbq + 2 * h) * L + tq) * 16;
+#pragma unroll
+  for (int i = 0; i < Q4; ++i) *reinterpret_cast<f32x4*>(op + (size_t)(i / 4) * L * 16 + (i % 4) * 4) = o[i] * inv;
 }
 
 }  // namespace tha4

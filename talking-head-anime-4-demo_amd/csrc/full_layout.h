@@ -148,21 +148,26 @@ inline std::vector<char> pack_conv_weight16(const float* W, int cout, int cin, i
   return P;
 }
 
-// Workgroup tiling of conv_tile_kernel<TMB, PG>: 8 waves x PG pixel groups of 16 positions.
+// Workgroup tiling of conv_tile_kernel<TMB, PG>: 8 waves x PG pixel groups of 16 positions, tile = th x 2^tw_log2
+// positions; the tile grid may overhang the map (masked), `efficiency` is the fraction of computed positions kept.
 struct TileGeom {
   bool ok = false;
-  int tw_log2 = 4, th = 0;       // workgroup tile: th x (1 << tw_log2) positions
+  int tw_log2 = 4, th = 0;
+  int tiles = 0;                 // tiles per frame (and per parity class)
+  float efficiency = 0.f;
   int win_h = 0, win_w = 0, dy0 = 0, dx0 = 0;
   int taps_per_chunk = 1;
   size_t lds = 0;
 };
-inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB) {
+inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB, int tw_log2) {
   TileGeom t;
   const int px = 8 * PG * 16;
-  t.tw_log2 = (PG >= 4 && tile_w % 32 == 0) ? 5 : 4;
-  const int tw = 1 << t.tw_log2;
+  t.tw_log2 = tw_log2;
+  const int tw = 1 << tw_log2;
   t.th = px / tw;
-  if (tile_w % tw != 0 || tile_h % t.th != 0) return t;
+  if (t.th < 1) return t;
+  t.tiles = ((tile_h + t.th - 1) / t.th) * ((tile_w + tw - 1) / tw);
+  t.efficiency = (float)(tile_h * tile_w) / (float)(t.tiles * px);
   int dy_lo = g.dy[0], dy_hi = g.dy[0], dx_lo = g.dx[0], dx_hi = g.dx[0];
   for (int i = 1; i < g.ntaps; ++i) {
     dy_lo = std::min(dy_lo, g.dy[i]); dy_hi = std::max(dy_hi, g.dy[i]);
@@ -180,6 +185,51 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   t.lds = 8 * plane + 2 * (size_t)t.taps_per_chunk * TMB * 2048 + 8 * (size_t)TMB * 16 * 2 * sizeof(float);
   t.ok = t.lds <= 160 * 1024;
   return t;
+}
+
+// Launch plan: pixel groups per wave, tile shape and K split for one convolution (all parity classes share it).
+//   want_wgs: workgroups needed to fill the chip; nq: 32-channel K groups; mtiles: output-channel tiles
+struct TilePlan {
+  bool ok = false;
+  int pg = 1, ksplit = 1;
+  TileGeom geom;
+};
+inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TMB, int mtiles, int nq, int want_wgs = 256) {
+  TilePlan best;
+  float best_eff = 0.f;
+  for (int pg : {4, 2, 1})
+    for (int twl : {5, 4, 3}) {
+      const TileGeom t = tile_geom(g, tile_h, tile_w, pg, TMB, twl);
+      if (t.ok) best_eff = std::max(best_eff, t.efficiency);
+    }
+  if (best_eff == 0.f) return best;
+  // 1) no K split: the largest tile that still gives every CU a workgroup, else the smallest tile if that at least
+  //    half-fills the chip (a K split costs ksplit x the output in partial traffic plus a second launch)
+  auto pick = [&](int pg) {
+    for (int twl : {4, 5, 3}) {
+      const TileGeom t = tile_geom(g, tile_h, tile_w, pg, TMB, twl);
+      if (t.ok && t.efficiency >= 0.9f * best_eff) { best.ok = true; best.pg = pg; best.geom = t; return true; }
+    }
+    return false;
+  };
+  for (int pg : {4, 2, 1})
+    if (pick(pg) && best.geom.tiles * mtiles >= want_wgs) return best;
+  if (pick(1) && best.geom.tiles * mtiles >= want_wgs / 2) return best;
+  if (pick(2) && best.geom.tiles * mtiles >= want_wgs / 2) return best;
+  // 2) small maps: the largest tile whose K groups can still be spread over the chip
+  best.ok = false;
+  for (int pg : {4, 2, 1})
+    if (pick(pg) && (long)best.geom.tiles * mtiles * std::min(nq, 16) >= want_wgs) break;
+  if (!best.ok) return best;
+  const int wgs = best.geom.tiles * mtiles;
+  int ksplit = 1;
+  if (wgs < want_wgs / 2) {
+    const int want = std::min(std::min(nq, 16), (want_wgs + wgs - 1) / wgs);
+    const int per = (nq + want - 1) / want;
+    ksplit = (nq + per - 1) / per;                     // every split gets at least one K group
+  }
+  best.ksplit = ksplit;
+  return best;
 }
 
 // NCHW [c][h*w] <-> C16 [cb][h*w][16] for one frame

@@ -58,6 +58,10 @@ class FullModel {
   char* dev_params = nullptr;
   char* dev_work = nullptr;
   size_t work_floats = 0;
+  // split-K scratch shared by all convolutions (they run back to back on one stream): sized while the schedule is
+  // built, placed in the workspace by finalize_scratch() before the arena is allocated (and zeroed) by the caller
+  size_t partial_floats = 0, partial_off = 0;
+  void finalize_scratch() { partial_off = alloc_work(partial_floats); }
 
   size_t add_param(const void* p, size_t bytes) {
     size_t at = (host_params.size() + 255) / 256 * 256;
@@ -174,34 +178,44 @@ class FullModel {
     std::vector<ChannelSegment> segs;
     for (auto& s : srcs) { segs.push_back({cin, s.channels}); cin += s.channels; }
     const int nb = (cout + 15) / 16;
-    const int tmb = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
-    const int mtiles = nb / tmb;
+    int tmb = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
+    int mtiles = nb / tmb;
     const int tile_px = th * tw;
     int cbtot = 0;
     for (auto& s : srcs) cbtot += (s.channels + 15) / 16;
     const int ntaps_k = kind == K_SAME3 ? 9 : kind == K_SAME1 ? 1 : kind == K_S2K4 ? 16 : 4;
-    // small maps (<= 32x32): one pixel group per workgroup, K split over its 4 waves (conv_splitk_kernel)
-    const bool splitk = tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
-    int pg = 1;
-    if (!splitk && tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
-    // maps >= 64x64: LDS-staged window + fp16 hi/lo MFMA (conv_tile_kernel); largest pixel tile that still fills the chip
+    // every k > 1 convolution: LDS-staged window + fp16 hi/lo MFMA (conv_tile_kernel); small maps split K over blockIdx.z
     bool tiled = false;
-    TileGeom tgeom;
-    if (!splitk && kind != K_SAME1 && !std::getenv("THA4_NO_TILE_CONV")) {
+    TilePlan plan;
+    const int nq = (cbtot + 1) / 2;
+    if (kind != K_SAME1 && !std::getenv("THA4_NO_TILE_CONV")) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
-      for (int cand : {4, 2, 1}) {
-        const TileGeom tg = tile_geom(g0, th, tw, cand, tmb);
-        if (!tg.ok) continue;
-        const int wgs = tile_px / (128 * cand) * mtiles;
-        if (!tiled || wgs >= 256 || cand == 1) { tiled = true; tgeom = tg; pg = cand; }
-        if (wgs >= 256) break;
+      plan = plan_tile_conv(g0, th, tw, tmb, mtiles, nq);
+      // a half-filled chip without K split: halve the output tile instead (the window is staged twice as often, but
+      // no partial-sum traffic and no second launch)
+      if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles < 200) {
+        const TilePlan p2 = plan_tile_conv(g0, th, tw, 2, mtiles * 2, nq);
+        if (p2.ok && p2.ksplit == 1 && p2.pg >= plan.pg) { plan = p2; tmb = 2; mtiles *= 2; }
       }
+      tiled = plan.ok;
+      if (std::getenv("THA4_NO_TILE_SPLITK") && plan.ksplit > 1) tiled = false;
     }
+    // fallbacks (1x1 convolutions): small maps (<= 32x32) one pixel group per workgroup with K split over its 4 waves
+    // (conv_splitk_kernel), otherwise the exact-fp32 pixel-tiled kernel (conv_mfma_kernel)
+    const bool splitk = !tiled && tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
+    int pg = 1;
+    if (tiled) pg = plan.pg;
+    else if (!splitk && tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
     if (!tiled && tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
-    const int tiles = tiled ? tile_px / (128 * pg) : splitk ? tile_px / 16 : tile_px / (64 * pg);
+    const int tiles = tiled ? plan.geom.tiles : splitk ? tile_px / 16 : tile_px / (64 * pg);
+    const int ksplit = tiled ? plan.ksplit : 1;
+    if (tiled && ksplit > 1) {
+      partial_floats = std::max(partial_floats, (size_t)ksplit * mtiles * tiles * tmb * 8 * pg * 64 * 4);
+    }
     if (std::getenv("THA4_DUMP_SCHEDULE"))
-      std::fprintf(stderr, "conv kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d\n", (int)kind, ih,
-                   iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles, (int)tiled);
+      std::fprintf(stderr, "conv kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d ksplit=%d twl=%d\n", (int)kind, ih,
+                   iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles * ksplit, (int)tiled, ksplit,
+                   tiled ? plan.geom.tw_log2 : 0);
     FTensor out = new_tensor(nb, oh, ow);
     if (want_stats) {
       out.stats_tiles = tiles * nclass;
@@ -222,7 +236,7 @@ class FullModel {
       int cq = 1;
       ConvArgs a{};
       if (tiled) {
-        const TileGeom tg = tile_geom(g, th, tw, pg, tmb);
+        const TileGeom tg = tile_geom(g, th, tw, pg, tmb, plan.geom.tw_log2);
         float inv = 1.f;
         const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb, &inv);
         w_off = add_param(p16.data(), p16.size());
@@ -263,6 +277,8 @@ class FullModel {
         }
         c.w = P(w_off);
         c.w16 = P<char>(w_off);
+        c.partial = ksplit > 1 ? Wk(partial_off) : nullptr;
+        c.ksplit = ksplit;
         c.bias = bias_off == kNone ? nullptr : P(bias_off);
         c.act_out = act_off == kNone ? nullptr : P<int>(act_off);
         c.residual = has_res ? Wk(resc.off) : nullptr;
@@ -275,7 +291,14 @@ class FullModel {
           else if (in_mode == IN_UP2) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_UP2>), grid, dim3(256), 16 * 1024, f.stream, c);
           else hipLaunchKernelGGL((conv_splitk_kernel<4, IN_POOL2>), grid, dim3(256), 16 * 1024, f.stream, c);
         } else if (tiled) {
-          dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
+          if (ksplit > 1) {
+            c.phase = 1;
+            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, ksplit), lds, f.stream);
+            c.phase = 2;
+            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, 1), lds, f.stream);
+          } else {
+            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, 1), lds, f.stream);
+          }
         } else {
           dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
         }
@@ -433,7 +456,7 @@ class FullModel {
     const int tokens = x.t.px();
     ops.push_back([=](const Frame& f) {
       AttnArgs a{Wk(qkv.off), Wk(att.off), C, 8, tokens};
-      hipLaunchKernelGGL(attention_kernel, dim3(8, f.batch), dim3(tokens), (size_t)2 * tokens * (C / 8) * sizeof(float), f.stream, a);
+      hipLaunchKernelGGL(attention_kernel, dim3(8, f.batch, tokens / kAttnQueries), dim3(256), (size_t)2 * tokens * kAttnRow * sizeof(f32x4), f.stream, a);
     });
     FTensor o = conv(ops, K_SAME1, {src_tensor(att, C)}, IN_DIRECT, ACT_NONE, get(w, p + ".conv.weight"), get(w, p + ".conv.bias").data,
                      C, true, &x.t, IN_DIRECT);
@@ -685,6 +708,7 @@ class FullModel {
       });
     }
     head_storage.clear();
+    finalize_scratch();
     return error.empty();
   }
 

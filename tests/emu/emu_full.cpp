@@ -15,7 +15,8 @@ extern "C" {
 //  returns out [n][cout][oh][ow] and stats sums [n][cout][2] (reduced over tiles on the host)
 int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, int c0, int c1, int vec1, int h, int w,
              const float* x0, const float* x1, const float* scale, const float* shift, const float* weight, int cout,
-             const float* bias, const float* residual, const int* act_out, int chunk_quads, float* out, float* stats_out) {
+             const float* bias, const float* residual, const int* act_out, int chunk_quads, float* out, float* stats_out,
+             int tw_log2, int ksplit) {
   const int cin = c0 + c1;
   const int cb0 = (c0 + 15) / 16, cb1 = (c1 + 15) / 16;
   const int vh = in_mode == IN_UP2 ? 2 * h : (in_mode == IN_POOL2 ? h / 2 : h);
@@ -62,7 +63,12 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   const bool splitk = pg == 0;
   const bool tiled = pg >= 10;              // conv_tile_kernel<tmb, pg - 10>
   const int tpg = pg - 10;
-  const int tiles_per_class = splitk ? th * tw / 16 : (tiled ? th * tw / (8 * tpg * 16) : (th * tw / 16) / (4 * pg));
+  TileGeom tg0;
+  if (tiled) {
+    tg0 = tile_geom(kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0)), th, tw, tpg, tmb, tw_log2);
+    if (!tg0.ok) return -4;
+  }
+  const int tiles_per_class = splitk ? th * tw / 16 : (tiled ? tg0.tiles : (th * tw / 16) / (4 * pg));
   if (!splitk && !tiled && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
   const int stats_tiles = tiles_per_class * nclass;
   std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
@@ -92,17 +98,24 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
     a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
     std::vector<char> P16;
+    std::vector<float> partial;
     TileGeom tg;
     if (tiled) {
-      tg = tile_geom(g, th, tw, tpg, tmb);
+      tg = tile_geom(g, th, tw, tpg, tmb, tw_log2);
       if (!tg.ok) return -4;
+      partial.assign((size_t)ksplit * n * mtiles * tg.tiles * tmb * 8 * tpg * 64 * 4, 0.f);
+      a.partial = partial.data(); a.ksplit = ksplit;
       float inv = 1.f;
       P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb, &inv);
       a.w16 = P16.data(); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
       a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk;
     }
     const size_t lds = tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
-    dim3 grid(n * tiles_per_class, mtiles);
+    const int phases = tiled && ksplit > 1 ? 2 : 1;
+    for (int ph = 0; ph < phases; ++ph) {
+    a.phase = phases == 1 ? 0 : ph + 1;
+    dim3 grid(n * tiles_per_class, mtiles, a.phase == 1 ? ksplit : 1);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
 #define RUN(TM, PGV)                                                                                               \
@@ -114,9 +127,9 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
         RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
 #define RUNT(TM, PGV)                                                                                                          \
   if (tiled && tmb == TM && tpg == PGV) {                                                                                       \
-    if (in_mode == IN_DIRECT) emu::run_block(conv_tile_kernel<TM, PGV, IN_DIRECT>, grid, dim3(bx, by), kTileThreads, lds, a);    \
-    else if (in_mode == IN_UP2) emu::run_block(conv_tile_kernel<TM, PGV, IN_UP2>, grid, dim3(bx, by), kTileThreads, lds, a);     \
-    else emu::run_block(conv_tile_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by), kTileThreads, lds, a);                          \
+    if (in_mode == IN_DIRECT) emu::run_block(conv_tile_kernel<TM, PGV, IN_DIRECT>, grid, dim3(bx, by, bz), kTileThreads, lds, a);    \
+    else if (in_mode == IN_UP2) emu::run_block(conv_tile_kernel<TM, PGV, IN_UP2>, grid, dim3(bx, by, bz), kTileThreads, lds, a);     \
+    else emu::run_block(conv_tile_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by, bz), kTileThreads, lds, a);                          \
   }
         RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 2) RUNT(1, 1)
 #undef RUNT
@@ -127,6 +140,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
         }
 #undef RUN
       }
+    }
   }
   for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * nb * opx * 16, cout, opx, out + (size_t)i * cout * opx);
   if (stats_out)
@@ -174,9 +188,11 @@ int emu_attention(int n, int channels, int heads, int tokens, const float* qkv, 
   std::vector<float> Q((size_t)n * cb3 * tokens * 16), O((size_t)n * cb * tokens * 16, 0.f);
   for (int i = 0; i < n; ++i) nchw_to_c16(qkv + (size_t)i * 3 * channels * tokens, 3 * channels, tokens, Q.data() + (size_t)i * cb3 * tokens * 16);
   AttnArgs a{Q.data(), O.data(), channels, heads, tokens};
-  const size_t lds = (size_t)2 * tokens * (channels / heads) * sizeof(float);
+  const size_t lds = (size_t)2 * tokens * kAttnRow * sizeof(f32x4);
+  const dim3 grid(heads, n, tokens / kAttnQueries);
   for (int i = 0; i < n; ++i)
-    for (int h = 0; h < heads; ++h) emu::run_block(attention_kernel, dim3(heads, n), dim3(h, i), tokens, lds, a);
+    for (int h = 0; h < heads; ++h)
+      for (unsigned z = 0; z < grid.z; ++z) emu::run_block(attention_kernel, grid, dim3(h, i, z), 256, lds, a);
   for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * cb * tokens * 16, channels, tokens, out + (size_t)i * channels * tokens);
   return 0;
 }

@@ -32,7 +32,8 @@ def torch_act(x, name):
     return {"none": lambda v: v, "relu": F.relu, "silu": F.silu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[name](x)
 
 
-def run_conv(lib, kind, k, tmb, pg, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out, chunk_quads):
+def run_conv(lib, kind, k, tmb, pg, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out, chunk_quads,
+             tw_log2=4, ksplit=1):
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     cout = weight.shape[1] if kind == 2 else weight.shape[0]
@@ -44,7 +45,7 @@ def run_conv(lib, kind, k, tmb, pg, in_mode, act_in, x0, x1, vec1, scale, shift,
     ao = None if act_out is None else np.ascontiguousarray(act_out, np.int32)
     rc = lib.emu_conv(kind, k, tmb, pg, in_mode, ACT[act_in], n, c0, c1, int(vec1), h, w, P(x0), P(x1), P(scale), P(shift),
                       P(weight), cout, P(bias), P(residual), None if ao is None else ao.ctypes.data_as(C.POINTER(C.c_int)),
-                      chunk_quads, P(out), P(stats))
+                      chunk_quads, P(out), P(stats), tw_log2, ksplit)
     assert rc == 0, rc
     return out, stats
 
@@ -103,15 +104,22 @@ CASES = [
     (0, 3, 4, 0, 2, "silu", 32, 0, False, 16, 16, 64, True, False, False, True, 1),   # split-K: avg-pool on load
     (0, 3, 2, 1, 0, "none", 4, 0, False, 24, 24, 32, True, False, False, False, 1),   # 4-channel image input, 24x24 (rows not a multiple of 16 px)
     # conv_tile_kernel (pg = 10 + PG): LDS-staged window, fp16 hi/lo split MFMA
-    (0, 3, 4, 12, 0, "relu", 40, 0, False, 16, 32, 64, True, True, False, True, 1),    # 3x3, odd quad count (phantom quad), residual
-    (0, 3, 2, 14, 0, "silu", 32, 16, False, 32, 32, 32, True, False, False, True, 1),  # PG=4 (16x32 tiles), concat of two tensors
-    (0, 3, 2, 11, 0, "relu", 16, 12, True, 16, 16, 32, False, False, False, True, 1),  # PG=1, tensor ++ broadcast pose vector
-    (1, 4, 2, 11, 0, "relu", 16, 0, False, 32, 32, 32, False, False, False, True, 1),  # 4x4 stride 2 (8x16 tiles, 18x34 window)
-    (2, 4, 2, 12, 0, "relu", 32, 0, False, 16, 16, 32, False, False, False, True, 1),  # convT 4x4 s2 (4 parity classes)
-    (0, 3, 2, 12, 1, "silu", 16, 0, False, 8, 16, 32, True, False, False, True, 1),    # nearest-up x2 on load
-    (0, 3, 2, 12, 2, "silu", 16, 0, False, 32, 32, 32, True, False, False, True, 1),   # avg-pool 2x2 on load
-    (0, 3, 1, 12, 0, "relu", 64, 0, False, 16, 16, 10, True, False, True, False, 1),   # head block: mixed sigmoid/tanh/none rows
-    (0, 3, 2, 12, 0, "none", 4, 0, False, 48, 48, 32, True, False, False, False, 1),   # 4-channel image input, 48x48 (3x3 tiles)
+    # last field for these: (log2 tile width, K split)
+    (0, 3, 4, 12, 0, "relu", 40, 0, False, 16, 32, 64, True, True, False, True, (4, 1)),    # 3x3, odd quad count (phantom quad), residual
+    (0, 3, 2, 14, 0, "silu", 32, 16, False, 32, 32, 32, True, False, False, True, (5, 1)),  # PG=4 (16x32 tiles), concat of two tensors
+    (0, 3, 2, 11, 0, "relu", 16, 12, True, 16, 16, 32, False, False, False, True, (4, 1)),  # PG=1, tensor ++ broadcast pose vector
+    (1, 4, 2, 11, 0, "relu", 16, 0, False, 32, 32, 32, False, False, False, True, (4, 1)),  # 4x4 stride 2 (8x16 tiles, 18x34 window)
+    (2, 4, 2, 12, 0, "relu", 32, 0, False, 16, 16, 32, False, False, False, True, (4, 1)),  # convT 4x4 s2 (4 parity classes)
+    (0, 3, 2, 12, 1, "silu", 16, 0, False, 8, 16, 32, True, False, False, True, (4, 1)),    # nearest-up x2 on load
+    (0, 3, 2, 12, 2, "silu", 16, 0, False, 32, 32, 32, True, False, False, True, (4, 1)),   # avg-pool 2x2 on load
+    (0, 3, 1, 12, 0, "relu", 64, 0, False, 16, 16, 10, True, False, True, False, (4, 1)),   # head block: mixed sigmoid/tanh/none rows
+    (0, 3, 2, 12, 0, "none", 4, 0, False, 48, 48, 32, True, False, False, False, (4, 1)),   # 4-channel image input, 48x48 (3x3 tiles)
+    (0, 3, 2, 12, 0, "relu", 96, 27, True, 16, 16, 64, True, True, False, True, (4, 4)),    # split-K x4 (8 K groups), pose vector, residual
+    (0, 3, 4, 12, 0, "silu", 80, 0, False, 16, 16, 64, True, False, False, True, (4, 3)),   # split-K x3 over 3 K groups (5 quads)
+    (0, 3, 2, 11, 0, "relu", 32, 0, False, 24, 24, 32, True, True, False, True, (3, 1)),    # ragged: 24x24 map in 16x8 tiles (rows 24..31 masked)
+    (0, 3, 2, 12, 0, "relu", 64, 0, False, 24, 24, 32, True, False, False, True, (5, 2)),   # ragged 8x32 tiles (cols 24..31 masked) + split-K
+    (2, 4, 2, 11, 0, "relu", 64, 0, False, 12, 12, 32, False, False, False, True, (4, 2)),  # convT on a 12x12 map: ragged + split-K, 4 classes
+    (1, 4, 2, 11, 0, "relu", 32, 0, False, 48, 48, 32, False, False, False, True, (3, 1)),  # 4x4 s2 -> 24x24 in 16x8 tiles (34x18 window)
 ]
 
 
@@ -135,7 +143,9 @@ def test_conv_kernel_matches_torch(lib, case):
     ref_shape = ref_conv(kind, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, None, act_out).shape
     residual = rng.standard_normal(ref_shape).astype(np.float32) if has_res else None
     ref = ref_conv(kind, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out)
-    out, stats = run_conv(lib, kind, k, tmb, pg, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out, chunk)
+    twl, ksplit = chunk if isinstance(chunk, tuple) else (4, 1)
+    out, stats = run_conv(lib, kind, k, tmb, pg, in_mode, act_in, x0, x1, vec1, scale, shift, weight, bias, residual, act_out,
+                          1 if isinstance(chunk, tuple) else chunk, twl, ksplit)
     assert np.abs(out - ref).max() < (3e-5 if pg >= 10 else 2e-5)
     assert np.abs(stats[..., 0] - ref.sum(axis=(2, 3))).max() < 2e-3
     assert np.abs(stats[..., 1] - (ref ** 2).sum(axis=(2, 3))).max() < 5e-3

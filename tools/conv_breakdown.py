@@ -13,7 +13,7 @@ for line in open(sys.argv[1]):
         sched.append(kv)
 launches = []
 for kv in sched:
-    for c in range(int(kv["classes"])):
+    for c in range(int(kv["classes"]) * (2 if int(kv.get("ksplit", "1")) > 1 else 1)):
         launches.append(kv)
 rows = [r for r in csv.DictReader(open(sys.argv[2]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -29,12 +29,12 @@ for kv, r in zip(launches, last):
     th, tw = map(int, kv["tile"].split("x"))
     cin = int(kv["cin"].split("(")[0])
     gflop = 2.0 * th * tw * cin * int(kv["cout"]) * taps / 1e9
-    key = (kv["kind"], kv["tile"], kv["mode"], cin, kv["cout"], kv["splitk"], kv["tmb"], kv["pg"], kv["wgs"])
+    key = (kv["kind"], kv["tile"], kv["mode"], cin, kv["cout"], kv["splitk"], kv["tmb"], kv["pg"], kv["wgs"], kv.get("ksplit", "1"))
     agg[key][0] += 1
     agg[key][1] += us
-    agg[key][2] += gflop
+    agg[key][2] += gflop / (2 if int(kv.get("ksplit", "1")) > 1 else 1)
     tot += us
 print(f"total conv time {tot / 1e3:.2f} ms")
 for key, (cnt, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"kind={key[0]} tile={key[1]:8s} mode={key[2]} cin={key[3]:4d} cout={key[4]:>4s} splitk={key[5]} tmb={key[6]} pg={key[7]} wgs={key[8]:>5s}  "
+    print(f"kind={key[0]} tile={key[1]:8s} mode={key[2]} cin={key[3]:4d} cout={key[4]:>4s} splitk={key[5]} tmb={key[6]} pg={key[7]} wgs={key[8]:>5s} ksplit={key[9]:>2s}  "
           f"launches={cnt:3d}  total={us:8.1f} us  avg={us / cnt:7.1f} us  {gf / (us * 1e-6) / 1e3:6.1f} TFLOP/s")
