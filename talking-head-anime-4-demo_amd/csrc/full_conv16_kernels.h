@@ -265,9 +265,11 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         f32x4 v[16];
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
-          v[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (k2 < a.ksplit)
-            v[k2] = part[(((size_t)k2 * ntile_ids + tile_id) * TMB + b) * frag + (size_t)(wave * PG + pg) * 64 + lane];
+          // branch-free: splits past the last one re-read it and are zeroed by a select, so no load waits on a branch
+          const int kc = min(k2, a.ksplit - 1);
+          const f32x4 ld = part[(((size_t)kc * ntile_ids + tile_id) * TMB + b) * frag + (size_t)(wave * PG + pg) * 64 + lane];
+          const float keep = k2 < a.ksplit ? 1.0f : 0.0f;
+          v[k2] = ld * keep;
         }
         f32x4 s = v[0];
 #pragma unroll

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -196,6 +197,7 @@ struct TilePlan {
 };
 inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TMB, int mtiles, int nq, int want_wgs = 256) {
   TilePlan best;
+  const int kmax = std::getenv("THA4_KSPLIT_MAX") ? std::atoi(std::getenv("THA4_KSPLIT_MAX")) : 16;   // tuning aid
   float best_eff = 0.f;
   for (int pg : {4, 2, 1})
     for (int twl : {5, 4, 3}) {
@@ -219,12 +221,12 @@ inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TM
   // 2) small maps: the largest tile whose K groups can still be spread over the chip
   best.ok = false;
   for (int pg : {4, 2, 1})
-    if (pick(pg) && (long)best.geom.tiles * mtiles * std::min(nq, 16) >= want_wgs) break;
+    if (pick(pg) && (long)best.geom.tiles * mtiles * std::min(nq, kmax) >= want_wgs) break;
   if (!best.ok) return best;
   const int wgs = best.geom.tiles * mtiles;
   int ksplit = 1;
   if (wgs < want_wgs / 2) {
-    const int want = std::min(std::min(nq, 16), (want_wgs + wgs - 1) / wgs);
+    const int want = std::min(std::min(nq, kmax), (want_wgs + wgs - 1) / wgs);
     const int per = (nq + want - 1) / want;
     ksplit = (nq + per - 1) / per;                     // every split gets at least one K group
   }

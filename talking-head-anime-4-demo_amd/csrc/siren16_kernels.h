@@ -621,7 +621,10 @@ namespace cfg {
 #define THA4_L216_CFG 4, 1, 1, 1            // NS, MS, PG, CQ
 #endif
 #ifndef THA4_L216P_CFG
-#define THA4_L216P_CFG 8, 4, 2              // WAVES, strips per wave, pixel groups per strip (weights-resident level 2)
+// WAVES, strips per wave, pixel groups per strip (weights-resident level 2).  8,4,2 (one A fragment feeding two pixel
+// groups) is 2.5 % faster but its 256-VGPR build spills and produced wrong, run-to-run varying pixels on the device
+// while passing the emulator - not shipped until that is understood; 8,8,1 is parity-clean.
+#define THA4_L216P_CFG 8, 8, 1
 #endif
 #ifndef THA4_L2_RESIDENT
 #define THA4_L2_RESIDENT 1                  // 1: level2_16p_kernel, 0: streamed level2_16_kernel

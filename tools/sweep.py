@@ -17,11 +17,8 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "nosin": ["-DTHA4_ABLATE_SIN"],
-    "nozload": ["-DTHA4_ABLATE_ZLOAD"],
-    "nomfma": ["-DTHA4_ABLATE_MFMA"],
-    "nosin_nozload": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_ZLOAD"],
-    "nothing": ["-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_ZLOAD", "-DTHA4_ABLATE_MFMA"],
+    "l2stream": ["-DTHA4_L2_RESIDENT=0"],
+    "p881": ["-DTHA4_L216P_CFG=8,8,1"],
 }
 
 
@@ -56,7 +53,7 @@ def run(steps):
         if "--parity" in sys.argv:
             r2 = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_student_gpu.py"), "-x", "-q", "-k",
                                  "output0_parity or all_six", "-s"], capture_output=True, text=True, env=env, timeout=600)
-            print("   parity:", [l for l in r2.stdout.splitlines() if "passed" in l or "failed" in l or "PARITY" in l][-3:], flush=True)
+            print("   parity:", [l for l in r2.stdout.splitlines() if "passed" in l or "failed" in l or "PARITY" in l][-6:], flush=True)
     return rows
 
 
