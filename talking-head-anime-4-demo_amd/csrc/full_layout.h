@@ -181,7 +181,7 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   if (npx * 4 > 5 * 512) return t;                     // kTileMaxItems staging items per thread
   t.taps_per_chunk = 1;
   for (int d = 1; d <= g.ntaps; ++d)
-    if (g.ntaps % d == 0 && d * TMB * 2048 <= 32 * 1024) t.taps_per_chunk = d;
+    if (g.ntaps % d == 0 && d <= 4 && d * TMB * 2048 <= 32 * 1024) t.taps_per_chunk = d;
   const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
   t.lds = 8 * plane + 2 * (size_t)t.taps_per_chunk * TMB * 2048 + 8 * (size_t)TMB * 16 * 2 * sizeof(float);
   t.ok = t.lds <= 160 * 1024;

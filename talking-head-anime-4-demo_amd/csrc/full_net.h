@@ -188,8 +188,8 @@ class FullModel {
     bool tiled = false;
     TilePlan plan;
     const int nq = (cbtot + 1) / 2;
-    if (kind != K_SAME1 && !std::getenv("THA4_NO_TILE_CONV")) {
-      const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
+    if ((kind != K_SAME1 || std::getenv("THA4_TILE_1X1")) && !std::getenv("THA4_NO_TILE_CONV")) {
+      const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
       plan = plan_tile_conv(g0, th, tw, tmb, mtiles, nq);
       // a half-filled chip without K split: halve the output tile instead (the window is staged twice as often, but
       // no partial-sum traffic and no second launch)

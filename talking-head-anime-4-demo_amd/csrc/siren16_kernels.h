@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   const int g4 = (w.lane >> 4) * 4;
 #pragma unroll 1
   for (int k = 0; k < PGW; ++k) {
-    const int strip = (blockIdx.x * PGW + k) * WAVES + w.wave;         // the WAVES waves work on adjacent strips
+    const int strip = (xcd_tile(blockIdx.x, gridDim.x) * PGW + k) * WAVES + w.wave;   // the WAVES waves work on adjacent strips
     const int n = strip / STRIPS;
     int pix0[PG], X0[PG], Y[PG];
     float px[PG], py[PG];

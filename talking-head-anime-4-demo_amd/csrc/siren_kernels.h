@@ -334,13 +334,21 @@ THA4_DEV void first_layer_up(const float* zframe, int lowS, const float* wx, con
   }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Remapped, XCD k works on the k-th contiguous
+// eighth of the tile sequence, so vertically neighbouring strips - which share the rows of the x2-upsample taps -
+// share an L2 instead of each fetching them from HBM (level 2: FETCH_SIZE 67 MB -> see profiles/).
+THA4_DEV int xcd_tile(int block, int nblocks) {
+  constexpr int kXcd = 8;
+  return nblocks % kXcd == 0 ? (block % kXcd) * (nblocks / kXcd) + block / kXcd : block;
+}
+
 // pixel groups of this wave's slot: global id (over the batch) -> frame, strip origin, positions
 template <class G, int S>
 THA4_DEV int slot_pixels(const WaveCtx& w, const float* axis, int (&pix0)[G::PG], int (&X0)[G::PG], int (&Y)[G::PG],
                          float (&px)[G::PG], float (&py)[G::PG]) {
   constexpr int PGS = S * S / 16;
   static_assert(PGS % (G::NS * G::PG) == 0, "a workgroup must not straddle frames");
-  const int pg_first = (blockIdx.x * G::NS + w.ns) * G::PG;
+  const int pg_first = (xcd_tile(blockIdx.x, gridDim.x) * G::NS + w.ns) * G::PG;
 #pragma unroll
   for (int pg = 0; pg < G::PG; ++pg) {
     pix0[pg] = ((pg_first + pg) % PGS) * 16;

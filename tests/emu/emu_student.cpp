@@ -162,7 +162,7 @@ void emu_student_block_pixels_gen(int kernel, int block, int gen, int* first, in
              : (THA4_L2_RESIDENT ? v2::cfg::L2P::PX : v2::cfg::L2G::PX);
   else
     *count = kernel == 1 ? cfg::FaceG::PX : kernel == 2 ? cfg::L0G::PX : kernel == 3 ? cfg::L1G::PX : cfg::L2G::PX;
-  *first = block * (*count);
+  *first = xcd_tile(block, emu_student_grid_gen(kernel, gen)) * (*count);
 }
 void emu_student_block_pixels(int kernel, int block, int* first, int* count) { emu_student_block_pixels_gen(kernel, block, 1, first, count); }
 

@@ -46,6 +46,13 @@ class EmuStudent:
     def run(self, kernel, first, count=1):
         assert self.lib.emu_student_run(self.h, kernel, first, count) == 0
 
+    def block_of_tile(self, kernel, tile):
+        """Workgroup id that computes the tile-th run of pixels (inverse of the kernels' XCD-aware remap xcd_tile)."""
+        n = self.grid(kernel)
+        if kernel == 0 or n % 8:
+            return tile
+        return (tile % (n // 8)) * 8 + tile // (n // 8)
+
     def block_pixels(self, kernel, block):
         f, c = C.c_int(), C.c_int()
         self.lib.emu_student_block_pixels_gen(kernel, block, self.gen, C.byref(f), C.byref(c))

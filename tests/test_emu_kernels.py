@@ -56,7 +56,7 @@ def test_level0_kernel_blocks(ctx):
     emu, it, _ = ctx
     emu.run(K_POSEBIAS, 0, emu.grid(K_POSEBIAS))
     ref = it["z1"].reshape(180, -1)
-    for b in (0, 77, emu.grid(K_L0) - 1):
+    for b in (emu.block_of_tile(K_L0, t) for t in (0, 77, emu.grid(K_L0) - 1)):
         emu.run(K_L0, b)
         px = emu.block_pixels(K_L0, b)
         got = unpack_z(emu.buf("z1"), 12, 128 * 128, 180)[:, px]
@@ -70,7 +70,7 @@ def test_level1_kernel_blocks(ctx):
     emu.run(K_POSEBIAS, 0, emu.grid(K_POSEBIAS))
     emu.buf("z1")[:] = pack_z(it["z1"].reshape(180, -1), 12)
     ref = it["z2"].reshape(90, -1)
-    for b in (0, 1, 300, emu.grid(K_L1) - 1):               # 0/1: image corners (clamped taps)
+    for b in (emu.block_of_tile(K_L1, t) for t in (0, 1, 300, emu.grid(K_L1) - 1)):   # 0/1: image corners (clamped taps)
         emu.run(K_L1, b)
         px = emu.block_pixels(K_L1, b)
         got = unpack_z(emu.buf("z2"), 6, 256 * 256, 90)[:, px]
@@ -88,7 +88,7 @@ def test_level2_kernel_blocks(ctx, golden_weights, golden_io):
     # 288/289: row 144 (inside the pasted face rows), 160..: row 80 = first face row
     g = emu.grid(K_L2)
     # rows 0, 80 (first face row), 144 (inside the pasted face), 200 and the last one
-    for b in sorted({0, 1, g * 80 // 512, g * 144 // 512, g * 144 // 512 + 1, g * 200 // 512, g - 1}):
+    for b in (emu.block_of_tile(K_L2, t) for t in sorted({0, 1, g * 80 // 512, g * 144 // 512, g * 144 // 512 + 1, g * 200 // 512, g - 1})):
         emu.run(K_L2, b)
         px = emu.block_pixels(K_L2, b)
         for name, k, c in (("out_blended", 0, 4), ("out_alpha", 1, 1), ("out_color", 2, 4), ("out_warped", 3, 4),

@@ -14,7 +14,7 @@ def main():
             dur = defaultdict(list)
             seen = set()
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]
+                k = r["Kernel_Name"].split("(")[0].split("::")[-1]
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 if r["Dispatch_Id"] not in seen:
                     seen.add(r["Dispatch_Id"])

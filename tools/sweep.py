@@ -17,8 +17,7 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "l2stream": ["-DTHA4_L2_RESIDENT=0"],
-    "p881": ["-DTHA4_L216P_CFG=8,8,1"],
+    "noslp": ["-fno-slp-vectorize"],
 }
 
 

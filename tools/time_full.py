@@ -15,8 +15,9 @@ image = torch.from_numpy(io["image_f32"]).to(dev)
 poses = torch.from_numpy(io["poses"]).to(dev)
 for i in range(3): p.pose(image, poses[i % 8])
 torch.cuda.synchronize()
+NFRAMES = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 20
 for name, changed in (("steady", False), ("cold", True)):
-    n = 20
+    n = NFRAMES
     t0 = time.perf_counter()
     for i in range(n): p.pose(image, poses[i % 8], image_changed=changed)
     torch.cuda.synchronize()
