@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 summaries collected under gpurun_out/ (tools/profile_student.sh, profile_traffic.sh,
+pmc_full.sh, breakdown_full.sh) into the tracked files under profiles/.  usage: make_profile_md.py <round tag>"""
+import csv
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def stats_table(path, top=40):
+    rows = list(csv.DictReader(open(path)))
+    out = ["| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+    for r in rows[:top]:
+        out.append(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | {r['Percentage']} |")
+    return "\n".join(out)
+
+
+def read(path):
+    return open(path).read() if os.path.exists(path) else "(not collected)\n"
+
+
+def student():
+    shutil.copy(os.path.join(G, "ps_kernel_stats.csv"), os.path.join(P, f"{tag}_student_b1_kernel_stats.csv"))
+    md = [f"# Round 1 - student path, batch 1 stream (`bench.py --steps 200 --warmup 50 --full-frames 0`), MI355X",
+          "Source: `tools/profile_student.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) and",
+          "`tools/profile_traffic.sh` (FETCH_SIZE and WRITE_SIZE each in its own pass: together they abort rocprofv3 on this image).",
+          "Kernels: generation 2 (fp16 hi/lo split MFMA), weights-resident level 2, XCD-aware tile order.", "",
+          f"## rocprofv3 --kernel-trace --stats (full CSV: {tag}_student_b1_kernel_stats.csv)", stats_table(os.path.join(G, "ps_kernel_stats.csv")), "",
+          "## PMC passes (per-launch averages summed over the chip; SQ_* cycle counters count quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES)",
+          "```", read(os.path.join(G, "ps_pmc_summary.txt")).strip(), "```", "",
+          "## HBM-side traffic (FETCH_SIZE / WRITE_SIZE in KiB per launch; reads x2 for wide streams per MI355X_MICROARCH.md)",
+          "```", read(os.path.join(G, "pt_summary.txt")).strip(), "```", "",
+          read(os.path.join(P, f"{tag}_student_b1_reading.md"))]
+    open(os.path.join(P, f"{tag}_student_b1_profile.md"), "w").write("\n".join(md))
+
+
+def full():
+    shutil.copy(os.path.join(G, "pf_kernel_stats.csv"), os.path.join(P, f"{tag}_full_b1_kernel_stats.csv"))
+    md = [f"# Round 1 - full THA4 model (mode_07), batch 1, MI355X",
+          "Source: `tools/profile_traffic.sh` / `tools/profile_full.sh` (`rocprofv3 --kernel-trace --stats -- python tools/time_full.py`:",
+          "3 warm-up + 20 steady + 20 cold frames = 43 frames, 21 of them run the eyebrow decomposer), `tools/pmc_full.sh` (PMC, 9 frames),",
+          "`tools/breakdown_full.sh` (per-layer join of the schedule dump with the kernel trace).  Synthetic seeded weights.", "",
+          "Un-profiled wall clock of the same script:", "```", read(os.path.join(G, "pf_time.log")).strip(), "```", "",
+          f"## rocprofv3 --kernel-trace --stats (full CSV: {tag}_full_b1_kernel_stats.csv)", stats_table(os.path.join(G, "pf_kernel_stats.csv")), "",
+          "## Per-layer breakdown of one cold frame (largest first; TFLOP/s = as-written FLOPs of the layer / its launches)",
+          "```", "\n".join(read(os.path.join(G, "bd_report.txt")).splitlines()[:60]), "```", "",
+          "## PMC passes (per-launch averages summed over the chip)", "```",
+          "\n".join(l for l in read(os.path.join(G, "pmcfull_summary.txt")).splitlines() if l.startswith("==") or "conv_" in l or "norm_" in l or "attention" in l),
+          "```", "", read(os.path.join(P, f"{tag}_full_b1_reading.md"))]
+    open(os.path.join(P, f"{tag}_full_b1_profile.md"), "w").write("\n".join(md))
+
+
+if __name__ == "__main__":
+    student()
+    full()
