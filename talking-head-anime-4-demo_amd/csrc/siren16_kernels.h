@@ -1,27 +1,33 @@
 // Second-generation student kernels: the SIREN contractions run on v_mfma_f32_16x16x32_f16 with BOTH
-// operands split into fp16 hi + scaled fp16 lo halves (x = hi + lo/2048, 22 significant bits):
-//     W x  ~=  W_hi x_hi  +  (W_hi x_lo + W_lo x_hi) / 2048          (3 MFMAs, fp32 accumulate)
+// operands split into fp16 hi + fp16 lo halves (v = hi + lo, 22 significant bits):
+//     W x  ~=  W_hi x_hi  +  W_hi x_lo  +  W_lo x_hi            (3 MFMAs into ONE fp32 accumulator)
 // fp16 products are exact in the fp32 accumulator; what is dropped is the lo*lo term (2^-22 relative) and the
 // rounding of the lo halves (2^-22), i.e. about two bits less than an exact-fp32 product.  End to end the posed
-// frame moves by < 3e-4 against the exact-fp32 kernels and sits at the SAME distance from the fp64 reference
-// (1.5e-4, tests/test_split_precision.py simulates the scheme in numpy; GPU parity gates on 1e-3 as before) -
-// single-pass fp16/bf16 weights would be off by 0.25 / 1.6.  Per 32-channel K group the matrix
-// pipe spends 3 x 16 cycles instead of 8 x 32 (v_mfma_f32_16x16x4_f32): 5.3x fewer MFMA cycles, which moves the
-// bottleneck to the VALU (sin + split) and LDS; everything else (fused level chains, LDS-resident activations,
-// streamed fragment-linear weights, z hand-off, warp epilogue) is the design of siren_kernels.h.
+// frame moves by < 6e-4 against the exact-fp32 kernels and sits at the SAME distance from the fp64 reference
+// (1.5e-4 in a numpy simulation of the whole student; GPU parity gates on 1e-3 as before) - single-pass fp16/bf16
+// weights would be off by 0.25 / 1.6.  Per 32-channel K group the matrix pipe spends 3 x 16 cycles
+// instead of 8 x 32 (v_mfma_f32_16x16x4_f32): 5.3x fewer MFMA cycles, which moves the bound to the VALU - and VALU
+// work does NOT hide under MFMAs on this chip (tools/microbench/valu_rate.hip) - so everything per-value is trimmed:
+//   * weights are packed as W' = c S W with c = 30 for sine layers (and for the z hand-off layers, whose consumer is a
+//     sine) and S a per-layer power of two that lifts the lo halves of small weights out of the fp16 subnormal range;
+//     the epilogue is ONE fma  u = acc / S + 30 b  and sin(u) needs no 30x multiply;
+//   * activations are in [-1, 1]: their lo halves are stored unscaled (abs error <= 2^-25, MFMA keeps fp16
+//     subnormals), so the split is cvt + one mixed-precision fma per value and one accumulator serves all 3 MFMAs;
+//   * sin(u): k = rint(u/pi) by the 1.5*2^23 magic add (its low mantissa bit is the parity of k), 2-term Cody-Waite,
+//     degree-9 odd polynomial: 12 VALU ops instead of 15.
+// Everything else (fused level chains, streamed fragment-linear weights, z hand-off, warp epilogue) is the design of
+// siren_kernels.h.
 //
 // Images.  K group Q = 32 channels = output blocks 2Q, 2Q+1 of the producing layer.  k-slot (g, j) of lane group
 // g = lane>>4, j = 0..7 is channel 32Q + 16(j>>2) + 4g + (j&3), so the 4 rows a lane holds of block 2Q (j<4) and
 // of block 2Q+1 (j>=4) ARE its B fragment for the next layer (C/D layout: row 4g+r, col lane&15).
-//   weights     piece (Q, b) = 2 KiB: [hi: lane x 8 halves | lo: lane x 8 halves], W[16b+(lane&15)][k-slot channel]
+//   weights     piece (Q, b) = 2 KiB: [hi: lane x 8 halves | lo: lane x 8 halves], W'[16b+(lane&15)][k-slot channel]
 //   activations per pixel group and K group: 2 KiB: [hi: lane x 8 halves | lo: lane x 8 halves]
 #pragma once
 #include "siren_kernels.h"
 
 namespace tha4 {
 namespace v2 {
-
-constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
 // ---- host/device shared layout helpers ---------------------------------------------------------
 // order of the pieces of one K group in the weight stream when a chunk is 1/HB of the group's blocks and MS waves
@@ -36,12 +42,12 @@ constexpr int piece_block(int NB, int MS, int HB, int idx) {   // inverse: globa
   return (r / per) * NBW + h * per + (r % per);
 }
 
-// split 4 fp32 values into fp16 hi / scaled lo
+// split 4 fp32 values (|v| <= 1: sines) into fp16 hi + fp16 lo, v = hi + lo
 THA4_DEV void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     hi[j] = (_Float16)v[j];
-    lo[j] = (_Float16)((v[j] - (float)hi[j]) * kLoScale);
+    lo[j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[j], v[j]);     // one v_fma_mix: (f16 -> f32) * -1 + v, rounded to f16
   }
 }
 
@@ -76,7 +82,7 @@ THA4_DEV void fetch2k(const char* g, char* l, int wave, int lane) {   // PIECES 
 // activations [pg][group] at av), accumulating into acc[bo0 + ...].  Software pipelined: the next block group's
 // fragments are read from LDS under the last two thirds of the current group's MFMAs.
 template <class G, int ROW, int BPC, int CQ, int NBW>
-THA4_DEV void mma_chunk(const char* wv, const char* av, f32x4 (&acc1)[NBW][G::PG], f32x4 (&acc2)[NBW][G::PG], int bo0) {
+THA4_DEV void mma_chunk(const char* wv, const char* av, f32x4 (&acc)[NBW][G::PG], int bo0) {
   constexpr int PG = G::PG;
   constexpr int GB = group_blocks(BPC), NGB = BPC / GB, T = CQ * NGB;
   f16x8 ah[2][GB], al[2][GB], bh[2][PG], bl[2][PG];
@@ -97,7 +103,7 @@ THA4_DEV void mma_chunk(const char* wv, const char* av, f32x4 (&acc1)[NBW][G::PG
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc1[bo + b][pg] = mfma16h(ah[t & 1][b], bh[qq & 1][pg], acc1[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], bh[qq & 1][pg], acc[bo + b][pg]);
     THA4_SCHED_FENCE();
     if (t + 1 < T) {
       const int nq = (t + 1) / NGB, ng = (t + 1) % NGB;
@@ -119,21 +125,21 @@ THA4_DEV void mma_chunk(const char* wv, const char* av, f32x4 (&acc1)[NBW][G::PG
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(ah[t & 1][b], bl[qq & 1][pg], acc2[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], bl[qq & 1][pg], acc[bo + b][pg]);
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(al[t & 1][b], bh[qq & 1][pg], acc2[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(al[t & 1][b], bh[qq & 1][pg], acc[bo + b][pg]);
     THA4_SCHED_FENCE();
   }
 }
 
 // One linear layer, this wave's share (NBW of the NB output blocks) for its PG pixel groups.
 //   KG K groups of 32 channels; chunk = CQ whole groups (HB == 1) or one 1/HB slice of a group's blocks (HB > 1, CQ == 1)
-//   acc1 += Whi Xhi;  acc2 += Whi Xlo + Wlo Xhi;   result = acc1 + acc2/2048
+//   acc += W'hi Xhi + W'hi Xlo + W'lo Xhi;   W x = acc / S
 template <class G, int NB, int NBW, int KG, int HB, int CQ, int NEXT_PIECES>
-THA4_DEV void gemm16_stream(const char*& gw, char* ring, int& slot, const char* act, f32x4 (&acc1)[NBW][G::PG],
-                            f32x4 (&acc2)[NBW][G::PG], const WaveCtx& w, bool active) {
+THA4_DEV void gemm16_stream(const char*& gw, char* ring, int& slot, const char* act, f32x4 (&acc)[NBW][G::PG], const WaveCtx& w,
+                            bool active) {
   static_assert(HB == 1 || CQ == 1, "block slicing and multi-group chunks are exclusive");
   static_assert(NBW % HB == 0 && KG % CQ == 0, "bad chunking");
   constexpr int PG = G::PG;
@@ -157,7 +163,7 @@ THA4_DEV void gemm16_stream(const char*& gw, char* ring, int& slot, const char* 
       // this wave's pieces inside the slot: slice-local index = ms*BPC + i  (see piece_index)
       const char* wv = ring + slot * G::SLOT + (size_t)(w.ms * BPC) * 2048 + w.lane * 16;
       const char* av = act + (size_t)(cg * CQ) * 2048 + w.lane * 16;
-      mma_chunk<G, NB / HB, BPC, CQ, NBW>(wv, av, acc1, acc2, h * BPC);
+      mma_chunk<G, NB / HB, BPC, CQ, NBW>(wv, av, acc, h * BPC);
     }
 #ifndef THA4_ABLATE_BARRIER
     __syncthreads();
@@ -168,30 +174,25 @@ THA4_DEV void gemm16_stream(const char*& gw, char* ring, int& slot, const char* 
   gw += (size_t)NC * CHUNK;
 }
 
-template <int NBW, int PG>
-THA4_DEV void zero2(f32x4 (&a)[NBW][PG], f32x4 (&b)[NBW][PG]) {
-  zero_acc<NBW, PG>(a);
-  zero_acc<NBW, PG>(b);
-}
-
-// sine hidden layer: act <- split(sin(30 (W act + b)))
+// sine hidden layer: act <- split(sin(acc / S + 30 b))          (30 and S are folded into the packed weights)
 template <class G, int NB, int KG, int HB, int CQ, int NEXT_PIECES>
-THA4_DEV void sine16_layer(const char*& gw, const float*& bias, char* ring, int& slot, char* act, const WaveCtx& w) {
+THA4_DEV void sine16_layer(const char*& gw, const float*& bias, const float*& scl, char* ring, int& slot, char* act, const WaveCtx& w) {
   static_assert(NB % G::MS == 0, "row split must divide the block count");
   constexpr int NBW = NB / G::MS, PG = G::PG;
   const int mbase = w.ms * NBW;
-  f32x4 acc1[NBW][PG], acc2[NBW][PG];
-  zero2<NBW, PG>(acc1, acc2);
-  gemm16_stream<G, NB, NBW, KG, HB, CQ, NEXT_PIECES>(gw, ring, slot, act, acc1, acc2, w, true);
+  f32x4 acc[NBW][PG];
+  zero_acc<NBW, PG>(acc);
+  gemm16_stream<G, NB, NBW, KG, HB, CQ, NEXT_PIECES>(gw, ring, slot, act, acc, w, true);
   const int g4 = (w.lane >> 4) * 4;
+  const float inv = *scl++;
 #pragma unroll
   for (int b = 0; b < NBW; ++b) {
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + (mbase + b) * 16 + g4);
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
-      f32x4 v = acc1[b][pg] + acc2[b][pg] * kLoInv + bb;
+      f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
+      for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(acc[b][pg][j], inv, bb[j]));
       store_block<G>(act, pg, mbase + b, w.lane, v);
     }
   }
@@ -199,21 +200,22 @@ THA4_DEV void sine16_layer(const char*& gw, const float*& bias, char* ring, int&
   if (G::MS > 1) __syncthreads();
 }
 
-// z layer: z = W act (fp32) -> global z[n][b][pix][16]
+// z layer: z = 30 W act (fp32) -> global z[n][b][g][pix][4]; the consumer is the first (sine) layer of the next level
 template <class G, int NB, int KG, int HB, int CQ>
-THA4_DEV void z16_layer(const char*& gw, char* ring, int& slot, const char* act, float* zframe, int npix,
+THA4_DEV void z16_layer(const char*& gw, const float*& scl, char* ring, int& slot, const char* act, float* zframe, int npix,
                         const int (&pix0)[G::PG], const WaveCtx& w) {
   constexpr int NBW = NB / G::MS, PG = G::PG;
   const int mbase = w.ms * NBW;
-  f32x4 acc1[NBW][PG], acc2[NBW][PG];
-  zero2<NBW, PG>(acc1, acc2);
-  gemm16_stream<G, NB, NBW, KG, HB, CQ, 0>(gw, ring, slot, act, acc1, acc2, w, true);
-  const int p = w.lane & 15, g4 = (w.lane >> 4) * 4;
+  f32x4 acc[NBW][PG];
+  zero_acc<NBW, PG>(acc);
+  gemm16_stream<G, NB, NBW, KG, HB, CQ, 0>(gw, ring, slot, act, acc, w, true);
+  const int p = w.lane & 15;
+  const float inv = *scl++;
 #pragma unroll
   for (int b = 0; b < NBW; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg)
-      *reinterpret_cast<f32x4*>(zframe + z_offset(mbase + b, w.lane >> 4, pix0[pg] + p, npix)) = acc1[b][pg] + acc2[b][pg] * kLoInv;
+      *reinterpret_cast<f32x4*>(zframe + z_offset(mbase + b, w.lane >> 4, pix0[pg] + p, npix)) = acc[b][pg] * inv;
 }
 
 template <class G, int NB>
@@ -231,7 +233,7 @@ THA4_DEV void first16_pos(const float* wx, const float* wy, const float* pb, con
     for (int pg = 0; pg < PG; ++pg) {
       f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = sin_omega(fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));
+      for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));     // tables carry the 30x
       store_block<G>(act, pg, b, w.lane, v);
     }
   }
@@ -274,7 +276,7 @@ THA4_DEV void first16_up_to(const float* zframe, int lowS, const float* wx, cons
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float up = ly0 * (lx0 * a[j] + lx1 * bq[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
-        v[j] = sin_omega(up + fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));
+        v[j] = sin_u(up + fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));                           // z and tables carry the 30x
       }
       sink(pg, b, v);
     }
@@ -316,24 +318,26 @@ __global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
   const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_face);
   const float* bias = d.b_face;
+  const float* scl = d.s_face;
   int slot = 0;
   fetch2k<CQ * kNBF, G::WAVES>(gw, ring, w.wave, w.lane);
   first16_pos<G, kNBF>(d.wx[0], d.wy[0], d.pbias + (size_t)n * kPbStride + kPbFace, px, py, act, w);
   __syncthreads();
 #pragma unroll 1
-  for (int l = 0; l < 6; ++l) sine16_layer<G, kNBF, kKGF, 1, CQ, CQ * kNBF>(gw, bias, ring, slot, act, w);
-  sine16_layer<G, kNBF, kKGF, 1, CQ, kKGF>(gw, bias, ring, slot, act, w);
-  f32x4 a1[1][PG], a2[1][PG];
-  zero2<1, PG>(a1, a2);
+  for (int l = 0; l < 6; ++l) sine16_layer<G, kNBF, kKGF, 1, CQ, CQ * kNBF>(gw, bias, scl, ring, slot, act, w);
+  sine16_layer<G, kNBF, kKGF, 1, CQ, kKGF>(gw, bias, scl, ring, slot, act, w);
+  f32x4 a1[1][PG];
+  zero_acc<1, PG>(a1);
   // head: ONE block; only row-split 0 computes, its piece is the first of every group (MS folded: NB = 1)
-  gemm16_stream<Geo16<NS, 1, PG, kKGF, Face16Cfg<NS, MS, PG, CQ>::kSlotPieces>, 1, 1, kKGF, 1, kKGF, 0>(gw, ring, slot, act, a1, a2,
+  gemm16_stream<Geo16<NS, 1, PG, kKGF, Face16Cfg<NS, MS, PG, CQ>::kSlotPieces>, 1, 1, kKGF, 1, kKGF, 0>(gw, ring, slot, act, a1,
                                                                                                    WaveCtx{w.lane, w.wave, w.ns, 0}, w.ms == 0);
   if (w.ms == 0 && w.lane < 16) {
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias);
+    const float inv = *scl;
     float* fo = d.face + (size_t)n * 4 * NPIX;
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
-      const f32x4 v = a1[0][pg] + a2[0][pg] * kLoInv + bb;
+      const f32x4 v = a1[0][pg] * inv + bb;
 #pragma unroll
       for (int j = 0; j < 4; ++j) fo[(size_t)j * NPIX + pix0[pg] + w.lane] = v[j];
     }
@@ -362,13 +366,14 @@ __global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
   const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_l0);
   const float* bias = d.b_l0;
+  const float* scl = d.s_l0;
   int slot = 0;
   fetch2k<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
   first16_pos<G, kNB0>(d.wx[1], d.wy[1], d.pbias + (size_t)n * kPbStride + kPbL0, px, py, act, w);
   __syncthreads();
-  sine16_layer<G, kNB0, kKG0, HBA, 1, Cfg::kP2>(gw, bias, ring, slot, act, w);
-  sine16_layer<G, kNB1, kKG0, HBA, 1, Cfg::kP3>(gw, bias, ring, slot, act, w);
-  z16_layer<G, kNB1, kKG1, 1, CQB>(gw, ring, slot, act, d.z1 + (size_t)n * kNB1 * NPIX * 16, NPIX, pix0, w);
+  sine16_layer<G, kNB0, kKG0, HBA, 1, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
+  sine16_layer<G, kNB1, kKG0, HBA, 1, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
+  z16_layer<G, kNB1, kKG1, 1, CQB>(gw, scl, ring, slot, act, d.z1 + (size_t)n * kNB1 * NPIX * 16, NPIX, pix0, w);
 }
 
 // ---- level 1 ----------------------------------------------------------------------------------------
@@ -393,22 +398,23 @@ __global__ void __launch_bounds__(NS* MS * 64) level1_16_kernel(StudentDev d) {
   const int n = slot_pixels<G, S>(w, d.pos256, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_l1);
   const float* bias = d.b_l1;
+  const float* scl = d.s_l1;
   int slot = 0;
   fetch2k<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
   first16_up<G, kNB1>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, d.wx[2], d.wy[2],
                       d.pbias + (size_t)n * kPbStride + kPbL1, X0, Y, px, py, act, w);
   __syncthreads();
-  sine16_layer<G, kNB1, kKG1, 1, CQA, Cfg::kP2>(gw, bias, ring, slot, act, w);
-  sine16_layer<G, kNB2, kKG1, 1, CQA, Cfg::kP3>(gw, bias, ring, slot, act, w);
-  z16_layer<G, kNB2, kKG2, 1, CQB>(gw, ring, slot, act, d.z2 + (size_t)n * kNB2 * NPIX * 16, NPIX, pix0, w);
+  sine16_layer<G, kNB1, kKG1, 1, CQA, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
+  sine16_layer<G, kNB2, kKG1, 1, CQA, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
+  z16_layer<G, kNB2, kKG2, 1, CQB>(gw, scl, ring, slot, act, d.z2 + (size_t)n * kNB2 * NPIX * 16, NPIX, pix0, w);
 }
 
 // last_linear rows -> grid_sample warp of (image with the face patch) -> alpha blend -> NCHW outputs
 // (siren_morpher_03.py:125-131, image_processing_util.py:33-54, mode_14.py:72-78).  Rows 0..3 (dx, dy, alpha,
 // colour R) live in lane group 0, rows 4..6 (G, B, A) in group 1; lane group g then handles image channel g.
 template <int PG>
-THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bias, const int (&pix0)[PG], const float (&px)[PG],
-                               const float (&py)[PG], f32x4 (&a1)[1][PG], f32x4 (&a2)[1][PG], const WaveCtx& w) {
+THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bias, float inv, const int (&pix0)[PG], const float (&px)[PG],
+                               const float (&py)[PG], f32x4 (&a1)[1][PG], const WaveCtx& w) {
   constexpr int S = kImg, NPIX = S * S;
   const int p = w.lane & 15, g = w.lane >> 4;
   const f32x4 bb = *reinterpret_cast<const f32x4*>(head_bias + g * 4);
@@ -416,7 +422,7 @@ THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bia
   const float* face = d.face + (size_t)n * 4 * kFaceSize * kFaceSize;
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) {
-    const f32x4 v = a1[0][pg] + a2[0][pg] * kLoInv + bb;
+    const f32x4 v = a1[0][pg] * inv + bb;
     const float dx = lane_read(v[0], p), dy = lane_read(v[1], p), al = lane_read(v[2], p);
     const float c0 = lane_read(v[3], p), c1 = lane_read(v[0], p + 16), c2 = lane_read(v[1], p + 16),
                 c3 = lane_read(v[2], p + 16);
@@ -466,18 +472,19 @@ __global__ void __launch_bounds__(NS* MS * 64) level2_16_kernel(StudentDev d) {
   const int n = slot_pixels<G, S>(w, d.pos512, pix0, X0, Y, px, py);
   const char* gw = reinterpret_cast<const char*>(d.w_l2);
   const float* bias = d.b_l2;
+  const float* scl = d.s_l2;
   int slot = 0;
   fetch2k<CQ * kNB2, G::WAVES>(gw, ring, w.wave, w.lane);
   first16_up<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
                       d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, act, w);
   __syncthreads();
-  sine16_layer<G, kNB2, kKG2, 1, CQ, CQ * kNB2>(gw, bias, ring, slot, act, w);
-  sine16_layer<G, kNB2, kKG2, 1, CQ, kKG2>(gw, bias, ring, slot, act, w);
-  f32x4 a1[1][PG], a2[1][PG];
-  zero2<1, PG>(a1, a2);
-  gemm16_stream<G, 1, 1, kKG2, 1, kKG2, 0>(gw, ring, slot, act, a1, a2, w, true);
+  sine16_layer<G, kNB2, kKG2, 1, CQ, CQ * kNB2>(gw, bias, scl, ring, slot, act, w);
+  sine16_layer<G, kNB2, kKG2, 1, CQ, kKG2>(gw, bias, scl, ring, slot, act, w);
+  f32x4 a1[1][PG];
+  zero_acc<1, PG>(a1);
+  gemm16_stream<G, 1, 1, kKG2, 1, kKG2, 0>(gw, ring, slot, act, a1, w, true);
 
-  warp_blend_store<PG>(d, n, bias, pix0, px, py, a1, a2, w);
+  warp_blend_store<PG>(d, n, bias, *scl, pix0, px, py, a1, w);
 }
 
 // ---- level 2, weights-resident variant -------------------------------------------------------------
@@ -498,10 +505,9 @@ THA4_DEV void put_rows(f16x8 (&xh)[kKG2][PG], f16x8 (&xl)[kKG2][PG], int pg, int
   }
 }
 
-// acc += W x for one resident layer: pieces [Q][NB] at wv (lane offset applied), x in registers
+// acc += W' x for one resident layer: pieces [Q][NB] at wv (lane offset applied), x in registers
 template <int NB, int KG, int PG>
-THA4_DEV void mma_resident(const char* wv, const f16x8 (&xh)[KG][PG], const f16x8 (&xl)[KG][PG], f32x4 (&acc1)[NB][PG],
-                           f32x4 (&acc2)[NB][PG]) {
+THA4_DEV void mma_resident(const char* wv, const f16x8 (&xh)[KG][PG], const f16x8 (&xl)[KG][PG], f32x4 (&acc)[NB][PG]) {
   constexpr int GB = group_blocks(NB), NGB = NB / GB, T = KG * NGB;
   f16x8 ah[2][GB], al[2][GB];
 #pragma unroll
@@ -515,7 +521,7 @@ THA4_DEV void mma_resident(const char* wv, const f16x8 (&xh)[KG][PG], const f16x
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc1[bo + b][pg] = mfma16h(ah[t & 1][b], xh[qq][pg], acc1[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], xh[qq][pg], acc[bo + b][pg]);
     THA4_SCHED_FENCE();
     if (t + 1 < T) {
 #pragma unroll
@@ -529,11 +535,11 @@ THA4_DEV void mma_resident(const char* wv, const f16x8 (&xh)[KG][PG], const f16x
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(ah[t & 1][b], xl[qq][pg], acc2[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], xl[qq][pg], acc[bo + b][pg]);
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc2[bo + b][pg] = mfma16h(al[t & 1][b], xh[qq][pg], acc2[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(al[t & 1][b], xh[qq][pg], acc[bo + b][pg]);
     THA4_SCHED_FENCE();
   }
 }
@@ -583,26 +589,27 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
     const float* bias = d.b_l2;
 #pragma unroll
     for (int layer = 0; layer < 2; ++layer) {
-      f32x4 acc1[kNB2][PG], acc2[kNB2][PG];
-      zero2<kNB2, PG>(acc1, acc2);
-      mma_resident<kNB2, kKG2, PG>(layer == 0 ? w1 : w2, xh, xl, acc1, acc2);
+      f32x4 acc[kNB2][PG];
+      zero_acc<kNB2, PG>(acc);
+      mma_resident<kNB2, kKG2, PG>(layer == 0 ? w1 : w2, xh, xl, acc);
+      const float inv = d.s_l2[layer];
 #pragma unroll
       for (int b = 0; b < kNB2; ++b) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + b * 16 + g4);
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) {
-          f32x4 v = acc1[b][pg] + acc2[b][pg] * kLoInv + bb;
+          f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = sin_omega(v[j]);
+          for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(acc[b][pg][j], inv, bb[j]));
           put_rows<PG>(xh, xl, pg, b, v);
         }
       }
       bias += kNB2 * 16;
     }
-    f32x4 a1[1][PG], a2[1][PG];
-    zero2<1, PG>(a1, a2);
-    mma_resident<1, kKG2, PG>(w3, xh, xl, a1, a2);
-    warp_blend_store<PG>(d, n, bias, pix0, px, py, a1, a2, w);
+    f32x4 a1[1][PG];
+    zero_acc<1, PG>(a1);
+    mma_resident<1, kKG2, PG>(w3, xh, xl, a1);
+    warp_blend_store<PG>(d, n, bias, d.s_l2[2], pix0, px, py, a1, w);
   }
 }
 
@@ -646,8 +653,19 @@ constexpr int blocks_for(int batch, int side) { return batch * (side * side) / G
 }  // namespace cfg
 
 // ---- host packer -------------------------------------------------------------------------------------
-// One layer [O x I] -> pieces [Q][piece idx][hi 1 KiB | lo 1 KiB] with the block order of (MS, HB).
-inline void pack_layer16(const float* W, int ldw, int col0, int O, int I, int NB, int KG, int MS, int HB, std::vector<char>& dst) {
+// One layer [O x I] -> pieces [Q][piece idx][hi 1 KiB | lo 1 KiB] with the block order of (MS, HB).  The weights are
+// multiplied by `pre` (30 for layers feeding a sine) and by a power of two S chosen so that max |W'| lies in
+// [2^13, 2^14): hi = fp16(W'), lo = fp16(W' - hi) then keeps ~11 bits even for weights 2^-11 below the largest.
+// Returns 1/S (exact), which the kernel multiplies the accumulator with.
+inline float pack_layer16(const float* W, int ldw, int col0, int O, int I, int NB, int KG, int MS, int HB, float pre,
+                          std::vector<char>& dst) {
+  float mx = 0.f;
+  for (int o = 0; o < O; ++o)
+    for (int i = 0; i < I; ++i) mx = std::max(mx, std::fabs(W[(size_t)o * ldw + col0 + i] * pre));
+  int e = 0;
+  if (mx > 0.f) { std::frexp(16384.0f / mx, &e); e -= 1; }     // 2^e <= 16384 / mx < 2^(e+1)
+  e = std::min(std::max(e, -24), 24);
+  const float S = std::ldexp(1.0f, e);
   const size_t at = dst.size();
   dst.resize(at + (size_t)KG * NB * 2048);
   for (int Q = 0; Q < KG; ++Q)
@@ -659,32 +677,54 @@ inline void pack_layer16(const float* W, int ldw, int col0, int O, int I, int NB
         for (int j = 0; j < 8; ++j) {
           const int o = 16 * b + (lane & 15);
           const int i = 32 * Q + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
-          const float v = (o < O && i < I) ? W[(size_t)o * ldw + col0 + i] : 0.0f;
+          const float v = (o < O && i < I) ? (W[(size_t)o * ldw + col0 + i] * pre) * S : 0.0f;
           const _Float16 h = (_Float16)v;
           hi[lane * 8 + j] = h;
-          lo[lane * 8 + j] = (_Float16)((v - (float)h) * kLoScale);
+          lo[lane * 8 + j] = (_Float16)(v - (float)h);
         }
     }
+  return std::ldexp(1.0f, -e);
 }
 
 struct StudentPacked16 {
   std::vector<char> w_face, w_l0, w_l1, w_l2;
+  std::vector<float> s_face, s_l0, s_l1, s_l2;   // 1/S of every streamed layer, in execution order
+  std::vector<float> b_face, b_l0, b_l1, b_l2;   // biases of the streamed layers; sine layers carry the 30x
+  std::vector<float> wx[4], wy[4];               // first-layer position columns x 30 (0 face, 1..3 body levels)
 };
 
-// mirrors pack_student (siren_layout.h) for the weight streams only; biases / first layers are shared with generation 1
-inline void pack_student16(const StudentWeightsView& v, StudentPacked16& p) {
+// mirrors pack_student (siren_layout.h); `p1` is the generation-1 pack of the same weights (bias / first-layer tables)
+inline void pack_student16(const StudentWeightsView& v, const StudentPacked& p1, StudentPacked16& p) {
   p = StudentPacked16();
-  for (int i = 1; i < 8; ++i) pack_layer16(v.face_sine[i].weight, kCF, 0, kCF, kCF, kNBF, kKGF, cfg::kFaceMS, 1, p.w_face);
-  pack_layer16(v.face_last.weight, kCF, 0, 4, kCF, 1, kKGF, 1, 1, p.w_face);
-  pack_layer16(v.body_sine[0][1].weight, kC0, 0, kC0, kC0, kNB0, kKG0, cfg::kL0MS, cfg::kL0HBA, p.w_l0);
-  pack_layer16(v.body_sine[0][2].weight, kC0, 0, kC1, kC0, kNB1, kKG0, cfg::kL0MS, cfg::kL0HBA, p.w_l0);
-  pack_layer16(v.body_sine[1][0].weight, kC1 + 2 + kPose, 0, kC1, kC1, kNB1, kKG1, cfg::kL0MS, 1, p.w_l0);
-  pack_layer16(v.body_sine[1][1].weight, kC1, 0, kC1, kC1, kNB1, kKG1, cfg::kL1MS, 1, p.w_l1);
-  pack_layer16(v.body_sine[1][2].weight, kC1, 0, kC2, kC1, kNB2, kKG1, cfg::kL1MS, 1, p.w_l1);
-  pack_layer16(v.body_sine[2][0].weight, kC2 + 2 + kPose, 0, kC2, kC2, kNB2, kKG2, cfg::kL1MS, 1, p.w_l1);
-  pack_layer16(v.body_sine[2][1].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, p.w_l2);
-  pack_layer16(v.body_sine[2][2].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, p.w_l2);
-  pack_layer16(v.body_last.weight, kC2, 0, kHeadC, kC2, 1, kKG2, 1, 1, p.w_l2);
+  constexpr float W30 = kOmega;
+  for (int i = 1; i < 8; ++i) p.s_face.push_back(pack_layer16(v.face_sine[i].weight, kCF, 0, kCF, kCF, kNBF, kKGF, cfg::kFaceMS, 1, W30, p.w_face));
+  p.s_face.push_back(pack_layer16(v.face_last.weight, kCF, 0, 4, kCF, 1, kKGF, 1, 1, 1.0f, p.w_face));
+  p.s_l0.push_back(pack_layer16(v.body_sine[0][1].weight, kC0, 0, kC0, kC0, kNB0, kKG0, cfg::kL0MS, cfg::kL0HBA, W30, p.w_l0));
+  p.s_l0.push_back(pack_layer16(v.body_sine[0][2].weight, kC0, 0, kC1, kC0, kNB1, kKG0, cfg::kL0MS, cfg::kL0HBA, W30, p.w_l0));
+  p.s_l0.push_back(pack_layer16(v.body_sine[1][0].weight, kC1 + 2 + kPose, 0, kC1, kC1, kNB1, kKG1, cfg::kL0MS, 1, W30, p.w_l0));
+  p.s_l1.push_back(pack_layer16(v.body_sine[1][1].weight, kC1, 0, kC1, kC1, kNB1, kKG1, cfg::kL1MS, 1, W30, p.w_l1));
+  p.s_l1.push_back(pack_layer16(v.body_sine[1][2].weight, kC1, 0, kC2, kC1, kNB2, kKG1, cfg::kL1MS, 1, W30, p.w_l1));
+  p.s_l1.push_back(pack_layer16(v.body_sine[2][0].weight, kC2 + 2 + kPose, 0, kC2, kC2, kNB2, kKG2, cfg::kL1MS, 1, W30, p.w_l1));
+  p.s_l2.push_back(pack_layer16(v.body_sine[2][1].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, W30, p.w_l2));
+  p.s_l2.push_back(pack_layer16(v.body_sine[2][2].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, W30, p.w_l2));
+  p.s_l2.push_back(pack_layer16(v.body_last.weight, kC2, 0, kHeadC, kC2, 1, kKG2, 1, 1, 1.0f, p.w_l2));
+  // biases: every entry of the generation-1 arrays belongs to a sine layer except the trailing 16 of face / level 2
+  auto scaled = [&](const std::vector<float>& b, size_t plain_tail) {
+    std::vector<float> o(b);
+    for (size_t i = 0; i + plain_tail < o.size(); ++i) o[i] *= W30;
+    return o;
+  };
+  p.b_face = scaled(p1.b_face, 16);
+  p.b_l0 = scaled(p1.b_l0, 0);
+  p.b_l1 = scaled(p1.b_l1, 0);
+  p.b_l2 = scaled(p1.b_l2, 16);
+  const FirstLayerPack* fl[4] = {&p1.f_face, &p1.f_l0, &p1.f_l1, &p1.f_l2};
+  for (int i = 0; i < 4; ++i) {
+    p.wx[i] = fl[i]->wx;
+    p.wy[i] = fl[i]->wy;
+    for (auto& x : p.wx[i]) x *= W30;
+    for (auto& x : p.wy[i]) x *= W30;
+  }
 }
 
 }  // namespace v2

@@ -51,6 +51,10 @@ struct StudentDev {
   float* out_warped;         // [B][4][512][512] or null
   float* out_grid;           // [B][2][512][512] or null
   int batch;
+  // generation 2 (siren16_kernels.h): 1/S of every streamed layer in execution order; the first-layer tables (wx, wy),
+  // the pose-folded biases and the z hand-off carry the sine's 30x (pb_scale = 30; generation 1: 1)
+  const float *s_face, *s_l0, *s_l1, *s_l2;
+  float pb_scale;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -83,6 +87,27 @@ THA4_DEV float sin_omega(float z) {
   const float s = fmaf(r * r2, q, r);
   const unsigned flip = ((unsigned)(int)k) << 31;
   return __uint_as_float(__float_as_uint(s) ^ flip);
+}
+
+// sin(u) for a pre-scaled argument (generation 2 folds the 30x into weights and biases): k = rint(u/pi) comes from
+// adding 1.5*2^23 (valid for |u| < 2^22 pi; the low mantissa bit of the sum is the parity of k), r = u - k pi by a
+// 2-term Cody-Waite (k * 3.140625 is exact for |k| < 2^16; total error <= |k| 6e-11), same degree-9 polynomial.
+// 12 VALU ops: fma, sub, 2 fma, mul, 3 fma, mul, fma, shift, xor.
+THA4_DEV float sin_u(float u) {
+#ifdef THA4_ABLATE_SIN   // timing ablation only (tools/sweep.py): results are wrong
+  return u;
+#endif
+  const float t = fmaf(u, 0x1.45f306p-2f, 12582912.0f);
+  const float k = t - 12582912.0f;
+  float r = fmaf(-k, 0x1.92p+1f, u);
+  r = fmaf(-k, 0x1.fb5444p-11f, r);
+  const float r2 = r * r;
+  float q = 0x1.5cf94cp-19f;
+  q = fmaf(q, r2, -0x1.9f5ff6p-13f);
+  q = fmaf(q, r2, 0x1.110e6ap-7f);
+  q = fmaf(q, r2, -0x1.555548p-3f);
+  const float s = fmaf(r * r2, q, r);
+  return __uint_as_float(__float_as_uint(s) ^ (__float_as_uint(t) << 31));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -381,7 +406,7 @@ __global__ void __launch_bounds__(kPoseBiasBlock) posebias_kernel(StudentDev d) 
   float s[3] = {d.bias1[net][c], 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < kPose; ++k) s[k % 3] = fmaf(wp[(size_t)k * width], pose[k], s[k % 3]);
-  d.pbias[(size_t)n * kPbStride + idx] = s[0] + (s[1] + s[2]);
+  d.pbias[(size_t)n * kPbStride + idx] = (s[0] + (s[1] + s[2])) * d.pb_scale;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -139,20 +139,22 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
 
   const bool exact = (flags & THA4_STUDENT_EXACT_FP32) != 0;
   BlobBuilder bb;
-  size_t o_wf, o_w0, o_w1, o_w2;
-  if (exact) {
-    o_wf = bb.add(p.w_face); o_w0 = bb.add(p.w_l0); o_w1 = bb.add(p.w_l1); o_w2 = bb.add(p.w_l2);
-  } else {
-    v2::StudentPacked16 p16;
-    v2::pack_student16(to_view(weights), p16);
-    o_wf = bb.add(p16.w_face); o_w0 = bb.add(p16.w_l0); o_w1 = bb.add(p16.w_l1); o_w2 = bb.add(p16.w_l2);
-  }
-  const size_t o_bf = bb.add(p.b_face), o_b0 = bb.add(p.b_l0), o_b1 = bb.add(p.b_l1), o_b2 = bb.add(p.b_l2);
+  size_t o_wf, o_w0, o_w1, o_w2, o_bf, o_b0, o_b1, o_b2, o_sf = 0, o_s0 = 0, o_s1 = 0, o_s2 = 0;
   const FirstLayerPack* fl[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
   size_t o_wx[4], o_wy[4], o_b[4], o_wp[4];
+  if (exact) {
+    o_wf = bb.add(p.w_face); o_w0 = bb.add(p.w_l0); o_w1 = bb.add(p.w_l1); o_w2 = bb.add(p.w_l2);
+    o_bf = bb.add(p.b_face); o_b0 = bb.add(p.b_l0); o_b1 = bb.add(p.b_l1); o_b2 = bb.add(p.b_l2);
+    for (int i = 0; i < 4; ++i) { o_wx[i] = bb.add(fl[i]->wx); o_wy[i] = bb.add(fl[i]->wy); }
+  } else {
+    v2::StudentPacked16 p16;
+    v2::pack_student16(to_view(weights), p, p16);
+    o_wf = bb.add(p16.w_face); o_w0 = bb.add(p16.w_l0); o_w1 = bb.add(p16.w_l1); o_w2 = bb.add(p16.w_l2);
+    o_bf = bb.add(p16.b_face); o_b0 = bb.add(p16.b_l0); o_b1 = bb.add(p16.b_l1); o_b2 = bb.add(p16.b_l2);
+    o_sf = bb.add(p16.s_face); o_s0 = bb.add(p16.s_l0); o_s1 = bb.add(p16.s_l1); o_s2 = bb.add(p16.s_l2);
+    for (int i = 0; i < 4; ++i) { o_wx[i] = bb.add(p16.wx[i]); o_wy[i] = bb.add(p16.wy[i]); }
+  }
   for (int i = 0; i < 4; ++i) {
-    o_wx[i] = bb.add(fl[i]->wx);
-    o_wy[i] = bb.add(fl[i]->wy);
     o_b[i] = bb.add(fl[i]->bias);
     o_wp[i] = bb.add(fl[i]->wpose);
   }
@@ -197,6 +199,8 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
     d.wx[i] = F(o_wx[i]); d.wy[i] = F(o_wy[i]); d.bias1[i] = F(o_b[i]); d.wpose[i] = F(o_wp[i]);
   }
   d.pos128 = F(o_p128); d.pos256 = F(o_p256); d.pos512 = F(o_p512);
+  d.s_face = F(o_sf); d.s_l0 = F(o_s0); d.s_l1 = F(o_s1); d.s_l2 = F(o_s2);
+  d.pb_scale = exact ? 1.0f : kOmega;
   char* ws = h->workspace;
   d.pbias = reinterpret_cast<float*>(ws); ws += s_pb;
   d.face = reinterpret_cast<float*>(ws); ws += s_face;

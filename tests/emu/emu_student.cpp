@@ -71,7 +71,7 @@ void* emu_student_create_gen(const tha4_student_weights* w, const tha4_position_
   const StudentPacked& p = e->packed;
   d.w_face = p.w_face.data(); d.w_l0 = p.w_l0.data(); d.w_l1 = p.w_l1.data(); d.w_l2 = p.w_l2.data();
   if (gen == 2) {
-    v2::pack_student16(to_view(w), e->packed16);
+    v2::pack_student16(to_view(w), e->packed, e->packed16);
     d.w_face = reinterpret_cast<const float*>(e->packed16.w_face.data());
     d.w_l0 = reinterpret_cast<const float*>(e->packed16.w_l0.data());
     d.w_l1 = reinterpret_cast<const float*>(e->packed16.w_l1.data());
@@ -82,6 +82,15 @@ void* emu_student_create_gen(const tha4_student_weights* w, const tha4_position_
   for (int i = 0; i < 4; ++i) {
     d.wx[i] = f[i]->wx.data(); d.wy[i] = f[i]->wy.data();
     d.bias1[i] = f[i]->bias.data(); d.wpose[i] = f[i]->wpose.data();
+  }
+  d.pb_scale = 1.0f;
+  d.s_face = d.s_l0 = d.s_l1 = d.s_l2 = nullptr;
+  if (gen == 2) {
+    const v2::StudentPacked16& q = e->packed16;
+    d.b_face = q.b_face.data(); d.b_l0 = q.b_l0.data(); d.b_l1 = q.b_l1.data(); d.b_l2 = q.b_l2.data();
+    d.s_face = q.s_face.data(); d.s_l0 = q.s_l0.data(); d.s_l1 = q.s_l1.data(); d.s_l2 = q.s_l2.data();
+    for (int i = 0; i < 4; ++i) { d.wx[i] = q.wx[i].data(); d.wy[i] = q.wy[i].data(); }
+    d.pb_scale = kOmega;
   }
   d.pos128 = e->pos128.data(); d.pos256 = e->pos256.data(); d.pos512 = e->pos512.data();
   d.pbias = b["pbias"].data(); d.z1 = b["z1"].data(); d.z2 = b["z2"].data(); d.face = b["face"].data();
@@ -167,6 +176,7 @@ void emu_student_block_pixels_gen(int kernel, int block, int gen, int* first, in
 void emu_student_block_pixels(int kernel, int block, int* first, int* count) { emu_student_block_pixels_gen(kernel, block, 1, first, count); }
 
 float emu_sin_omega(float z) { return sin_omega(z); }
+float emu_sin_u(float u) { return sin_u(u); }
 
 void emu_student_destroy(void* h) { delete static_cast<EmuStudent*>(h); }
 

@@ -28,6 +28,8 @@ class EmuStudent:
         L.emu_student_destroy.argtypes = [C.c_void_p]
         L.emu_sin_omega.restype = C.c_float
         L.emu_sin_omega.argtypes = [C.c_float]
+        L.emu_sin_u.restype = C.c_float
+        L.emu_sin_u.argtypes = [C.c_float]
         face_sd, body_sd = split_flat_weights(flat_weights)
         ws, self._keep = _capi.build_student_weights(face_sd, body_sd)
         ax, self._keep2 = _capi.build_position_axes(axes)
@@ -60,6 +62,14 @@ class EmuStudent:
 
     def sin_omega(self, z):
         return self.lib.emu_sin_omega(float(z))
+
+    def sin_u(self, u):
+        return self.lib.emu_sin_u(float(u))
+
+    @property
+    def handoff_scale(self):
+        """Generation 2 folds the sine's 30x into the pose-folded biases and the z hand-off images."""
+        return 30.0 if self.gen == 2 else 1.0
 
     def close(self):
         if self.h:
