@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(CSRC, "libtha4_hip.so")
+RESOURCES = os.path.join(CSRC, "libtha4_hip.resources.txt")
 SOURCES = ["tha4_capi.hip"]
 
 
@@ -34,9 +35,33 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     deps = [os.path.join(CSRC, f) for f in SOURCES + _headers()] + [os.path.join(INCLUDE, "tha4_hip.h")]
     if not force and not _stale(LIB, deps):
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
            "-I", CSRC, "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+    with open(RESOURCES, "w") as f:          # per-kernel VGPR / scratch / LDS report (tests/test_api_surface.py gates on it)
+        f.write(parse_resource_remarks(r.stderr))
     return LIB
+
+
+def parse_resource_remarks(stderr: str) -> str:
+    """`-Rpass-analysis=kernel-resource-usage` remarks -> one line per kernel: name vgprs scratch_bytes occupancy."""
+    out, cur = [], {}
+    for line in stderr.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass", 1)[0].strip()
+        if body.startswith("Function Name:"):
+            if cur:
+                out.append(cur)
+            cur = {"name": body.split(":", 1)[1].strip()}
+        elif ":" in body and cur:
+            k, v = body.split(":", 1)
+            cur[k.strip()] = v.strip()
+    if cur:
+        out.append(cur)
+    return "".join(f"{c['name']} vgprs={c.get('VGPRs', '?')} scratch={c.get('ScratchSize [bytes/lane]', '?')} "
+                   f"occupancy={c.get('Occupancy [waves/SIMD]', '?')}\n" for c in out)

@@ -211,17 +211,9 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     for (int tc = 0; tc < ntc; ++tc) {
       if (chunk + 1 < nchunks) fetch(chunk + 1, slot ^ 1);
       const char* wsl = ring + slot * slot_bytes + lane * 16;
-      // window offsets of this chunk's taps (<= 4), fetched together so no tap waits on a scalar load
-      int toffs[4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int t = min(tc * a.taps_per_chunk + tt, a.ntaps - 1);
-        toffs[tt] = ((a.tap_dy[t] - a.win_dy0) * WW + (a.tap_dx[t] - a.win_dx0)) * 16;
-      }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        if (tt >= a.taps_per_chunk) break;
-        const int toff = toffs[tt];
+      for (int tt = 0; tt < a.taps_per_chunk; ++tt) {
+        const int t = tc * a.taps_per_chunk + tt;
+        const int toff = ((a.tap_dy[t] - a.win_dy0) * WW + (a.tap_dx[t] - a.win_dx0)) * 16;
         f16x8 bh[PG], bl[PG];
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) {
@@ -283,6 +275,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 #pragma unroll
         for (int k2 = 1; k2 < 16; ++k2) s = s + v[k2];
         acc[b][pg] = s;
+        THA4_SCHED_FENCE();                                  // one fragment's 16 loads in flight, not TMB*PG of them
       }
   }
 

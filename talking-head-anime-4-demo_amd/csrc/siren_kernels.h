@@ -151,11 +151,6 @@ THA4_DEV void fetch_pieces(const char* g, char* l, int wave, int lane) {
   }
 }
 
-#if !defined(THA4_EMU) && !defined(THA4_NO_PIPELINE)
-#define THA4_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define THA4_SCHED_FENCE()
-#endif
 
 // blocks per software-pipeline group: the A fragments of group t+1 are read from LDS while the
 // MFMAs of group t issue; inside a group MFMAs are ordered k-step-major so that consecutive

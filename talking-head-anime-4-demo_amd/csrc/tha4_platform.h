@@ -16,6 +16,13 @@
 
 #define THA4_DEV __device__ __forceinline__
 
+// instruction-scheduling fence: nothing moves across it (software pipelining by hand, and caps on loads in flight)
+#if !defined(THA4_EMU) && !defined(THA4_NO_PIPELINE)
+#define THA4_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define THA4_SCHED_FENCE()
+#endif
+
 namespace tha4 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -131,3 +131,13 @@ def test_full_weight_struct_and_create_validation(built):
     assert lib.tha4_full_create(None, 2, 0, 1, None) == -1
     assert lib.tha4_full_pose(None, None, 0, None, 1, None, 0, None) == -1
     lib.tha4_full_destroy(None)
+
+
+def test_no_kernel_uses_scratch(built):
+    """hipcc's per-kernel resource report (written by the build): no kernel may spill to scratch - a spilling build of
+    the weights-resident level-2 kernel once produced wrong, run-to-run varying pixels on the device."""
+    from tha4_amd import _build
+    lines = open(_build.RESOURCES).read().splitlines()
+    assert sum("conv_tile_kernel" in l for l in lines) == 27 and sum("tha42v2" in l for l in lines) >= 5
+    bad = [l for l in lines if "scratch=0" not in l]
+    assert not bad, bad

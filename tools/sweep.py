@@ -17,7 +17,8 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "noslp": ["-fno-slp-vectorize"],
+    "p842": ["-DTHA4_L216P_CFG=8,4,2"],
+    "l1_pg2": ["-DTHA4_L116_CFG=4,1,2,1,1"],
 }
 
 
