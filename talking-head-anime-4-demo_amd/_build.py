@@ -48,7 +48,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
 
 
 def parse_resource_remarks(stderr: str) -> str:
-    """`-Rpass-analysis=kernel-resource-usage` remarks -> one line per kernel: name vgprs scratch_bytes occupancy."""
+    """`-Rpass-analysis=kernel-resource-usage` remarks -> one line per kernel: name vgprs vgpr_spill scratch_bytes occupancy."""
     out, cur = [], {}
     for line in stderr.splitlines():
         if "remark:" not in line:
@@ -63,5 +63,5 @@ def parse_resource_remarks(stderr: str) -> str:
             cur[k.strip()] = v.strip()
     if cur:
         out.append(cur)
-    return "".join(f"{c['name']} vgprs={c.get('VGPRs', '?')} scratch={c.get('ScratchSize [bytes/lane]', '?')} "
-                   f"occupancy={c.get('Occupancy [waves/SIMD]', '?')}\n" for c in out)
+    return "".join(f"{c['name']} vgprs={c.get('VGPRs', '?')} vgpr_spill={c.get('VGPRs Spill', '?')} "
+                   f"scratch={c.get('ScratchSize [bytes/lane]', '?')} occupancy={c.get('Occupancy [waves/SIMD]', '?')}\n" for c in out)

@@ -7,7 +7,8 @@
 //     it stages the (TH*s + halo) x (TW*s + halo) input window ONCE into LDS, already normalised, activated,
 //     resampled (nearest-up / avg-pool), zero padded and split into fp16 hi + fp16 lo (v = hi + lo, 22 bits);
 //   * all taps then read their B fragments from that window at a constant LDS offset per tap, the weights stream
-//     through a 2-slot LDS ring as fp16 hi/lo fragment pieces (pre-scaled by a power of two so small weights keep
+//     through a 2..4-slot LDS ring (as deep as the LDS left by the window allows: workgroups with only 1-2 K groups
+//     - the K-split small maps - then have ALL their weight chunks in flight from the start) as fp16 hi/lo fragment pieces (pre-scaled by a power of two so small weights keep
 //     their low half out of the fp16 subnormal range), and every 32-deep k step costs three
 //     v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, 48 cycles instead of 256) into one fp32 accumulator;
 //   * the window of K group Q+1 is loaded into registers under the MFMAs of group Q;
@@ -73,7 +74,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   char* win_hi = smem;
   char* win_lo = smem + 4 * PLANE;
   char* ring = smem + 8 * PLANE;
-  float* red = reinterpret_cast<float*>(ring + 2 * slot_bytes);          // [8 waves][TMB*16][2]
+  const int D = a.ring_slots;                                            // ring depth (2..4)
+  float* red = reinterpret_cast<float*>(ring + D * slot_bytes);          // [8 waves][TMB*16][2]
   const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
 
   // ---- per-lane output pixels ------------------------------------------------------------------
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   // ---- staging items of this thread (geometry is the same for every K group) --------------------
   const int sg = tid & 3;                                 // lane group plane this thread stages
   const int nitems = NPX * 4;
-  int gofs[kTileMaxItems];                                // source pixel index (clamped); < 0: zero padding
+  struct Offsets { int v[kTileMaxItems]; } go;             // source pixel index (clamped); < 0: zero padding
 #pragma unroll
   for (int k = 0; k < kTileMaxItems; ++k) {
     const int item = tid + k * kTileThreads;
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     if (INMODE == IN_DIRECT) o = vy * a.in_w + vx;
     else if (INMODE == IN_UP2) o = (vy >> 1) * a.in_w + (vx >> 1);
     else o = (2 * vy) * a.in_w + 2 * vx;
-    gofs[k] = ok ? o : -1;
+    go.v[k] = ok ? o : -1;
   }
 
   auto fetch = [&](int chunk, int slot) {
@@ -154,22 +156,22 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 
   f32x4 rawA[kTileMaxItems], rawB[kTileMaxItems];
   QuadCtx cA, cB;
-  auto load_window = [&](int Q) {
+  auto load_window = [&](int Q, const Offsets gofs) {
     cA = quad_ctx(2 * Q);
     cB = quad_ctx(2 * Q + 1);
 #pragma unroll
     for (int k = 0; k < kTileMaxItems; ++k) {
-      rawA[k] = load_quad(cA, gofs[k]);
-      rawB[k] = load_quad(cB, gofs[k]);
+      rawA[k] = load_quad(cA, gofs.v[k]);
+      rawB[k] = load_quad(cB, gofs.v[k]);
     }
   };
-  auto write_window = [&]() {
+  auto write_window = [&](const Offsets gofs) {
 #pragma unroll
     for (int k = 0; k < kTileMaxItems; ++k) {
       const int item = tid + k * kTileThreads;
       if (item >= nitems) continue;
       f32x4 va = rawA[k], vb = rawB[k];
-      if (gofs[k] < 0) {                                   // zero padding is applied AFTER normalisation + activation
+      if (gofs.v[k] < 0) {                                 // zero padding is applied AFTER normalisation + activation
         va = f32x4{0.f, 0.f, 0.f, 0.f};
         vb = va;
       } else if (!kPool) {
@@ -200,16 +202,23 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   const int nchunks = q_end * ntc;
   const bool reduce_phase = a.phase == 2;
   if (reduce_phase) q_begin = q_end;                       // nothing to multiply: partials come from the workspace
+  int issued = chunk, islot = 0;                           // next chunk to fetch and the slot it goes to
   if (q_begin < q_end) {
-    fetch(chunk, 0);
-    load_window(q_begin);
-    write_window();
+    for (int i = 0; i < D - 1 && issued < nchunks; ++i) {  // D-1 chunks ahead; the D-th slot is the one being read
+      fetch(issued++, islot);
+      islot = islot + 1 == D ? 0 : islot + 1;
+    }
+    load_window(q_begin, go);
+    write_window(go);
   }
   __syncthreads();
   for (int Q = q_begin; Q < q_end; ++Q) {
-    if (Q + 1 < q_end) load_window(Q + 1);
+    if (Q + 1 < q_end) load_window(Q + 1, go);
     for (int tc = 0; tc < ntc; ++tc) {
-      if (chunk + 1 < nchunks) fetch(chunk + 1, slot ^ 1);
+      if (issued < nchunks) {                              // refill the slot freed by the previous barrier
+        fetch(issued++, islot);
+        islot = islot + 1 == D ? 0 : islot + 1;
+      }
       const char* wsl = ring + slot * slot_bytes + lane * 16;
       for (int tt = 0; tt < a.taps_per_chunk; ++tt) {
         const int t = tc * a.taps_per_chunk + tt;
@@ -233,11 +242,11 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         }
       }
       __syncthreads();
-      slot ^= 1;
+      slot = slot + 1 == D ? 0 : slot + 1;
       ++chunk;
     }
     if (Q + 1 < q_end) {
-      write_window();                                      // every wave has finished reading window Q (barrier above)
+      write_window(go);                                    // every wave has finished reading window Q (barrier above)
       __syncthreads();
     }
   }

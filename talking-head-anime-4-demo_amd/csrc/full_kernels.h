@@ -63,6 +63,7 @@ struct ConvArgs {
   int win_h, win_w;      // staged input window (virtual input pixels)
   int win_dy0, win_dx0;  // window origin relative to (tile origin * in_stride)
   int taps_per_chunk;    // taps per streamed weight chunk (divides ntaps)
+  int ring_slots;        // depth of the LDS weight ring (2..4)
   float* partial;        // split-K workspace [ksplit][batch][mtile][tile][TMB][8*PG][64] f32x4, or null
   int ksplit;            // K splits (phase 1 grid z)
   int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue

@@ -158,6 +158,7 @@ struct TileGeom {
   float efficiency = 0.f;
   int win_h = 0, win_w = 0, dy0 = 0, dx0 = 0;
   int taps_per_chunk = 1;
+  int ring_slots = 2;            // LDS weight ring depth: as deep (<= 4) as the LDS left by the window allows
   size_t lds = 0;
 };
 inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB, int tw_log2) {
@@ -183,7 +184,13 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   for (int d = 1; d <= g.ntaps; ++d)
     if (g.ntaps % d == 0 && d <= 4 && d * TMB * 2048 <= 32 * 1024) t.taps_per_chunk = d;
   const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
-  t.lds = 8 * plane + 2 * (size_t)t.taps_per_chunk * TMB * 2048 + 8 * (size_t)TMB * 16 * 2 * sizeof(float);
+  const size_t slot = (size_t)t.taps_per_chunk * TMB * 2048, red = 8 * (size_t)TMB * 16 * 2 * sizeof(float);
+  // deeper while it costs no occupancy: never push a workgroup that fits twice on a CU (<= 80 KiB) over that line
+  t.ring_slots = 2;
+  const size_t base = 8 * plane + 2 * slot + red;
+  const size_t cap = base <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
+  while (t.ring_slots < 4 && 8 * plane + (t.ring_slots + 1) * slot + red <= cap) ++t.ring_slots;
+  t.lds = 8 * plane + t.ring_slots * slot + red;
   t.ok = t.lds <= 160 * 1024;
   return t;
 }
@@ -198,6 +205,7 @@ struct TilePlan {
 inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TMB, int mtiles, int nq, int want_wgs = 256) {
   TilePlan best;
   const int kmax = std::getenv("THA4_KSPLIT_MAX") ? std::atoi(std::getenv("THA4_KSPLIT_MAX")) : 16;   // tuning aid
+  const int min_nq = std::getenv("THA4_KSPLIT_MIN_NQ") ? std::atoi(std::getenv("THA4_KSPLIT_MIN_NQ")) : 0;   // tuning aid
   float best_eff = 0.f;
   for (int pg : {4, 2, 1})
     for (int twl : {5, 4, 3}) {
@@ -225,7 +233,7 @@ inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TM
   if (!best.ok) return best;
   const int wgs = best.geom.tiles * mtiles;
   int ksplit = 1;
-  if (wgs < want_wgs / 2) {
+  if (wgs < want_wgs / 2 && nq >= min_nq) {
     const int want = std::min(std::min(nq, kmax), (want_wgs + wgs - 1) / wgs);
     const int per = (nq + want - 1) / want;
     ksplit = (nq + per - 1) / per;                     // every split gets at least one K group
