@@ -135,12 +135,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
                                   : S.data + ((size_t)n * S.cb + ql) * (size_t)in_px * 16 + sg * 4;
     return c;
   };
-  auto activate = [&](const f32x4& r, const QuadCtx& c) -> f32x4 {
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = apply_act(fmaf(r[j], c.sc[j], c.sh[j]), c.act);
-    return o;
-  };
+  auto activate = [&](const f32x4& r, const QuadCtx& c) -> f32x4 { return apply_act4(r, c.sc, c.sh, c.act); };
   // raw (IN_DIRECT / IN_UP2) or finished (IN_POOL2: the 2x2 mean of the activated samples) values of one item
   auto load_quad = [&](const QuadCtx& c, int o) -> f32x4 {
     if (!c.base || o < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
@@ -182,9 +177,9 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         hi[j] = (_Float16)va[j];
-        lo[j] = (_Float16)(va[j] - (float)hi[j]);
+        lo[j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[j], va[j]);          // one v_fma_mix
         hi[4 + j] = (_Float16)vb[j];
-        lo[4 + j] = (_Float16)(vb[j] - (float)hi[4 + j]);
+        lo[4 + j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[4 + j], vb[j]);
       }
       const int off = sg * PLANE + (item >> 2) * 16;
       *reinterpret_cast<f16x8*>(win_hi + off) = hi;
@@ -198,6 +193,14 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
+  long long* stamps = a.dbg ? a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTileWaves + wave) * 64 : nullptr;
+  int nstamp = 0;
+#define THA4_CSTAMP() do { if (stamps && lane == 0 && nstamp < 64) stamps[nstamp] = clock64(); ++nstamp; } while (0)
+#else
+#define THA4_CSTAMP()
+#endif
+  THA4_CSTAMP();                                           // 0: entry (after index set-up)
   int slot = 0, chunk = q_begin * ntc;
   const int nchunks = q_end * ntc;
   const bool reduce_phase = a.phase == 2;
@@ -209,9 +212,12 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       islot = islot + 1 == D ? 0 : islot + 1;
     }
     load_window(q_begin, go);
+    THA4_CSTAMP();                                         // 1: first window loads issued
     write_window(go);
+    THA4_CSTAMP();                                         // 2: first window written
   }
   __syncthreads();
+  THA4_CSTAMP();                                           // 3: prologue barrier passed
   for (int Q = q_begin; Q < q_end; ++Q) {
     if (Q + 1 < q_end) load_window(Q + 1, go);
     for (int tc = 0; tc < ntc; ++tc) {
@@ -241,13 +247,17 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
           for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(al, bh[pg], acc[b][pg]);
         }
       }
+      THA4_CSTAMP();                                       // chunk MFMAs issued
       __syncthreads();
+      THA4_CSTAMP();                                       // chunk barrier passed
       slot = slot + 1 == D ? 0 : slot + 1;
       ++chunk;
     }
     if (Q + 1 < q_end) {
       write_window(go);                                    // every wave has finished reading window Q (barrier above)
+      THA4_CSTAMP();                                       // next window written
       __syncthreads();
+      THA4_CSTAMP();                                       // window barrier passed
     }
   }
 

@@ -67,14 +67,46 @@ struct ConvArgs {
   float* partial;        // split-K workspace [ksplit][batch][mtile][tile][TMB][8*PG][64] f32x4, or null
   int ksplit;            // K splits (phase 1 grid z)
   int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue
+#ifdef THA4_PHASE_TIMING
+  long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
+#endif
 };
+
+// 1 / (1 + e^-v) on the hardware transcendentals: v_exp_f32 (2^x, ~1 ulp) and v_rcp_f32 (1 ulp) - libm's expf plus an
+// IEEE division cost ~40 VALU instructions per element, which made the SiLU operand staging of the U-Net convolutions
+// (8 elements per staged item) the largest single cost of those kernels; relative error ~2e-7, parity unaffected.
+THA4_DEV float fast_sigmoid(float v) {
+#ifdef THA4_EMU
+  return 1.0f / (1.0f + expf(-v));
+#else
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+#endif
+}
 
 THA4_DEV float apply_act(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.0f);
-  if (act == ACT_SILU) return v / (1.0f + expf(-v));
-  if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  if (act == ACT_SILU) return v * fast_sigmoid(v);
+  if (act == ACT_SIGMOID) return fast_sigmoid(v);
   if (act == ACT_TANH) return tanhf(v);
   return v;
+}
+
+// act(x * sc + sh) on four values with ONE (uniform) dispatch on the activation
+THA4_DEV f32x4 apply_act4(const f32x4& x, const f32x4& sc, const f32x4& sh, int act) {
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = fmaf(x[j], sc[j], sh[j]);
+  if (act == ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.0f);
+  } else if (act == ACT_SILU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = o[j] * fast_sigmoid(o[j]);
+  } else if (act != ACT_NONE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act);
+  }
+  return o;
 }
 
 // raw operand of one (quad, tap) step for one pixel group (NV = 4 samples of the 2x2 window when pooling)

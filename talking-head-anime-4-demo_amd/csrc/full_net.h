@@ -61,7 +61,14 @@ class FullModel {
   // split-K scratch shared by all convolutions (they run back to back on one stream): sized while the schedule is
   // built, placed in the workspace by finalize_scratch() before the arena is allocated (and zeroed) by the caller
   size_t partial_floats = 0, partial_off = 0;
-  void finalize_scratch() { partial_off = alloc_work(partial_floats); }
+  int conv_counter = 0;      // build-order index of every convolution (schedule dump / tuning aids)
+  size_t dbg_off = 0;        // tuning aid (THA4_PHASE_TIMING): stamp buffer
+  void finalize_scratch() {
+    partial_off = alloc_work(partial_floats);
+#ifdef THA4_PHASE_TIMING
+    dbg_off = alloc_work((size_t)2 << 20);
+#endif
+  }
 
   size_t add_param(const void* p, size_t bytes) {
     size_t at = (host_params.size() + 255) / 256 * 256;
@@ -212,8 +219,9 @@ class FullModel {
     if (tiled && ksplit > 1) {
       partial_floats = std::max(partial_floats, (size_t)ksplit * mtiles * tiles * tmb * 8 * pg * 64 * 4);
     }
+    const int conv_index = conv_counter++;
     if (std::getenv("THA4_DUMP_SCHEDULE"))
-      std::fprintf(stderr, "conv kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d ksplit=%d twl=%d\n", (int)kind, ih,
+      std::fprintf(stderr, "conv #%d kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d ksplit=%d twl=%d\n", conv_index, (int)kind, ih,
                    iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles * ksplit, (int)tiled, ksplit,
                    tiled ? plan.geom.tw_log2 : 0);
     FTensor out = new_tensor(nb, oh, ow);
@@ -278,6 +286,9 @@ class FullModel {
         c.w = P(w_off);
         c.w16 = P<char>(w_off);
         c.partial = ksplit > 1 ? Wk(partial_off) : nullptr;
+#ifdef THA4_PHASE_TIMING
+        c.dbg = (std::getenv("THA4_DBG_CONV") && std::atoi(std::getenv("THA4_DBG_CONV")) == conv_index) ? reinterpret_cast<long long*>(Wk(dbg_off)) : nullptr;
+#endif
         c.ksplit = ksplit;
         c.bias = bias_off == kNone ? nullptr : P(bias_off);
         c.act_out = act_off == kNone ? nullptr : P<int>(act_off);

@@ -396,6 +396,15 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
   return THA4_OK;
 }
 
+#ifdef THA4_PHASE_TIMING
+// tuning aid (not part of the ABI header): copy the head of the split-K workspace (phase stamps) to the host
+int tha4_full_debug_read(tha4_full* h, void* dst, size_t bytes) {
+  DeviceGuard guard(h->device);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpy(dst, h->model.Wk(h->model.dbg_off), bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void tha4_full_destroy(tha4_full* h) {
   if (!h) return;
   DeviceGuard guard(h->device);

@@ -8,8 +8,8 @@ from collections import defaultdict
 
 sched = []
 for line in open(sys.argv[1]):
-    if line.startswith("conv kind="):
-        kv = dict(re.findall(r"(\w+)=([\w()x ]+?)(?= \w+=|$)", line.strip()[5:]))
+    if line.startswith("conv "):
+        kv = dict(re.findall(r"(\w+)=([\w()x ]+?)(?= \w+=|$)", line.strip()[line.index("kind="):]))
         sched.append(kv)
 launches = []
 for kv in sched:

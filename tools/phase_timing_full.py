@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Phase timing of conv_tile_kernel (GPU box): `build` compiles a -DTHA4_PHASE_TIMING variant; the run selects a few
+convolutions of the full model by shape, poses one frame each with THA4_DBG_CONV=<index> and prints where a wave's
+cycles go (s_memtime stamps at every barrier).  Tuning aid."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "talking-head-anime-4-demo_amd", "csrc")
+lib = os.path.join(ROOT, "build_variants", "libtha4_phase.so")
+if "build" in sys.argv:
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTHA4_PHASE_TIMING", "-I", CSRC, "-I",
+                    os.path.join(ROOT, "include"), os.path.join(CSRC, "tha4_capi.hip"), "-o", lib], check=True)
+    sys.exit(0)
+
+import numpy as np
+import torch
+
+os.environ["THA4_HIP_LIB"] = lib
+os.environ["THA4_DUMP_SCHEDULE"] = "1"
+import tha4_amd  # noqa
+from tha4_amd import synthetic
+from tha4_amd.poser.modes import mode_07
+
+dev = torch.device("cuda:0")
+# capture the schedule dump (stderr of the native library)
+tmp = tempfile.TemporaryFile(mode="w+b")
+saved = os.dup(2)
+os.dup2(tmp.fileno(), 2)
+p = mode_07.create_poser_from_state_dicts(dev, synthetic.synth_full_weights())
+p.get_modules() if hasattr(p, "get_modules") else None
+io = np.load(os.path.join(ROOT, "tests/golden/student_lambda_00_io.npz"))
+image = torch.from_numpy(io["image_f32"]).to(dev)
+poses = torch.from_numpy(io["poses"]).to(dev)
+p.pose(image, poses[0])
+torch.cuda.synchronize()
+os.dup2(saved, 2)
+tmp.seek(0)
+sched = [l for l in tmp.read().decode().splitlines() if l.startswith("conv #")]
+del os.environ["THA4_DUMP_SCHEDULE"]
+
+targets = ["tile=64x64 cin=256(cb 16) cout=256", "tile=16x16 cin=512(cb 32) cout=512", "tile=256x256 cin=128(cb 8) cout=128",
+           "tile=128x128 cin=128(cb 8) cout=128", "tile=32x32 cin=256(cb 16) cout=256"]
+L = p._lib
+L.tha4_full_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+for tgt in targets:
+    line = next((l for l in sched if tgt in l and "kind=0" in l and "mode=0" in l), None)
+    if line is None:
+        print("no conv matches", tgt)
+        continue
+    kv = dict(re.findall(r"(\w+)=([\w()x]+)", line))
+    idx = int(re.match(r"conv #(\d+)", line).group(1))
+    wgs = int(kv["wgs"]) // max(1, int(kv["ksplit"]))
+    os.environ["THA4_DBG_CONV"] = str(idx)
+    buf = np.zeros(wgs * 8 * 64, np.int64)
+    # clear, run, read
+    for _ in range(2):
+        p.pose(image, poses[1], image_changed=True)
+    assert L.tha4_full_debug_read(p._handle, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+    t = buf.reshape(wgs, 8, 64).astype(np.float64)
+    n = int((t[0, 0] > 0).sum())
+    d = np.diff(t[:, :, :n], axis=-1)
+    print(f"== {line[:150]}")
+    print(f"   stamps per wave: {n}; wave span entry -> last stamp: {(t[:, :, n - 1] - t[:, :, 0]).mean():.0f} cycles")
+    print("   mean cycles between consecutive stamps: " + " ".join(f"{x:.0f}" for x in d.mean(axis=(0, 1))))
+os.environ.pop("THA4_DBG_CONV", None)
