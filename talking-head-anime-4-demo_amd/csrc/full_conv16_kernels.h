@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   // ---- staging items of this thread (geometry is the same for every K group) --------------------
   const int sg = tid & 3;                                 // lane group plane this thread stages
   const int nitems = NPX * 4;
-  struct Offsets { int v[kTileMaxItems]; } go;             // source pixel index (clamped); < 0: zero padding
+  struct Offsets { int v[kTileMaxItems]; } go;             // byte offset of the item inside a quad's plane; < 0: zero padding
 #pragma unroll
   for (int k = 0; k < kTileMaxItems; ++k) {
     const int item = tid + k * kTileThreads;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     if (INMODE == IN_DIRECT) o = vy * a.in_w + vx;
     else if (INMODE == IN_UP2) o = (vy >> 1) * a.in_w + (vx >> 1);
     else o = (2 * vy) * a.in_w + 2 * vx;
-    go.v[k] = ok ? o : -1;
+    go.v[k] = ok ? o * 64 + sg * 16 : -1;                  // BYTE offset from the (wave-uniform) quad base: saddr + voffset loads
   }
 
   auto fetch = [&](int chunk, int slot) {
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   };
 
   // one quad of one K group: which source, its scale/shift/activation for lane group sg
-  struct QuadCtx { const float* base; f32x4 sc, sh; int act; int kind; };
+  struct QuadCtx { const char* base; f32x4 sc, sh; int act; int kind; };   // base: wave-uniform
   auto quad_ctx = [&](int q) -> QuadCtx {
     QuadCtx c;
     c.base = nullptr; c.act = ACT_NONE; c.kind = SRC_TENSOR;
@@ -131,16 +131,16 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       c.sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + sg * 4);
       c.sh = *reinterpret_cast<const f32x4*>(S.shift + ((size_t)n * S.cb + ql) * 16 + sg * 4);
     }
-    c.base = S.kind == SRC_VECTOR ? S.data + ((size_t)n * S.cb + ql) * 16 + sg * 4
-                                  : S.data + ((size_t)n * S.cb + ql) * (size_t)in_px * 16 + sg * 4;
+    c.base = reinterpret_cast<const char*>(S.kind == SRC_VECTOR ? S.data + ((size_t)n * S.cb + ql) * 16
+                                                                : S.data + ((size_t)n * S.cb + ql) * (size_t)in_px * 16);
     return c;
   };
   auto activate = [&](const f32x4& r, const QuadCtx& c) -> f32x4 { return apply_act4(r, c.sc, c.sh, c.act); };
   // raw (IN_DIRECT / IN_UP2) or finished (IN_POOL2: the 2x2 mean of the activated samples) values of one item
   auto load_quad = [&](const QuadCtx& c, int o) -> f32x4 {
     if (!c.base || o < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c.kind == SRC_VECTOR) return *reinterpret_cast<const f32x4*>(c.base);
-    const float* ptr = c.base + (size_t)o * 16;
+    if (c.kind == SRC_VECTOR) return *reinterpret_cast<const f32x4*>(c.base + sg * 16);
+    const float* ptr = reinterpret_cast<const float*>(c.base + (unsigned)o);
     if (!kPool) return *reinterpret_cast<const f32x4*>(ptr);
     const f32x4 v00 = activate(*reinterpret_cast<const f32x4*>(ptr), c);
     const f32x4 v01 = activate(*reinterpret_cast<const f32x4*>(ptr + 16), c);
