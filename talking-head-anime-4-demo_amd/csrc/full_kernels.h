@@ -576,13 +576,26 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
     const int cl = c - (s ? c0 : 0);
     const int cw = a.cb[s] * 16;
     const float* ps = a.stats[s] + ((size_t)n * a.tiles[s] * cw + cl) * 2;
-    double su = 0.0, sq = 0.0;
-    for (int t = sl; t < a.tiles[s]; t += S) {
-      su += (double)ps[(size_t)t * cw * 2];
-      sq += (double)ps[(size_t)t * cw * 2 + 1];
+    // four independent partial sums (fixed assignment t -> sum (t/S)%4, combined in a fixed order): the loads of four
+    // tiles are in flight at once instead of one fp64 add chain waiting on each 8-byte load in turn
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    double su[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nt = a.tiles[s];
+    int t = sl;
+    for (; t + 3 * S < nt; t += 4 * S) {
+      f32x2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x2*>(ps + (size_t)(t + u * S) * cw * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { su[u] += (double)v[u][0]; sq[u] += (double)v[u][1]; }
     }
-    part[((size_t)sl * ctot + c) * 2] = su;
-    part[((size_t)sl * ctot + c) * 2 + 1] = sq;
+    for (; t < nt; t += S) {                               // at most three left-over tiles
+      const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
+      su[0] += (double)v[0];
+      sq[0] += (double)v[1];
+    }
+    part[((size_t)sl * ctot + c) * 2] = (su[0] + su[1]) + (su[2] + su[3]);
+    part[((size_t)sl * ctot + c) * 2 + 1] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < ctot; c += kNormThreads) {
