@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
-  long long* stamps = a.dbg ? a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTileWaves + wave) * 64 : nullptr;
+  long long* stamps = (a.dbg && a.phase != 2 && blockIdx.z == 0) ? a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTileWaves + wave) * 64 : nullptr;
   int nstamp = 0;
 #define THA4_CSTAMP() do { if (stamps && lane == 0 && nstamp < 64) stamps[nstamp] = clock64(); ++nstamp; } while (0)
 #else
@@ -274,6 +274,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg)
           part[(((size_t)ks * ntile_ids + tile_id) * TMB + b) * frag + (size_t)(wave * PG + pg) * 64 + lane] = acc[b][pg];
+      THA4_CSTAMP();                                       // partials written
       return;
     }
 #pragma unroll

@@ -59,12 +59,14 @@ for tgt in targets:
     wgs = int(kv["wgs"]) // max(1, int(kv["ksplit"]))
     os.environ["THA4_DBG_CONV"] = str(idx)
     buf = np.zeros(wgs * 8 * 64, np.int64)
+    L.tha4_full_debug_clear(p._handle) if hasattr(L, 'tha4_full_debug_clear') else None
     # clear, run, read
     for _ in range(2):
         p.pose(image, poses[1], image_changed=True)
     assert L.tha4_full_debug_read(p._handle, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
     t = buf.reshape(wgs, 8, 64).astype(np.float64)
     n = int((t[0, 0] > 0).sum())
+    first = t[:, :, 0].copy()
     d = np.diff(t[:, :, :n], axis=-1)
     print(f"== {line[:150]}")
     print(f"   stamps per wave: {n}; wave span entry -> last stamp: {(t[:, :, n - 1] - t[:, :, 0]).mean():.0f} cycles")
