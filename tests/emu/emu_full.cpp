@@ -157,6 +157,16 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   return 0;
 }
 
+// Launch plan of conv_tile_kernel for one convolution (host logic of full_layout.h): out = {ok, pg, ksplit, tw_log2, th,
+// tiles, win_h, win_w, taps_per_chunk, ring_slots, lds_bytes}
+int emu_plan_tile_conv(int kind, int k, int tile_h, int tile_w, int tmb, int mtiles, int nq, int* out) {
+  const ConvGeom g = kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0));
+  const TilePlan p = plan_tile_conv(g, tile_h, tile_w, tmb, mtiles, nq);
+  out[0] = p.ok; out[1] = p.pg; out[2] = p.ksplit; out[3] = p.geom.tw_log2; out[4] = p.geom.th; out[5] = p.geom.tiles;
+  out[6] = p.geom.win_h; out[7] = p.geom.win_w; out[8] = p.geom.taps_per_chunk; out[9] = p.geom.ring_slots; out[10] = (int)p.geom.lds;
+  return 0;
+}
+
 // norm finalize: stats partials given as [n][tiles][cb*16][2] per source; returns scale/shift [n][cb*16] per source
 int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float* st1, int tiles1, int cb1, int channels,
              int groups, float inv_count, float eps, const float* gamma, const float* beta, const float* film0,

@@ -226,3 +226,49 @@ def test_gemv_and_attention(lib):
     wgt = torch.softmax(torch.einsum("bct,bcs->bts", (q * s).reshape(n * heads, ch, L), (kk * s).reshape(n * heads, ch, L)), -1)
     ref = torch.einsum("bts,bcs->bct", wgt, v.reshape(n * heads, ch, L)).reshape(n, Cc, L).numpy()
     assert np.abs(out - ref).max() < 1e-5
+
+
+def test_tile_conv_launch_plans(lib):
+    """plan_tile_conv (host logic) over every convolution shape of the full model: valid geometry, LDS and staging
+    budgets respected, the tile grid covers the map, K splits cover the K groups with at least one group each, and
+    maps >= 128x128 are never K-split (partial traffic would be ksplit x the output)."""
+    shapes = []      # (kind, k, tile_h, tile_w, cin, cout)
+    for hw in (128, 192):                                                    # encoder-decoders (192: face morpher)
+        shapes += [(0, 3, hw, hw, 4, 64), (0, 3, hw, hw, 8, 64), (0, 3, hw, hw, 64, 12)]
+        c = 64
+        for lvl in range(3):
+            shapes.append((1, 4, hw >> (lvl + 1), hw >> (lvl + 1), c, 2 * c))
+            c *= 2
+        shapes += [(0, 3, hw >> 3, hw >> 3, 512, 512), (0, 3, hw >> 3, hw >> 3, 539, 512)]
+        for lvl in range(3):
+            shapes.append((2, 4, hw >> (3 - lvl), hw >> (3 - lvl), c, c // 2))
+            c //= 2
+    for size, ch in ((256, 64), (512, 32)):                                   # U-Nets
+        shapes += [(0, 3, size, size, 14, ch), (0, 3, size, size, ch, 7)]
+        for lvl, mult in enumerate((1, 2, 4, 4, 4, 8)):
+            s_ = size >> lvl
+            if s_ < 16:
+                break
+            shapes += [(0, 3, s_, s_, ch * mult, ch * mult), (0, 3, s_, s_, 3 * ch * mult // 2, ch * mult), (0, 3, s_, s_, 2 * ch * mult, ch * mult)]
+    out = (C.c_int * 11)()
+    seen_split = seen_ragged = False
+    for kind, k, th, tw, cin, cout in shapes:
+        nb = (cout + 15) // 16
+        tmb = 4 if nb % 4 == 0 else (2 if nb % 2 == 0 else 1)
+        nq = ((cin + 15) // 16 + 1) // 2
+        lib.emu_plan_tile_conv(kind, k, th, tw, tmb, nb // tmb, nq, out)
+        ok, pg, ksplit, twl, tile_h, tiles, win_h, win_w, tpc, slots, lds = list(out)
+        assert ok, (kind, k, th, tw, cin, cout)
+        assert pg in (1, 2, 4) and 128 * pg == tile_h << twl
+        assert tiles == -(-th // tile_h) * -(-tw // (1 << twl))
+        assert win_h * win_w * 4 <= 5 * 512 and lds <= 160 * 1024 and 2 <= slots <= 4
+        ntaps = {0: k * k, 1: 16, 2: 4}[kind]
+        assert ntaps % tpc == 0 and tpc <= 4
+        assert 1 <= ksplit <= min(nq, 16)
+        per = -(-nq // ksplit)
+        assert (ksplit - 1) * per < nq                     # every split owns at least one K group
+        if th * tw >= 128 * 128:
+            assert ksplit == 1, (th, tw, cin, cout, ksplit)
+        seen_split |= ksplit > 1
+        seen_ragged |= tiles * 128 * pg != th * tw
+    assert seen_split and seen_ragged
