@@ -46,8 +46,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # v_mfma_f32_16x16x4_f32 dense peak (what an 
 # HBM-side bytes per launch of each kernel from the PMC passes committed in profiles/r01_student_b1_profile.md
 # (FETCH_SIZE x 2 [gfx950 wide-read correction, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, KiB -> bytes).
 # bench.py cannot run rocprofv3 on itself, so this is the profiled value for the same command line.
-PMC_TRAFFIC_BYTES = {"face": (1920 * 2 + 256) * 1024, "level0": (4180 * 2 + 12290) * 1024,
-                     "level1": (11220 * 2 + 30820) * 1024, "level2": (32940 * 2 + 4175) * 1024}
+PMC_TRAFFIC_BYTES = {"face": (1920 * 2 + 256) * 1024, "level0": (4178 * 2 + 12290) * 1024,
+                     "level1": (8516 * 2 + 24580) * 1024, "level2": (30730 * 2 + 4284) * 1024}
 KERNEL_NAMES = ["posebias", "face", "level0", "level1", "level2"]
 # full THA4 system (mode_07), SURVEY.md §8d: FlopCounterMode on the reference modules
 GFLOP_FULL_COLD = 645.90
