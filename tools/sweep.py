@@ -17,8 +17,11 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "p842": ["-DTHA4_L216P_CFG=8,4,2"],
-    "l1_pg2": ["-DTHA4_L116_CFG=4,1,2,1,1"],
+    "l2stream": ["-DTHA4_L2_RESIDENT=0"],
+    "l1_422": ["-DTHA4_L116_CFG=4,2,2,1,1"],
+    "l0_243": ["-DTHA4_L016_CFG=2,4,2,3,1"],
+    "face_242": ["-DTHA4_FACE16_CFG=2,4,2,2"],
+    "nosin": ["-DTHA4_ABLATE_SIN"],
 }
 
 
