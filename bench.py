@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gather of finished frames")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--profile-frames", type=int, default=100, help="frames for the per-kernel HIP-event pass")
+    ap.add_argument("--d2h-frames", type=int, default=500, help="frames for the secondary RGBA8 + D2H inclusive measurement (0 = skip)")
     args = ap.parse_args()
     if args.model == "full":
         if args.steps == 2000:
@@ -250,6 +251,23 @@ def main():
                     "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
                     "whole_frame_frac": round(fps / world * GFLOP_FRAME / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
                     "algorithmic_gflop_per_frame": GFLOP_FRAME, "executed_gflop_per_frame": GFLOP_EXECUTED_FRAME}
+        # SURVEY.md §8d config 2 also asks for the rate with the display epilogue + D2H of the RGBA8 frame included (what a
+        # puppeteer actually consumes): pose -> tha4_display_rgba8 -> async copy into a pinned ring, same stream.  Never `value`.
+        d2h = None
+        if world == 1 and B == 1 and args.d2h_frames > 0:
+            from tha4_amd import image_io
+            ring = [torch.empty((1, 512, 512, 4), dtype=torch.uint8).pin_memory() for _ in range(4)]
+            with torch.no_grad():
+                for i in range(8):
+                    ring[i % 4].copy_(image_io.to_display_rgba8(poser.pose(image, poses[W + i])), non_blocking=True)
+                torch.cuda.synchronize(dev)
+                t0d = time.perf_counter()
+                for i in range(args.d2h_frames):
+                    ring[i % 4].copy_(image_io.to_display_rgba8(poser.pose(image, poses[W + (i % K)])), non_blocking=True)
+                torch.cuda.synchronize(dev)
+                dtd = time.perf_counter() - t0d
+            d2h = {"fps": round(args.d2h_frames / dtd, 2), "frames": args.d2h_frames,
+                   "what": "pose + sRGB/uint8 display epilogue + async D2H of the 1 MiB RGBA8 frame into pinned host memory (PCIe-inclusive)"}
         cpu = cpu_baseline(w, image_np, poses_cpu, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
         full = None
         if args.full_frames > 0 and world == 1:
@@ -269,7 +287,7 @@ def main():
                        "frames_per_gpu": K * B, "batch": B, "parallelism": f"frame-parallel x{world}",
                        "gather": bool(world > 1 and not args.no_gather and B == 1)},
             "per_gpu_fps": round(fps / world, 2),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "with_rgba8_d2h": d2h,
             "full_model": full,
         }
         print(json.dumps(result), flush=True)

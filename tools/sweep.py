@@ -17,10 +17,10 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "l2stream": ["-DTHA4_L2_RESIDENT=0"],
-    "l1_422": ["-DTHA4_L116_CFG=4,2,2,1,1"],
-    "l0_243": ["-DTHA4_L016_CFG=2,4,2,3,1"],
-    "face_242": ["-DTHA4_FACE16_CFG=2,4,2,2"],
+    "nofetch": ["-DTHA4_ABLATE_FETCH"],
+    "nobarrier": ["-DTHA4_ABLATE_BARRIER"],
+    "nofetch_nobarrier": ["-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER"],
+    "nomfma": ["-DTHA4_ABLATE_MFMA"],
     "nosin": ["-DTHA4_ABLATE_SIN"],
 }
 
