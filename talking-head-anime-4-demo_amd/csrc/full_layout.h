@@ -204,6 +204,7 @@ struct TilePlan {
 };
 inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TMB, int mtiles, int nq, int want_wgs = 256) {
   TilePlan best;
+  if (std::getenv("THA4_WANT_WGS")) want_wgs = std::atoi(std::getenv("THA4_WANT_WGS"));   // tuning aid
   const int kmax = std::getenv("THA4_KSPLIT_MAX") ? std::atoi(std::getenv("THA4_KSPLIT_MAX")) : 16;   // tuning aid
   const int min_nq = std::getenv("THA4_KSPLIT_MIN_NQ") ? std::atoi(std::getenv("THA4_KSPLIT_MIN_NQ")) : 0;   // tuning aid
   float best_eff = 0.f;
