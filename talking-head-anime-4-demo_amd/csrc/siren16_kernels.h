@@ -549,7 +549,8 @@ template <int WAVES, int PGW, int PG>
 struct Level2PCfg {
   static constexpr int kHidden = kNB2 * kKG2;                         // pieces of one 96->96 layer
   static constexpr int kPieces = 2 * kHidden + kKG2;                  // + head (1 block x 3 groups)
-  static constexpr int LDS = kPieces * 2048;
+  static constexpr int kWeightBytes = kPieces * 2048;
+  static constexpr int LDS = kWeightBytes + 16;                       // + the strip ticket counter
   static constexpr int THREADS = WAVES * 64;
   static constexpr int PX = WAVES * PGW * PG * 16;
   using G = Geo16<WAVES, 1, PG, kKG2, 1>;
@@ -564,14 +565,20 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   THA4_DYN_LDS(smem);
   const WaveCtx w = wave_ctx<G>();
   fetch_pieces<2 * Cfg::kPieces, WAVES>(reinterpret_cast<const char*>(d.w_l2), smem, w.wave, w.lane);
+  // Strips are handed out dynamically: a wave that hits slow image gathers in its warp epilogue does not hold the
+  // workgroup back (static assignment: the slowest wave finished ~22 k cycles after the mean).  Which wave computes a
+  // strip does not change its bytes.
+  int* ticket = reinterpret_cast<int*>(smem + Cfg::kWeightBytes);
+  if (threadIdx.x == 0) *ticket = WAVES;                               // strips 0..WAVES-1 are taken statically
   __syncthreads();
   const char* w1 = smem + w.lane * 16;
   const char* w2 = w1 + (size_t)Cfg::kHidden * 2048;
   const char* w3 = w2 + (size_t)Cfg::kHidden * 2048;
   const int g4 = (w.lane >> 4) * 4;
+  const int strip0 = xcd_tile(blockIdx.x, gridDim.x) * PGW * WAVES;
 #pragma unroll 1
-  for (int k = 0; k < PGW; ++k) {
-    const int strip = (xcd_tile(blockIdx.x, gridDim.x) * PGW + k) * WAVES + w.wave;   // the WAVES waves work on adjacent strips
+  for (int k = w.wave; k < PGW * WAVES; k = wave_take_ticket(ticket, w.lane)) {
+    const int strip = strip0 + k;
     const int n = strip / STRIPS;
     int pix0[PG], X0[PG], Y[PG];
     float px[PG], py[PG];

@@ -49,6 +49,12 @@ THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 THA4_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the next value of a workgroup-shared LDS counter, fetched by lane 0 and broadcast to the wave
+THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {
+  int v = 0;
+  if (lane == 0) v = atomicAdd(lds_counter, 1);
+  return __builtin_amdgcn_readfirstlane(v);
+}
 THA4_DEV float lane_read(float v, int src_lane) { return __shfl(v, src_lane, 64); }
 #else
 THA4_DEV void glds16(const void* gsrc_lane, void* lds_base_uniform) { emu::glds16(gsrc_lane, lds_base_uniform); }
@@ -65,6 +71,11 @@ THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
   return f32x4{r[0], r[1], r[2], r[3]};
 }
 THA4_DEV int uniform_i32(int v) { return v; }
+THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {      // fibers run one at a time: a plain read-modify-write
+  float v = 0.f;
+  if (lane == 0) { v = (float)*lds_counter; *lds_counter += 1; }
+  return (int)emu::shfl(v, 0);                                   // tickets are small integers: exact in fp32
+}
 THA4_DEV float lane_read(float v, int src_lane) { return emu::shfl(v, src_lane); }
 #endif
 
