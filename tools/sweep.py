@@ -17,11 +17,7 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "nofetch": ["-DTHA4_ABLATE_FETCH"],
-    "nobarrier": ["-DTHA4_ABLATE_BARRIER"],
-    "nofetch_nobarrier": ["-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER"],
-    "nomfma": ["-DTHA4_ABLATE_MFMA"],
-    "nosin": ["-DTHA4_ABLATE_SIN"],
+    "p881": ["-DTHA4_L216P_CFG=8,8,1"],
 }
 
 
