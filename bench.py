@@ -117,12 +117,33 @@ def measure_full(dev, image, frames, batch=1):
     return out
 
 
+def cpu_baseline_full(image, budget_s):
+    """CPU path of the full model beside the GPU path: the oracle's torch-functional restatement of mode_07 (same ATen
+    ops, every frame cold as the reference would be for a new image), fp32, all host cores, bounded sample."""
+    from oracle import full_oracle as fo
+    from tha4_amd import synthetic
+    w = synthetic.synth_full_weights()
+    poses = make_poses(4, seed=77).numpy()
+    fo.full_forward_torch(w, image, poses[0], "float32")              # warm-up
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        fo.full_forward_torch(w, image, poses[n % 4], "float32")
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 16:
+            break
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} cold frames, oracle.full_forward_torch fp32, synthetic weights ({dt:.1f} s)", "ms_per_frame": round(1e3 * dt / n, 1)}
+
+
 def main_full(args):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     _, image_np = load_fixture()
     image = torch.from_numpy(image_np).to(dev)
     r = measure_full(dev, image, args.steps, max(1, args.batch))
+    cpu = cpu_baseline_full(image_np, args.cpu_seconds) if args.cpu_seconds > 0 else None
     print(json.dumps({
         "metric": "frames/sec on 512x512 RGBA + 45-dim pose, full THA4 model", "value": r["steady"]["fps"], "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": 3, "ms_per_step": round(r["steady"]["ms_per_frame"] * max(1, args.batch), 3), "higher_is_better": True,
@@ -135,7 +156,7 @@ def main_full(args):
                      "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate (k > 1 convolutions)",
                      "traffic": None,
                      "algorithmic_gflop_per_frame": GFLOP_FULL_STEADY},
-        "cold": r["cold"], "cpu_baseline": None}), flush=True)
+        "cold": r["cold"], "cpu_baseline": cpu}), flush=True)
 
 
 def main():
