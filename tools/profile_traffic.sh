@@ -4,7 +4,7 @@ set -x
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-B="python $R/bench.py --steps 100 --warmup 20 --cpu-seconds 0 --profile-frames 5 --full-frames 0"
+B="python $R/bench.py --steps 100 --warmup 20 --cpu-seconds 0 --profile-frames 5 --full-frames 0 --d2h-frames 0"
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pt_fetch -- $B > $R/gpurun_out/pt_fetch.log 2>&1
 timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pt_write -- $B > $R/gpurun_out/pt_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pf_stats -- python $R/tools/time_full.py > $R/gpurun_out/pf_stats.log 2>&1
