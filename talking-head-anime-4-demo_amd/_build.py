@@ -33,7 +33,7 @@ def hipcc_path() -> str:
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
     deps = [os.path.join(CSRC, f) for f in SOURCES + _headers()] + [os.path.join(INCLUDE, "tha4_hip.h")]
-    if not force and not _stale(LIB, deps):
+    if not force and not _stale(LIB, deps) and os.path.exists(RESOURCES):
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
            "-I", CSRC, "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
