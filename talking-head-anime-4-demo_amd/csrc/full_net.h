@@ -305,8 +305,8 @@ class FullModel {
           if (ksplit > 1) {
             c.phase = 1;
             dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, ksplit), lds, f.stream);
-            c.phase = 2;
-            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, 1), lds, f.stream);
+            c.phase = 2;                       // one output block per workgroup: 4x the workgroups, a quarter of the load rounds each
+            dispatch_tile(1, pg, in_mode, c, dim3(f.batch * tiles, mtiles * tmb, 1), lds, f.stream);
           } else {
             dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, 1), lds, f.stream);
           }

@@ -114,7 +114,8 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     const int phases = tiled && ksplit > 1 ? 2 : 1;
     for (int ph = 0; ph < phases; ++ph) {
     a.phase = phases == 1 ? 0 : ph + 1;
-    dim3 grid(n * tiles_per_class, mtiles, a.phase == 1 ? ksplit : 1);
+    const int run_tmb = a.phase == 2 ? 1 : tmb;          // phase 2 runs one output block per workgroup
+    dim3 grid(n * tiles_per_class, a.phase == 2 ? nb : mtiles, a.phase == 1 ? ksplit : 1);
     for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -126,12 +127,12 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   }
         RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
 #define RUNT(TM, PGV)                                                                                                          \
-  if (tiled && tmb == TM && tpg == PGV) {                                                                                       \
+  if (tiled && run_tmb == TM && tpg == PGV) {                                                                                       \
     if (in_mode == IN_DIRECT) emu::run_block(conv_tile_kernel<TM, PGV, IN_DIRECT>, grid, dim3(bx, by, bz), kTileThreads, lds, a);    \
     else if (in_mode == IN_UP2) emu::run_block(conv_tile_kernel<TM, PGV, IN_UP2>, grid, dim3(bx, by, bz), kTileThreads, lds, a);     \
     else emu::run_block(conv_tile_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by, bz), kTileThreads, lds, a);                          \
   }
-        RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 2) RUNT(1, 1)
+        RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 4) RUNT(1, 2) RUNT(1, 1)
 #undef RUNT
         if (splitk && tmb == 4) {
           if (in_mode == IN_DIRECT) emu::run_block(conv_splitk_kernel<4, IN_DIRECT>, grid, dim3(bx, by), 256, lds, a);
