@@ -262,23 +262,21 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   }
 
   // ---- split-K: phase 1 publishes the partial fragments, phase 2 adds them in split order ----------------
-  if (a.phase != 0) {
+  if (PG < 4 && a.phase != 0) {      // the planner never splits K with the largest tile (its registers are all spoken for)
     const size_t frag = (size_t)kTileWaves * PG * 64;                         // f32x4 fragments per output block
     // partial layout [split][frame][output block][tile][fragment]: indexed by the OUTPUT BLOCK, not by (m-tile, b), so
     // that phase 2 can run with one output block per workgroup (TMB = 1: 4x the workgroups, a quarter of the serial
     // load rounds each) on partials written by a TMB = 4 phase 1
-    const size_t blocks_total = (size_t)a.batch * a.nb * tiles_per_frame;
-    auto part_index = [&](int split, int b) -> size_t {
-      return ((size_t)split * blocks_total + ((size_t)n * a.nb + (size_t)mtile * TMB + b) * tiles_per_frame + tile) * frag +
-             (size_t)(wave * PG) * 64 + lane;
-    };
-    f32x4* part = reinterpret_cast<f32x4*>(a.partial);
+    const size_t stride_split = (size_t)a.batch * a.nb * tiles_per_frame * frag;      // wave-uniform strides (f32x4 units)
+    const size_t stride_block = (size_t)tiles_per_frame * frag;
+    f32x4* part = reinterpret_cast<f32x4*>(a.partial) + (((size_t)n * a.nb + (size_t)mtile * TMB) * tiles_per_frame + tile) * frag +
+                  (size_t)(wave * PG) * 64 + lane;      // this lane's fragment of output block mtile*TMB, split 0, pixel group 0
     if (a.phase == 1) {
 #pragma unroll
       for (int b = 0; b < TMB; ++b)
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg)
-          part[part_index(ks, b) + (size_t)pg * 64] = acc[b][pg];
+          part[(size_t)ks * stride_split + (size_t)b * stride_block + (size_t)pg * 64] = acc[b][pg];
       THA4_CSTAMP();                                       // partials written
       return;
     }
@@ -292,7 +290,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         for (int k2 = 0; k2 < 16; ++k2) {
           // branch-free: splits past the last one re-read it and are zeroed by a select, so no load waits on a branch
           const int kc = min(k2, a.ksplit - 1);
-          const f32x4 ld = part[part_index(kc, b) + (size_t)pg * 64];
+          const f32x4 ld = part[(size_t)kc * stride_split + (size_t)b * stride_block + (size_t)pg * 64];
           const float keep = k2 < a.ksplit ? 1.0f : 0.0f;
           v[k2] = ld * keep;
         }

@@ -229,12 +229,12 @@ inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TM
   if (pick(2) && best.geom.tiles * mtiles >= want_wgs / 2) return best;
   // 2) small maps: the largest tile whose K groups can still be spread over the chip
   best.ok = false;
-  for (int pg : {4, 2, 1})
+  for (int pg : {2, 1})            // K split is compiled out of the PG = 4 kernel
     if (pick(pg) && (long)best.geom.tiles * mtiles * std::min(nq, kmax) >= want_wgs) break;
   if (!best.ok) return best;
   const int wgs = best.geom.tiles * mtiles;
   int ksplit = 1;
-  if (wgs < want_wgs / 2 && nq >= min_nq) {
+  if (wgs < want_wgs / 2 && nq >= min_nq && best.pg < 4) {
     const int want = std::min(std::min(nq, kmax), (want_wgs + wgs - 1) / wgs);
     const int per = (nq + want - 1) / want;
     ksplit = (nq + per - 1) / per;                     // every split gets at least one K group
