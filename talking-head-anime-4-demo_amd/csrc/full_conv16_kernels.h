@@ -1,26 +1,28 @@
-// Tiled implicit-GEMM convolution, second generation (feature maps >= 64x64 of the full THA4 system).
+// Tiled implicit-GEMM convolution, second generation: every k > 1 convolution of the full THA4 system.
 //
 // conv_mfma_kernel (full_kernels.h) re-forms its im2col operand for EVERY tap and output tile - scale/shift,
 // activation, padding select and 64-bit address arithmetic per 16-byte load - and multiplies with exact-fp32
 // v_mfma_f32_16x16x4_f32 (32 cycles per 4-deep k step).  Here
 //   * a workgroup (8 waves) owns a TH x TW block of output positions and TMB output blocks; per 32-channel K group
-//     it stages the (TH*s + halo) x (TW*s + halo) input window ONCE into LDS, already normalised, activated,
-//     resampled (nearest-up / avg-pool), zero padded and split into fp16 hi + fp16 lo (v = hi + lo, 22 bits);
-//   * all taps then read their B fragments from that window at a constant LDS offset per tap, the weights stream
-//     through a 2..4-slot LDS ring (as deep as the LDS left by the window allows: workgroups with only 1-2 K groups
-//     - the K-split small maps - then have ALL their weight chunks in flight from the start) as fp16 hi/lo fragment pieces (pre-scaled by a power of two so small weights keep
-//     their low half out of the fp16 subnormal range), and every 32-deep k step costs three
-//     v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, 48 cycles instead of 256) into one fp32 accumulator;
+//     it stages the (TH*s + halo) x (TW*s + halo) input window ONCE into LDS, already normalised, activated
+//     (SiLU on v_exp_f32 / v_rcp_f32), resampled (nearest-up / avg-pool), zero padded and split into fp16 hi + fp16 lo
+//     (v = hi + lo, 22 bits);
+//   * all taps then read their B fragments from that window at a constant LDS offset per tap; the weights stream
+//     through a 2..4-slot LDS ring (as deep as the LDS left by the window allows without costing occupancy) as fp16
+//     hi/lo fragment pieces, pre-scaled by a power of two so that small weights keep their low half out of the fp16
+//     subnormal range; every 32-deep k step costs three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, 48 cycles
+//     instead of 256) into one fp32 accumulator;
 //   * the window of K group Q+1 is loaded into registers under the MFMAs of group Q;
 //   * small maps (16x16 .. 48x48 with 256-512 channels) do not have enough output tiles to fill 256 CUs, and a
 //     pixel-tiled grid would re-read every weight once per tile: there blockIdx.z splits the K groups instead
-//     (phase 1: every workgroup writes its fp32 partial fragments to a workspace) and a second launch of the same
-//     kernel (phase 2, one workgroup per output tile) adds the partials in split order and runs the epilogue.
-//     Every weight is read exactly once per frame.  (A single-launch "last workgroup reduces" variant was measured
-//     slower: the agent-scope release/acquire it needs writes back and invalidates the per-XCD L2s.)
+//     (phase 1: every workgroup writes its fp32 partial fragments to a workspace indexed by output block) and a second
+//     launch of the same kernel with ONE output block per workgroup (phase 2) adds the partials in split order and
+//     runs the epilogue.  Every weight is read exactly once per frame.  (A single-launch "last workgroup reduces"
+//     variant is far slower on this chip: tools/microbench/last_arrival.hip.)  Not compiled into the PG = 4 kernel;
 //   * tile grids need not divide the map: positions outside it are computed on zero padding and masked at the store.
 // Numerics: products are exact in fp32; dropped lo*lo terms and the rounding of the lo halves are ~2^-22 relative,
-// four times the fp32 rounding the reference itself commits per product (tests: 2e-5 abs on O(1) outputs).
+// four times the fp32 rounding the reference itself commits per product (tests: 3e-5 abs on O(1) outputs).
+// tools/phase_timing_full.py (-DTHA4_PHASE_TIMING) prints the cycle budget of a K group from in-kernel stamps.
 //
 // K-slot permutation: lane group g = lane>>4 holds, in its 8 k-slots, channels 4g..4g+3 of quad 2Q (j<4) and of quad
 // 2Q+1 (j>=4), i.e. exactly the two 16-byte C16 loads a staging thread makes for one (pixel, g); the weight
