@@ -218,7 +218,7 @@ def main():
                 base = rank * K
                 blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
                 for i in range(lo, hi):
-                    blk[i - lo].copy_(poser.pose(image, poses[W + i - base])[0])
+                    poser.pose(image, poses[W + i - base], out=blk[i - lo:i - lo + 1])    # straight into the gather block
                 return blk
 
             stream = FrameShardedStream(frame_fn, total=K * world, frame_shape=(4, 512, 512), dtype=torch.float32,

@@ -92,11 +92,16 @@ class HipStudentPoser(Poser):
         self._ensure_handle(self._max_batch)
         return self._state_dicts
 
-    def pose(self, image: Tensor, pose: Tensor, output_index: Optional[int] = None) -> Tensor:
+    def pose(self, image: Tensor, pose: Tensor, output_index: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+        """Reference signature plus an optional ``out`` (extension; output 0 only): a contiguous float32 ``[B,4,512,512]``
+        device tensor the posed frames are written into directly - e.g. a row block of a gather buffer - instead of a
+        fresh allocation."""
         if output_index is None:
             output_index = self.default_output_index
         if output_index == 0:
-            return self._run(image, pose, all_outputs=False)[0]
+            return self._run(image, pose, all_outputs=False, out=out)[0]
+        if out is not None:
+            raise AssertionError("`out` is only supported for output_index 0")
         return self.get_posing_outputs(image, pose)[output_index]
 
     def get_posing_outputs(self, image: Tensor, pose: Tensor) -> List[Tensor]:
@@ -171,12 +176,18 @@ class HipStudentPoser(Poser):
                 raise AssertionError(f"{name} is on {t.device}, poser is on {self.device}")
         return image.contiguous(), pose.contiguous(), b
 
-    def _run(self, image: Tensor, pose: Tensor, all_outputs: bool) -> List[Tensor]:
+    def _run(self, image: Tensor, pose: Tensor, all_outputs: bool, out: Optional[Tensor] = None) -> List[Tensor]:
         image, pose, b = self._check_inputs(image, pose)
         self._ensure_handle(b)
         dev = self._device_index()
         opts = dict(dtype=torch.float32, device=image.device)
-        blended = torch.empty((b, 4, IMAGE_SIZE, IMAGE_SIZE), **opts)
+        if out is not None:
+            if (tuple(out.shape) != (b, 4, IMAGE_SIZE, IMAGE_SIZE) or out.dtype != torch.float32 or out.device != image.device
+                    or not out.is_contiguous()):
+                raise AssertionError(f"out must be a contiguous float32 [{b},4,{IMAGE_SIZE},{IMAGE_SIZE}] tensor on {image.device}")
+            blended = out
+        else:
+            blended = torch.empty((b, 4, IMAGE_SIZE, IMAGE_SIZE), **opts)
         outs = [blended]
         aux_ref = None
         if all_outputs:

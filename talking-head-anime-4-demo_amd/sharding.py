@@ -89,16 +89,27 @@ class FrameShardedStream:
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 send.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
-                recv = [self._empty(self.chunk) for _ in range(self.world)] if self.rank == 0 else None
-                dist.gather(send, recv, dst=dst, group=self.group)
+                recv, tails = None, []
                 if self.rank == 0:
+                    # full chunks land directly in their rows of `result` (no staging copy on the root, which also
+                    # has its own frames to compute); only a rank's ragged last chunk goes through a temporary
+                    recv = []
                     for r in range(self.world):
                         rlo, rhi = shard_bounds(self.total, r, self.world)
                         ra = min(rlo + c * self.chunk, rhi)
                         rb = min(ra + self.chunk, rhi)
+                        if rb - ra == self.chunk:
+                            recv.append(result[ra:rb])
+                        else:
+                            tmp = self._empty(self.chunk)
+                            recv.append(tmp)
+                            tails.append((tmp, ra, rb))
+                dist.gather(send, recv, dst=dst, group=self.group)
+                if self.rank == 0:
+                    for tmp, ra, rb in tails:
                         if rb > ra:
-                            result[ra:rb] = recv[r][:rb - ra]
-                    keep.append(recv)
+                            result[ra:rb] = tmp[:rb - ra]
+                    keep.append(tails)
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
         return result

@@ -225,3 +225,20 @@ def test_config4_batch32_shared_image(poser, dev, golden_io, golden_weights):
         assert torch.equal(out[i], poser.pose(image, poses[i])[0])
     ref = so.student_forward_torch(golden_weights, golden_io["image_f32"], poses_np[[0, 31]], "float32")[0].numpy()
     assert np.abs(out[[0, 31]].cpu().numpy() - ref).max() <= TOL_OUT0
+
+
+@pytest.mark.gpu
+def test_pose_writes_into_caller_buffer(poser, dev, golden_io):
+    """`out=` extension: frames land directly in a row block of a larger (gather) buffer, bitwise equal to a fresh pose"""
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    poses = torch.from_numpy(golden_io["poses"][:3]).to(dev)
+    block = torch.full((5, 4, 512, 512), 7.0, device=dev)
+    for i in range(3):
+        r = poser.pose(image, poses[i], out=block[i + 1:i + 2])
+        assert r.data_ptr() == block[i + 1].data_ptr()
+        assert torch.equal(block[i + 1], poser.pose(image, poses[i])[0])
+    assert float(block[0].min()) == 7.0 and float(block[4].max()) == 7.0          # neighbours untouched
+    with pytest.raises(AssertionError):
+        poser.pose(image, poses[0], out=block[:, :, ::2])                          # wrong shape / not contiguous
+    with pytest.raises(AssertionError):
+        poser.pose(image, poses[0], output_index=1, out=block[0:1])
