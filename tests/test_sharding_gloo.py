@@ -40,7 +40,7 @@ def _worker(rank, world, port, total, chunk, gather, q):
         return torch.stack([_frame(i) for i in range(lo, hi)])
 
     s = FrameShardedStream(frame_fn, total, (2, 4, 4), torch.float32, torch.device("cpu"), chunk=chunk, gather=gather)
-    out = s.run()
+    out = s.run(s.allocate_result()) if total % 2 else s.run()      # both entry points: caller-provided / internal buffer
     q.put((rank, s.local_range(), calls, None if out is None else out.clone()))
     dist.barrier()
     dist.destroy_process_group()
@@ -106,3 +106,14 @@ def test_single_process_path():
     out = FrameShardedStream(lambda lo, hi: torch.stack([_frame(i) for i in range(lo, hi)]), 5, (2, 4, 4),
                              torch.float32, torch.device("cpu"), chunk=2).run()
     assert out.shape == (5, 2, 4, 4) and torch.equal(out[4], _frame(4))
+
+
+def test_preallocated_result_is_validated():
+    s = FrameShardedStream(lambda lo, hi: torch.stack([_frame(i) for i in range(lo, hi)]), 5, (2, 4, 4), torch.float32,
+                           torch.device("cpu"), chunk=2)
+    buf = s.allocate_result()
+    out = s.run(buf)
+    assert out.data_ptr() == buf.data_ptr() and torch.equal(out[3], _frame(3))
+    import pytest
+    with pytest.raises(RuntimeError):
+        s.run(torch.empty(4, 2, 4, 4))
