@@ -25,6 +25,23 @@ def golden_io():
     return {k: z[k] for k in z.files}
 
 
+CHARACTERS = ["lambda_00", "lambda_01"]      # both students the reference ships (data/character_models/)
+
+
+@pytest.fixture(scope="session")
+def char_weights():
+    return {c: dict(np.load(os.path.join(GOLDEN, f"student_{c}_weights.npz"))) for c in CHARACTERS}
+
+
+@pytest.fixture(scope="session")
+def char_io():
+    out = {}
+    for c in CHARACTERS:
+        z = np.load(os.path.join(GOLDEN, f"student_{c}_io.npz"))
+        out[c] = {k: z[k] for k in z.files}
+    return out
+
+
 @pytest.fixture(scope="session")
 def built():
     """Make sure the native pieces exist (hipcc cross-compiles without a GPU)."""

@@ -4,7 +4,9 @@ reference (imported read-only from /root/reference/src) on CPU.
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [lambda_00|lambda_01]     (default lambda_00)
+
+Both shipped students are covered; `student_<name>_*.npz` have the same layout.
 
 Writes (all under tests/golden/):
   student_lambda_00_weights.npz   the two shipped state_dicts, flattened to fp32 arrays
@@ -18,7 +20,7 @@ Writes (all under tests/golden/):
                                     ref64_sub_out{0..5}    [3 poses] same subset, reference modules .double(), rounded to fp32 for storage
   student_lambda_00_noise.json    the reference's own noise floor (1 vs N threads, fp32 vs fp64)
 
-Data licence: the lambda_00 character image and student weights are (c) Pramook Khungurn,
+Data licence: the lambda_00 / lambda_01 character images and student weights are (c) Pramook Khungurn,
 CC BY-NC 4.0 (reference README.md:273-274, data/images/README.md).
 """
 import json
@@ -45,7 +47,9 @@ N_REF = 3
 
 
 def main():
-    cm = os.path.join(REF, "data/character_models/lambda_00")
+    name = sys.argv[1] if len(sys.argv) > 1 else "lambda_00"
+    assert name in ("lambda_00", "lambda_01"), name
+    cm = os.path.join(REF, "data/character_models", name)
     files = {"face_morpher": os.path.join(cm, "face_morpher.pt"),
              "body_morpher": os.path.join(cm, "body_morpher.pt")}
     poser = create_poser(torch.device("cpu"), module_file_names=dict(files))
@@ -56,7 +60,7 @@ def main():
 
     mods = poser.get_modules()
     w = state_dicts_to_numpy(mods["face_morpher"].state_dict(), mods["body_morpher"].state_dict())
-    np.savez(os.path.join(HERE, "student_lambda_00_weights.npz"), **w)
+    np.savez(os.path.join(HERE, f"student_{name}_weights.npz"), **w)
 
     io = {"image_rgba8": rgba8, "image_f32": image.numpy(), "poses": poses}
     torch.set_num_threads(8)
@@ -86,7 +90,7 @@ def main():
                           for o in poser.get_posing_outputs(image.double(), torch.from_numpy(poses[i]).double())])
     for k in range(6):
         io[f"ref64_sub_out{k}"] = np.stack([r[k][:, SUB, SUB] for r in ref64]).astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, "student_lambda_00_io.npz"), **io)
+    np.savez_compressed(os.path.join(HERE, f"student_{name}_io.npz"), **io)
 
     names = ["blended", "alpha", "color_change", "warped", "grid_change", "face"]
     noise = {"torch": torch.__version__, "threads": 8, "poses": N_REF,
@@ -94,7 +98,7 @@ def main():
                                       for k in range(6)},
              "fp32_vs_fp64_maxabs": {names[k]: float(max(np.abs(ref32[i][k] - ref64[i][k]).max() for i in range(N_REF)))
                                      for k in range(6)}}
-    with open(os.path.join(HERE, "student_lambda_00_noise.json"), "w") as f:
+    with open(os.path.join(HERE, f"student_{name}_noise.json"), "w") as f:
         json.dump(noise, f, indent=1)
     print(json.dumps(noise, indent=1))
 

@@ -12,7 +12,9 @@ NAMES = ["blended", "alpha", "color_change", "warped", "grid_change", "face"]
 TOL32 = [6e-4, 1e-4, 2e-4, 2.5e-3, 2e-5, 6e-5]
 
 
-def test_torch_restatement_matches_reference_fp32(golden_weights, golden_io):
+@pytest.mark.parametrize("character", ["lambda_00", "lambda_01"])
+def test_torch_restatement_matches_reference_fp32(character, char_weights, char_io):
+    golden_weights, golden_io = char_weights[character], char_io[character]
     out = so.student_forward_torch(golden_weights, golden_io["image_f32"], golden_io["poses"][:3], "float32")
     full = out[0][0].numpy()
     assert np.abs(full - golden_io["ref32_full_out0"][0]).max() <= TOL32[0]
@@ -23,7 +25,9 @@ def test_torch_restatement_matches_reference_fp32(golden_weights, golden_io):
         assert np.abs(got - ref).max() <= TOL32[k], NAMES[k]
 
 
-def test_torch_restatement_matches_reference_fp64(golden_weights, golden_io):
+@pytest.mark.parametrize("character", ["lambda_00", "lambda_01"])
+def test_torch_restatement_matches_reference_fp64(character, char_weights, char_io):
+    golden_weights, golden_io = char_weights[character], char_io[character]
     # the reference's fp64 run keeps fp32 position grids (default-dtype identity theta) and, through
     # GridChangeApplier's cache, an fp32 warp base grid; the oracle mirrors the former, hence 5e-5 on
     # the two warp-dependent outputs and storage rounding (fixtures hold ref64 rounded to fp32) elsewhere

@@ -64,6 +64,67 @@ def test_output0_parity_vs_oracle_and_reference_fixture(poser, dev, golden_io, o
             assert np.abs(got[:, SUB, SUB] - golden_io["ref64_sub_out0"][i]).max() <= TOL_OUT0
 
 
+@pytest.mark.parametrize("character", ["lambda_00", "lambda_01"])
+def test_both_shipped_characters_vs_reference_fixtures(character, dev, char_weights, char_io):
+    """Both students the reference ships: all six outputs against the fixtures the UNMODIFIED
+    reference produced (tests/golden/make_golden.py) - guards the per-layer power-of-two weight scales of pack_layer16
+    against being tuned to one character."""
+    w, io = char_weights[character], char_io[character]
+    face, body = split_flat_weights(w)
+    p = mode_14.create_poser_from_state_dicts(dev, face, body)
+    image = torch.from_numpy(io["image_f32"]).to(dev)
+    n_ref = io["ref32_sub_out0"].shape[0]
+    for i in range(n_ref):
+        outs = p.get_posing_outputs(image, torch.from_numpy(io["poses"][i]).to(dev))
+        got0 = outs[0][0].cpu().numpy()
+        if i == 0:
+            assert np.abs(got0 - io["ref32_full_out0"][0]).max() <= TOL_OUT0
+        for k in range(6):
+            tol = TOL_OUT0 if k == 0 else TOL_AUX[k] * 1.5
+            got = outs[k][0].cpu().numpy()[:, SUB, SUB]
+            e32 = np.abs(got - io[f"ref32_sub_out{k}"][i]).max()
+            e64 = np.abs(got - io[f"ref64_sub_out{k}"][i]).max()
+            print(f"PARITY {character} pose {i} out{k}: vs ref fp32 {e32:.3e}  vs ref fp64 {e64:.3e}")
+            assert e32 <= tol, (character, i, k, e32)
+            if k == 0:
+                assert e64 <= TOL_OUT0
+    p.free()
+
+
+def test_create_poser_from_pt_files_and_character_model(dev, char_weights, char_io, tmp_path):
+    """The literal drop-in calls: mode_14.create_poser(device, module_file_names={...pt}) (character_model.py:23-33) and
+    CharacterModel.load(yaml).get_poser / get_character_image.  The .pt files are written here from the committed fixture
+    with torch.save of an OrderedDict of [O,I,1,1] conv kernels - the format of the reference's checkpoints (SURVEY.md
+    Appendix B; test_weights_ingest.py proves load_state_dict_file(reference .pt) == this fixture on the build box)."""
+    import collections
+    import PIL.Image
+    from tha4_amd.charmodel.character_model import CharacterModel
+    w, io = char_weights["lambda_01"], char_io["lambda_01"]
+    face, body = split_flat_weights(w)
+    d = tmp_path / "lambda_01"
+    d.mkdir()
+    for name, sd in (("face_morpher", face), ("body_morpher", body)):
+        od = collections.OrderedDict((k, torch.from_numpy(v.reshape(v.shape + (1, 1)) if v.ndim == 2 else v)) for k, v in sd.items())
+        torch.save(od, str(d / f"{name}.pt"))
+    PIL.Image.fromarray(io["image_rgba8"], "RGBA").save(str(d / "character.png"))
+    (d / "character_model.yaml").write_text("character_image_file_name: character.png\nface_morpher_file_name: face_morpher.pt\n"
+                                           "body_morpher_file_name: body_morpher.pt\n")
+    pose = torch.from_numpy(io["poses"][0]).to(dev)
+    p = mode_14.create_poser(dev, module_file_names={"face_morpher": str(d / "face_morpher.pt"), "body_morpher": str(d / "body_morpher.pt")})
+    out = p.pose(torch.from_numpy(io["image_f32"]).to(dev), pose)
+    assert np.abs(out[0].cpu().numpy() - io["ref32_full_out0"][0]).max() <= TOL_OUT0
+    cm = CharacterModel.load(str(d / "character_model.yaml"))
+    poser = cm.get_poser(dev)
+    image = cm.get_character_image(dev)                       # PNG -> tha4_ingest_rgba8 on the device
+    assert image.shape == (4, 512, 512) and image.device.type == "cuda"
+    assert np.abs(image.cpu().numpy() - io["image_f32"]).max() <= 2e-6
+    out2 = poser.pose(image, pose)
+    assert np.abs(out2[0].cpu().numpy() - io["ref32_full_out0"][0]).max() <= TOL_OUT0
+    assert cm.get_poser(dev) is poser
+    p.free()
+    poser.free()
+
+
 def test_all_six_outputs(poser, dev, golden_io, oracle32):
     image = torch.from_numpy(golden_io["image_f32"]).to(dev)
     outs = poser.get_posing_outputs(image, torch.from_numpy(golden_io["poses"][1]).to(dev))
