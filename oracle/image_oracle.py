@@ -1,8 +1,11 @@
 """CPU oracle for the image ingest / display epilogue rows.
 
-*** TEST INFRASTRUCTURE ONLY ***  Pinned by the committed reference fixture
-(tests/golden/student_lambda_00_io.npz holds the decoded RGBA8 character image AND the tensor the
-reference's ``extract_pytorch_image_from_PIL_image`` produced from it).
+*** TEST INFRASTRUCTURE ONLY ***  Parity status: PINNED BY LIVE REFERENCE.
+  * ingest: tests/golden/student_lambda_0{0,1}_io.npz hold the decoded RGBA8 character image AND the tensor the
+    reference's ``extract_pytorch_image_from_PIL_image`` produced from it;
+  * display: tests/golden/display_io.npz holds what the reference's ``convert_linear_to_srgb`` /
+    ``torch_linear_to_srgb`` (imported unmodified by tests/golden/make_golden_display.py) produce inside the
+    puppeteers' post-processing sequence, for five backgrounds (tests/test_image_io.py).
 
 Restated reference code (paths relative to /root/reference/src/tha4):
   shion/base/image_util.py:10-17,127-149,194-198   PIL RGBA8 -> fp32 poser input

@@ -57,6 +57,17 @@ def image_from_rgba8(rgba: Tensor) -> Tensor:
     return out[0] if squeeze else out
 
 
+def resize_PIL_image(pil_image, size=(512, 512)):
+    """Centre-crop to a square and Lanczos-resize, as the reference does for character images that are not already
+    512x512 (src/tha4/image_util.py:29-33; its default size is 256, the posers need 512).  Host-side PIL call: the
+    resampling kernel is PIL's, exactly as in the reference."""
+    import PIL.Image
+    w, h = pil_image.size
+    d = min(w, h)
+    r = ((w - d) // 2, (h - d) // 2, (w + d) // 2, (h + d) // 2)
+    return pil_image.resize(size, resample=PIL.Image.LANCZOS, box=r)
+
+
 def image_from_pil(pil_image, device: torch.device) -> Tensor:
     """PIL RGBA image -> poser input tensor [4,H,W] on `device` (the reference raises for non-RGBA character images,
     charmodel/character_model.py:38-39)."""
