@@ -13,6 +13,10 @@
  * Every function returns 0 on success or a negative tha4_status; nothing throws across the ABI.
  * `tha4_*_pose` never allocates, never synchronises and enqueues all work on the given stream
  * (callers bracket it with stream events exactly like full_manual_poser.py:388-398 does).
+ * A handle owns ONE workspace: consecutive calls on the same stream are ordered by the stream; when the stream
+ * differs from the previous call's, the new stream is made to wait (event, no host sync) for the work enqueued on
+ * the previous one.  A handle must not be used from two host threads at once (the reference is single-threaded,
+ * SURVEY.md §8b); use one handle per thread.
  */
 #ifndef THA4_HIP_H
 #define THA4_HIP_H
@@ -23,7 +27,7 @@
 extern "C" {
 #endif
 
-#define THA4_ABI_VERSION 1
+#define THA4_ABI_VERSION 2
 
 typedef enum tha4_status {
   THA4_OK = 0,
@@ -115,6 +119,13 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
                       const float* pose_dev, int batch, float* out_blended_dev,
                       const tha4_student_aux* aux, void* stream);
 
+/* Hot-swap of the character (the puppeteers' "load model" action,
+ * character_model_ifacialmocap_puppeteer.py:383-399 -> CharacterModel.get_poser, character_model.py:23-33): packs a new
+ * pair of student state_dicts and overwrites the parameter blob of the live handle IN PLACE - no device allocation,
+ * the workspace, max_batch, position axes and the handle itself stay valid.  Waits for pose calls in flight on the
+ * handle's device before copying (a rare, host-synchronous operation; `tha4_student_pose` itself never synchronises). */
+int tha4_student_set_weights(tha4_student* h, const tha4_student_weights* weights);
+
 /* Replaces: GeneralPoser02.free (general_poser_02.py:84-85).  NULL is a no-op. */
 void tha4_student_destroy(tha4_student* h);
 
@@ -156,11 +167,19 @@ typedef struct tha4_full tha4_full; /* opaque */
 int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
                      tha4_full** out);
 
+/* Same with the number of networks: 5 = mode_07; 3 = the reference's mode_12 (src/tha4/poser/modes/mode_12.py:169-202,
+ * the teacher of the face-morpher distillation, siren_face_morpher_00_trainer.py:23-26): eyebrow_decomposer ->
+ * eyebrow_morphing_combiner -> face_morpher only (weights->tensors[3], [4] are ignored).  Such a handle produces
+ * outputs 11..32 of the list below (mode_12's list = face_morpher 8 + combiner 8 + decomposer 6, mode_12.py:92-97). */
+int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
+                        int num_networks, tha4_full** out);
+
 /* Replaces: GeneralPoser02.get_posing_outputs -> FiveStepPoserComputationProtocol (mode_07.py:54-134).
  *   outputs_dev[i]  device pointer for output i of the reference's 33-entry list (order mode_07.py:126-132:
  *                   upscaler 0-4, face_morphed_full 5, body_morpher 6-10, face_morpher 11-18,
  *                   eyebrow_morphing_combiner 19-26, eyebrow_decomposer 27-32), fp32 NCHW [B,C,S,S];
- *                   NULL = not wanted.  outputs_dev[0] (the posed frame) is required.
+ *                   NULL = not wanted and not computed into caller memory; at least one must be given
+ *                   (e.g. the distiller asks for 0,1,2,3,5 only, siren_morpher_protocols_03.py:56-72).
  *   reuse_decomposer  non-zero: the image (and batch) is unchanged since the previous call on this handle,
  *                   reuse the cached eyebrow-decomposer result (the reference detects this with a
  *                   max|delta| device->host sync, mode_07.py:56-61; here the caller states it). */
@@ -169,6 +188,7 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
 
 void tha4_full_destroy(tha4_full* h);
 int tha4_full_max_batch(const tha4_full* h);
+int tha4_full_num_networks(const tha4_full* h);
 
 /* ------------------------------------------------------------------------------------------------
  * Callers / data formats either side of the path.  Stateless, device pointers.

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtha4_hip.so")
 
-THA4_ABI_VERSION = 1
+THA4_ABI_VERSION = 2
 STUDENT_EXACT_FP32 = 1
 
 c_float_p = C.POINTER(C.c_float)
@@ -91,6 +91,8 @@ def build_full_weights(state_dicts: Dict[str, Dict[str, np.ndarray]]):
     keep: list = []
     s = Tha4FullWeights()
     for i, net in enumerate(FULL_NETWORKS):
+        if net not in state_dicts:           # mode_12: the first three networks only
+            continue
         sd = state_dicts[net]
         arr = (Tha4NamedTensor * len(sd))()
         for j, (k, v) in enumerate(sd.items()):
@@ -156,6 +158,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.tha4_student_pose.restype = C.c_int
     lib.tha4_student_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                       C.POINTER(Tha4StudentAux), C.c_void_p]
+    lib.tha4_student_set_weights.restype = C.c_int
+    lib.tha4_student_set_weights.argtypes = [C.c_void_p, C.POINTER(Tha4StudentWeights)]
     lib.tha4_student_destroy.restype = None
     lib.tha4_student_destroy.argtypes = [C.c_void_p]
     lib.tha4_student_max_batch.restype = C.c_int
@@ -168,6 +172,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.tha4_student_last_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     lib.tha4_full_create.restype = C.c_int
     lib.tha4_full_create.argtypes = [C.POINTER(Tha4FullWeights), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.tha4_full_create_ex.restype = C.c_int
+    lib.tha4_full_create_ex.argtypes = [C.POINTER(Tha4FullWeights), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.tha4_full_num_networks.restype = C.c_int
+    lib.tha4_full_num_networks.argtypes = [C.c_void_p]
     lib.tha4_full_pose.restype = C.c_int
     lib.tha4_full_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
                                    C.c_void_p]
@@ -188,9 +196,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_create_ex", "tha4_student_pose", "tha4_student_destroy",
+    "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_create_ex", "tha4_student_pose", "tha4_student_set_weights", "tha4_student_destroy",
     "tha4_student_max_batch", "tha4_student_device", "tha4_student_set_timing", "tha4_student_last_ms",
-    "tha4_full_create", "tha4_full_pose", "tha4_full_destroy", "tha4_full_max_batch",
+    "tha4_full_create", "tha4_full_create_ex", "tha4_full_num_networks", "tha4_full_pose", "tha4_full_destroy", "tha4_full_max_batch",
     "tha4_display_rgba8", "tha4_ingest_rgba8",
 ]
 

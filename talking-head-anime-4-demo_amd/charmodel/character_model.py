@@ -32,6 +32,14 @@ class CharacterModel:
                 KEY_BODY_MORPHER: self.body_morpher_file_name})
         return self.poser
 
+    def load_into(self, poser):
+        """Extension: swap THIS character into an existing student poser without re-allocating anything on the device
+        (the puppeteers' "load model" action re-creates the poser, character_model_ifacialmocap_puppeteer.py:383-399;
+        with several characters served from one process the handle and workspace are reused instead)."""
+        poser.load_character({KEY_FACE_MORPHER: self.face_morpher_file_name, KEY_BODY_MORPHER: self.body_morpher_file_name})
+        self.poser = poser
+        return poser
+
     def get_character_image(self, device: torch.device):
         if self.character_image is None:
             import PIL.Image

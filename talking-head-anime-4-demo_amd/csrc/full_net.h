@@ -611,9 +611,13 @@ class FullModel {
 
   // ---- whole pipeline ------------------------------------------------------------------------------
   // Output order (mode_07.py:126-132): upscaler 0-4, face_morphed_full 5, body 6-10, face 11-18, combiner 19-26, decomposer 27-32
-  bool build(const WeightMap nets[5], int max_batch_, int sel) {
+  // num_nets = 5: mode_07 (all 33 outputs); num_nets = 3: mode_12 (mode_12.py:42-97: eyebrow_decomposer ->
+  // eyebrow_morphing_combiner -> face_morpher only; outputs 11..32 of the list below exist, 0..10 are never written)
+  int num_networks = 5;
+  bool build(const WeightMap nets[5], int max_batch_, int sel, int num_nets = 5) {
     max_batch = max_batch_;
     sel_index = sel;
+    num_networks = num_nets;
     static const int och[33] = {4, 1, 4, 2, 4, 4, 4, 1, 4, 2, 4, 4, 1, 4, 4, 1, 4, 4, 2, 4, 1, 4, 4, 1, 4, 4, 2, 4, 1, 4, 4, 1, 4};
     static const int osz[33] = {512, 512, 512, 512, 512, 512, 256, 256, 256, 256, 256, 192, 192, 192, 192, 192, 192, 192, 192,
                                 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
@@ -670,6 +674,11 @@ class FullModel {
         a.head = Wk(hd.off); a.in0 = Wk(face_in_nchw);
         for (int i = 0; i < 8; ++i) a.out[i] = f.out[11 + i];
       });
+    }
+    if (num_nets == 3) {
+      head_storage.clear();
+      finalize_scratch();
+      return error.empty();
     }
     // face_morphed_full / half (mode_07.py:93-103)
     image_op(ops, paste_face_kernel, 512 * 512, [=](const Frame& f, ImgArgs& a) { a.in0 = f.out[11]; a.out[0] = f.out[5]; });

@@ -45,6 +45,38 @@ struct DeviceGuard {
 
 constexpr int kNumKernels = 5;
 
+// One workspace per handle: two pose calls on DIFFERENT streams would race on it.  Calls on the same stream are ordered
+// by the stream; when the stream changes, an event recorded on the previous stream (at that moment: it covers the
+// previous call and anything enqueued there since) is waited for by the new one.  Nothing is recorded on the common
+// single-stream path.
+struct StreamOrder {
+  hipStream_t last = nullptr;
+  bool used = false;
+  hipEvent_t done = nullptr;
+  hipError_t enter(hipStream_t s) {
+    hipError_t e = hipSuccess;
+    if (used && s != last) {
+      if (!done) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(done, last);
+      if (e == hipSuccess) e = hipStreamWaitEvent(s, done, 0);
+    }
+    last = s;
+    used = true;
+    return e;
+  }
+  void destroy() {
+    if (done) (void)hipEventDestroy(done);
+    done = nullptr;
+  }
+};
+
+// device that owns a device pointer (-1: unknown) - the stateless image entry points have no handle to ask
+int device_of(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.device;
+}
+
 }  // namespace
 
 struct tha4_student {
@@ -58,6 +90,9 @@ struct tha4_student {
   hipEvent_t ev[kNumKernels + 1] = {};
   bool ev_valid = false;
   bool ev_recorded = false;
+  size_t blob_bytes = 0;
+  std::vector<float> pos128, pos256, pos512;   // position axes given at create (reused by tha4_student_set_weights)
+  StreamOrder order;                           // the handle's workspace is shared by consecutive calls
 };
 
 namespace {
@@ -99,6 +134,43 @@ hipError_t allow_lds(K kernel, int bytes) {
 
 }  // namespace
 
+
+namespace {
+struct StudentBlobOffsets {
+  size_t wf, w0, w1, w2, bf, b0, b1, b2, sf = 0, s0 = 0, s1 = 0, s2 = 0;
+  size_t wx[4], wy[4], b[4], wp[4], p128, p256, p512;
+};
+
+// pack the two state_dicts into the parameter blob (layout depends on the architecture only, never on the values:
+// tha4_student_set_weights overwrites the blob of a live handle in place)
+std::string build_student_blob(const tha4_student_weights* weights, bool exact, const std::vector<float>& pos128,
+                               const std::vector<float>& pos256, const std::vector<float>& pos512, BlobBuilder& bb,
+                               StudentBlobOffsets& o) {
+  StudentPacked p;
+  std::string err = pack_student(to_view(weights), p);
+  if (!err.empty()) return err;
+  const FirstLayerPack* fl[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
+  if (exact) {
+    o.wf = bb.add(p.w_face); o.w0 = bb.add(p.w_l0); o.w1 = bb.add(p.w_l1); o.w2 = bb.add(p.w_l2);
+    o.bf = bb.add(p.b_face); o.b0 = bb.add(p.b_l0); o.b1 = bb.add(p.b_l1); o.b2 = bb.add(p.b_l2);
+    for (int i = 0; i < 4; ++i) { o.wx[i] = bb.add(fl[i]->wx); o.wy[i] = bb.add(fl[i]->wy); }
+  } else {
+    v2::StudentPacked16 p16;
+    v2::pack_student16(to_view(weights), p, p16);
+    o.wf = bb.add(p16.w_face); o.w0 = bb.add(p16.w_l0); o.w1 = bb.add(p16.w_l1); o.w2 = bb.add(p16.w_l2);
+    o.bf = bb.add(p16.b_face); o.b0 = bb.add(p16.b_l0); o.b1 = bb.add(p16.b_l1); o.b2 = bb.add(p16.b_l2);
+    o.sf = bb.add(p16.s_face); o.s0 = bb.add(p16.s_l0); o.s1 = bb.add(p16.s_l1); o.s2 = bb.add(p16.s_l2);
+    for (int i = 0; i < 4; ++i) { o.wx[i] = bb.add(p16.wx[i]); o.wy[i] = bb.add(p16.wy[i]); }
+  }
+  for (int i = 0; i < 4; ++i) {
+    o.b[i] = bb.add(fl[i]->bias);
+    o.wp[i] = bb.add(fl[i]->wpose);
+  }
+  o.p128 = bb.add(pos128); o.p256 = bb.add(pos256); o.p512 = bb.add(pos512);
+  return std::string();
+}
+}  // namespace
+
 extern "C" {
 
 int tha4_abi_version(void) { return THA4_ABI_VERSION; }
@@ -123,10 +195,6 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(THA4_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library only contains gfx950 code");
 
-  StudentPacked p;
-  std::string err = pack_student(to_view(weights), p);
-  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, "not a mode_14 student: " + err);
-
   std::vector<float> pos128(128), pos256(256), pos512(512);
   exact_position_axis(128, pos128.data());
   exact_position_axis(256, pos256.data());
@@ -136,29 +204,11 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
     if (axes->axis256) std::memcpy(pos256.data(), axes->axis256, 256 * sizeof(float));
     if (axes->axis512) std::memcpy(pos512.data(), axes->axis512, 512 * sizeof(float));
   }
-
   const bool exact = (flags & THA4_STUDENT_EXACT_FP32) != 0;
   BlobBuilder bb;
-  size_t o_wf, o_w0, o_w1, o_w2, o_bf, o_b0, o_b1, o_b2, o_sf = 0, o_s0 = 0, o_s1 = 0, o_s2 = 0;
-  const FirstLayerPack* fl[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
-  size_t o_wx[4], o_wy[4], o_b[4], o_wp[4];
-  if (exact) {
-    o_wf = bb.add(p.w_face); o_w0 = bb.add(p.w_l0); o_w1 = bb.add(p.w_l1); o_w2 = bb.add(p.w_l2);
-    o_bf = bb.add(p.b_face); o_b0 = bb.add(p.b_l0); o_b1 = bb.add(p.b_l1); o_b2 = bb.add(p.b_l2);
-    for (int i = 0; i < 4; ++i) { o_wx[i] = bb.add(fl[i]->wx); o_wy[i] = bb.add(fl[i]->wy); }
-  } else {
-    v2::StudentPacked16 p16;
-    v2::pack_student16(to_view(weights), p, p16);
-    o_wf = bb.add(p16.w_face); o_w0 = bb.add(p16.w_l0); o_w1 = bb.add(p16.w_l1); o_w2 = bb.add(p16.w_l2);
-    o_bf = bb.add(p16.b_face); o_b0 = bb.add(p16.b_l0); o_b1 = bb.add(p16.b_l1); o_b2 = bb.add(p16.b_l2);
-    o_sf = bb.add(p16.s_face); o_s0 = bb.add(p16.s_l0); o_s1 = bb.add(p16.s_l1); o_s2 = bb.add(p16.s_l2);
-    for (int i = 0; i < 4; ++i) { o_wx[i] = bb.add(p16.wx[i]); o_wy[i] = bb.add(p16.wy[i]); }
-  }
-  for (int i = 0; i < 4; ++i) {
-    o_b[i] = bb.add(fl[i]->bias);
-    o_wp[i] = bb.add(fl[i]->wpose);
-  }
-  const size_t o_p128 = bb.add(pos128), o_p256 = bb.add(pos256), o_p512 = bb.add(pos512);
+  StudentBlobOffsets o;
+  const std::string err = build_student_blob(weights, exact, pos128, pos256, pos512, bb, o);
+  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, "not a mode_14 student: " + err);
 
   DeviceGuard guard(device);
   auto* h = new tha4_student();
@@ -170,6 +220,8 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
     if (h->workspace) (void)hipFree(h->workspace);
     delete h;
   };
+  h->blob_bytes = bb.host.size();
+  h->pos128 = pos128; h->pos256 = pos256; h->pos512 = pos512;
   hipError_t e = hipMalloc((void**)&h->blob, bb.host.size());
   if (e == hipSuccess) e = hipMemcpy(h->blob, bb.host.data(), bb.host.size(), hipMemcpyHostToDevice);
   const size_t B = (size_t)max_batch;
@@ -193,13 +245,13 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   }
   auto F = [&](size_t off) { return reinterpret_cast<const float*>(h->blob + off); };
   StudentDev& d = h->dev;
-  d.w_face = F(o_wf); d.w_l0 = F(o_w0); d.w_l1 = F(o_w1); d.w_l2 = F(o_w2);
-  d.b_face = F(o_bf); d.b_l0 = F(o_b0); d.b_l1 = F(o_b1); d.b_l2 = F(o_b2);
+  d.w_face = F(o.wf); d.w_l0 = F(o.w0); d.w_l1 = F(o.w1); d.w_l2 = F(o.w2);
+  d.b_face = F(o.bf); d.b_l0 = F(o.b0); d.b_l1 = F(o.b1); d.b_l2 = F(o.b2);
   for (int i = 0; i < 4; ++i) {
-    d.wx[i] = F(o_wx[i]); d.wy[i] = F(o_wy[i]); d.bias1[i] = F(o_b[i]); d.wpose[i] = F(o_wp[i]);
+    d.wx[i] = F(o.wx[i]); d.wy[i] = F(o.wy[i]); d.bias1[i] = F(o.b[i]); d.wpose[i] = F(o.wp[i]);
   }
-  d.pos128 = F(o_p128); d.pos256 = F(o_p256); d.pos512 = F(o_p512);
-  d.s_face = F(o_sf); d.s_l0 = F(o_s0); d.s_l1 = F(o_s1); d.s_l2 = F(o_s2);
+  d.pos128 = F(o.p128); d.pos256 = F(o.p256); d.pos512 = F(o.p512);
+  d.s_face = F(o.sf); d.s_l0 = F(o.s0); d.s_l1 = F(o.s1); d.s_l2 = F(o.s2);
   d.pb_scale = exact ? 1.0f : kOmega;
   char* ws = h->workspace;
   d.pbias = reinterpret_cast<float*>(ws); ws += s_pb;
@@ -222,6 +274,7 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
     return fail(THA4_ERR_INVALID_ARGUMENT, "out_blended_dev must not alias image_dev");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(h->order.enter(s));
   StudentDev d = h->dev;
   d.image = image_dev;
   d.image_stride = image_batch_stride;
@@ -280,9 +333,25 @@ void tha4_student_destroy(tha4_student* h) {
   DeviceGuard guard(h->device);
   if (h->ev_valid)
     for (auto& e : h->ev) (void)hipEventDestroy(e);
+  h->order.destroy();
   if (h->blob) (void)hipFree(h->blob);
   if (h->workspace) (void)hipFree(h->workspace);
   delete h;
+}
+
+int tha4_student_set_weights(tha4_student* h, const tha4_student_weights* weights) {
+  if (!h || !weights) return fail(THA4_ERR_INVALID_ARGUMENT, "handle/weights must not be NULL");
+  BlobBuilder bb;
+  StudentBlobOffsets o;
+  const std::string err = build_student_blob(weights, h->exact_fp32, h->pos128, h->pos256, h->pos512, bb, o);
+  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, "not a mode_14 student: " + err);
+  if (bb.host.size() != h->blob_bytes) return fail(THA4_ERR_INVALID_ARGUMENT, "internal: packed size differs from the handle's blob");
+  DeviceGuard guard(h->device);
+  // rare operation: wait for every pose call in flight (whatever stream it is on), then overwrite the blob in place -
+  // no allocation, workspace and handle stay valid
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->blob, bb.host.data(), bb.host.size(), hipMemcpyHostToDevice));
+  return THA4_OK;
 }
 
 int tha4_student_max_batch(const tha4_student* h) { return h ? h->max_batch : THA4_ERR_INVALID_ARGUMENT; }
@@ -319,11 +388,18 @@ struct tha4_full {
   FullModel model;
   bool decomposer_valid = false;
   int last_batch = 0;
+  StreamOrder order;
 };
 
 int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
                      tha4_full** out) {
+  return tha4_full_create_ex(weights, eyebrow_morphed_image_index, device, max_batch, 5, out);
+}
+
+int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
+                        int num_networks, tha4_full** out) {
   if (!weights || !out) return fail(THA4_ERR_INVALID_ARGUMENT, "weights/out must not be NULL");
+  if (num_networks != 3 && num_networks != 5) return fail(THA4_ERR_INVALID_ARGUMENT, "num_networks must be 5 (mode_07) or 3 (mode_12)");
   *out = nullptr;
   if (max_batch < 1 || max_batch > 256) return fail(THA4_ERR_INVALID_ARGUMENT, "max_batch must be in [1, 256]");
   if (eyebrow_morphed_image_index != 0 && eyebrow_morphed_image_index != 2)
@@ -336,7 +412,7 @@ int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(THA4_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library only contains gfx950 code");
   WeightMap nets[5];
-  for (int n = 0; n < 5; ++n) {
+  for (int n = 0; n < num_networks; ++n) {
     if (!weights->tensors[n] || weights->counts[n] <= 0) return fail(THA4_ERR_INVALID_ARGUMENT, "empty state_dict");
     for (int i = 0; i < weights->counts[n]; ++i) {
       const tha4_named_tensor& t = weights->tensors[n][i];
@@ -349,8 +425,8 @@ int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image
   }
   auto* h = new tha4_full();
   h->device = device;
-  if (!h->model.build(nets, max_batch, eyebrow_morphed_image_index)) {
-    std::string msg = "not a mode_07 model: " + h->model.error;
+  if (!h->model.build(nets, max_batch, eyebrow_morphed_image_index, num_networks)) {
+    std::string msg = std::string(num_networks == 5 ? "not a mode_07 model: " : "not a mode_12 model: ") + h->model.error;
     delete h;
     return fail(THA4_ERR_INVALID_ARGUMENT, msg);
   }
@@ -374,8 +450,16 @@ int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image
 
 int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev, int batch,
                    float* const* outputs_dev, int reuse_decomposer, void* stream) {
-  if (!h || !image_dev || !pose_dev || !outputs_dev || !outputs_dev[0])
-    return fail(THA4_ERR_INVALID_ARGUMENT, "handle/image/pose/outputs[0] must not be NULL");
+  if (!h || !image_dev || !pose_dev || !outputs_dev)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "handle/image/pose/outputs must not be NULL");
+  {
+    const int first = h->model.num_networks == 5 ? 0 : 11;     // a mode_12 handle produces outputs 11..32 only
+    bool any = false;
+    for (int i = first; i < 33; ++i) any = any || outputs_dev[i] != nullptr;
+    if (!any) return fail(THA4_ERR_INVALID_ARGUMENT, "no output requested");
+    for (int i = 0; i < first; ++i)
+      if (outputs_dev[i]) return fail(THA4_ERR_INVALID_ARGUMENT, "outputs 0..10 do not exist on a 3-network (mode_12) handle");
+  }
   if (batch < 1) return fail(THA4_ERR_INVALID_ARGUMENT, "batch must be >= 1");
   if (batch > h->model.max_batch) return fail(THA4_ERR_BATCH_TOO_LARGE, "batch exceeds max_batch given at create");
   if (image_batch_stride != 0 && image_batch_stride < 4LL * 512 * 512)
@@ -385,6 +469,7 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
   FullModel::Frame f{};
   f.image = image_dev; f.image_stride = image_batch_stride; f.pose = pose_dev; f.batch = batch;
   f.stream = static_cast<hipStream_t>(stream);
+  HIP_TRY(h->order.enter(f.stream));
   bool want_dec[6];
   for (int i = 0; i < 33; ++i) f.out[i] = outputs_dev[i] ? outputs_dev[i] : m.Wk(m.scratch_out[i]);
   for (int i = 0; i < 6; ++i) want_dec[i] = outputs_dev[27 + i] != nullptr;
@@ -408,17 +493,22 @@ int tha4_full_debug_read(tha4_full* h, void* dst, size_t bytes) {
 void tha4_full_destroy(tha4_full* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
+  h->order.destroy();
   if (h->model.dev_params) (void)hipFree(h->model.dev_params);
   if (h->model.dev_work) (void)hipFree(h->model.dev_work);
   delete h;
 }
 
 int tha4_full_max_batch(const tha4_full* h) { return h ? h->model.max_batch : THA4_ERR_INVALID_ARGUMENT; }
+int tha4_full_num_networks(const tha4_full* h) { return h ? h->model.num_networks : THA4_ERR_INVALID_ARGUMENT; }
 
 int tha4_display_rgba8(const float* frames_dev, int batch, int height, int width, const float* background_rgb,
                        uint8_t* out_dev, void* stream) {
   if (!frames_dev || !out_dev || batch < 1 || height < 1 || width < 1)
     return fail(THA4_ERR_INVALID_ARGUMENT, "frames/out must not be NULL and batch/size must be positive");
+  const int dev = device_of(frames_dev);
+  if (dev < 0 || dev != device_of(out_dev)) return fail(THA4_ERR_INVALID_ARGUMENT, "frames/out must be device pointers of one GPU");
+  DeviceGuard guard(dev);
   DisplayArgs a{};
   a.frames = frames_dev; a.out = out_dev; a.pixels = height * width;
   a.has_background = background_rgb != nullptr;
@@ -431,6 +521,9 @@ int tha4_display_rgba8(const float* frames_dev, int batch, int height, int width
 int tha4_ingest_rgba8(const uint8_t* rgba_dev, int batch, int height, int width, float* out_dev, void* stream) {
   if (!rgba_dev || !out_dev || batch < 1 || height < 1 || width < 1)
     return fail(THA4_ERR_INVALID_ARGUMENT, "rgba/out must not be NULL and batch/size must be positive");
+  const int dev = device_of(rgba_dev);
+  if (dev < 0 || dev != device_of(out_dev)) return fail(THA4_ERR_INVALID_ARGUMENT, "rgba/out must be device pointers of one GPU");
+  DeviceGuard guard(dev);
   IngestArgs a{rgba_dev, out_dev, height * width};
   hipLaunchKernelGGL(ingest_rgba8_kernel, dim3((a.pixels + 255) / 256, batch), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   HIP_TRY(hipGetLastError());

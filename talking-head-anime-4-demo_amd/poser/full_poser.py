@@ -4,9 +4,15 @@ Mirrors ``GeneralPoser02`` as configured by ``mode_07.create_poser`` (src/tha4/p
 33 outputs in the reference order (:126-132), ``output_index`` selection, lazy loading, batching of
 3-D image / 1-D pose, ``to`` / ``free``.  The eyebrow-decomposer cache of the reference
 (``FiveStepPoserComputationProtocol.compute_func``, :54-70: reuse while ``max|image - cached| == 0``)
-is kept, but keyed on the tensor's identity (data_ptr, _version, shape) instead of a device->host
-``.item()`` synchronisation; pass ``image_changed=True`` to force a refresh after an in-place edit
-that does not bump ``_version``.
+is kept without its device->host ``.item()`` synchronisation.  The reference decides reuse by CONTENT and keeps a
+reference to the cached batch (``cached_batch_0``); here reuse is decided, in this order, by
+  * ``image_version=<int>`` given by the caller (SURVEY.md §8b proposal): reuse iff the version, shape and batch equal
+    the previous call's - the caller vouches for the content;
+  * otherwise the tensor's storage identity ``(data_ptr, shape, strides, _version)`` while the poser holds a STRONG
+    reference to the cached tensor, so the allocator cannot hand its address to a different image, and in-place
+    edits bump ``_version``.  Nothing is cached when the input had to be copied (non-contiguous) or does not track a
+    version (inference tensors): those calls are always "cold", which is the safe side;
+  * ``image_changed=True`` forces a refresh.
 """
 from __future__ import annotations
 
@@ -47,6 +53,10 @@ class HipFullPoser(Poser):
         self._lib = None
         self._handle = None
         self._cache_key = None
+        self._cache_image = None           # strong reference: keeps the keyed storage alive (mode_07.py:65 cached_batch_0)
+        self.num_networks = 5
+        self.first_output = 0              # C-ABI output index of list entry 0 (mode_12: 11)
+        self.list_length = _capi.FULL_NUM_OUTPUTS
 
     def get_image_size(self) -> int:
         return self.image_size
@@ -67,13 +77,19 @@ class HipFullPoser(Poser):
         self._ensure_handle(self._max_batch)
         return self._state_dicts
 
-    def pose(self, image: Tensor, pose: Tensor, output_index: Optional[int] = None, image_changed: bool = False) -> Tensor:
+    def pose(self, image: Tensor, pose: Tensor, output_index: Optional[int] = None, image_changed: bool = False,
+             image_version: Optional[int] = None) -> Tensor:
         if output_index is None:
             output_index = self.default_output_index
-        return self._run(image, pose, [output_index], image_changed)[0]
+        return self._run(image, pose, [output_index], image_changed, image_version)[0]
 
-    def get_posing_outputs(self, image: Tensor, pose: Tensor, image_changed: bool = False) -> List[Tensor]:
-        return self._run(image, pose, list(range(self.output_length)), image_changed)
+    def get_posing_outputs(self, image: Tensor, pose: Tensor, image_changed: bool = False, indices=None,
+                           image_version: Optional[int] = None) -> List[Tensor]:
+        """The reference's list of outputs (mode_07.py:126-132).  ``indices`` (extension) restricts the work to those
+        entries - only they are allocated and written - and returns them in the given order, e.g. ``(0, 1, 2, 3, 5)``
+        for the distiller's teacher call (siren_morpher_protocols_03.py:56-72)."""
+        wanted = list(range(self.list_length)) if indices is None else [int(i) for i in indices]
+        return self._run(image, pose, wanted, image_changed, image_version)
 
     def free(self):
         self._destroy_handle()
@@ -98,6 +114,7 @@ class HipFullPoser(Poser):
             self._lib.tha4_full_destroy(self._handle)
         self._handle = None
         self._cache_key = None
+        self._cache_image = None
 
     def __del__(self):
         try:
@@ -117,12 +134,15 @@ class HipFullPoser(Poser):
         self._max_batch = max(self._max_batch, batch)
         weights, keep = _capi.build_full_weights(self._state_dicts)
         handle = C.c_void_p()
-        st = self._lib.tha4_full_create(C.byref(weights), self.eyebrow_morphed_image_index, dev, self._max_batch, C.byref(handle))
-        _capi.check(self._lib, st, "tha4_full_create")
+        st = self._lib.tha4_full_create_ex(C.byref(weights), self.eyebrow_morphed_image_index, dev, self._max_batch,
+                                           self.num_networks, C.byref(handle))
+        _capi.check(self._lib, st, "tha4_full_create_ex")
         del keep
         self._handle = handle
 
-    def _run(self, image: Tensor, pose: Tensor, wanted: List[int], image_changed: bool) -> List[Tensor]:
+    def _run(self, image: Tensor, pose: Tensor, wanted: List[int], image_changed: bool,
+             image_version: Optional[int] = None) -> List[Tensor]:
+        given = image                                       # the caller's tensor object (cache identity)
         if image.dim() == 3:
             image = image.unsqueeze(0)
         if pose.dim() == 1:
@@ -134,23 +154,43 @@ class HipFullPoser(Poser):
         b = pose.shape[0]
         if image.shape[0] not in (1, b):
             raise AssertionError(f"image batch {image.shape[0]} does not match pose batch {b}")
-        if image.dtype != torch.float32 or pose.dtype != torch.float32:
-            raise AssertionError("image and pose must be float32")
+        dev = self._device_index()
+        for name, t in (("image", image), ("pose", pose)):
+            if t.dtype != torch.float32:
+                raise AssertionError(f"{name} must be float32, got {t.dtype}")
+            if t.device.type != "cuda" or t.device.index != dev:
+                raise AssertionError(f"{name} is on {t.device}, poser is on {self.device}")
+        if not wanted or any(i < 0 or i >= self.list_length for i in wanted):
+            raise AssertionError(f"output indices must be in [0, {self.list_length}), got {wanted}")
+        copied = not image.is_contiguous()
         image, pose = image.contiguous(), pose.contiguous()
         self._ensure_handle(b)
-        dev = self._device_index()
-        key = (image.data_ptr(), image._version, tuple(image.shape), b)
-        reuse = (not image_changed) and key == self._cache_key
+        # ---- eyebrow-decomposer cache (mode_07.py:56-67) ----
+        if image_version is not None:
+            key = ("version", int(image_version), tuple(image.shape), b)
+            keep = None
+        else:
+            try:
+                version = given._version
+            except RuntimeError:                           # inference tensors do not track a version counter
+                version = None
+            key = None if (copied or version is None) else ("tensor", given.data_ptr(), tuple(given.shape), tuple(given.stride()), version, b)
+            keep = given
+        reuse = (not image_changed) and key is not None and key == self._cache_key
+        target = torch.device("cuda", dev)
         outs = {}
         ptrs = (C.c_void_p * _capi.FULL_NUM_OUTPUTS)()
-        for i in sorted(set(wanted) | {0}):
-            t = torch.empty((b, OUT_CHANNELS[i], OUT_SIZE[i], OUT_SIZE[i]), dtype=torch.float32, device=image.device)
+        for i in sorted(set(wanted)):
+            ci = self.first_output + i                     # index in the C ABI's 33-entry list
+            t = torch.empty((b, OUT_CHANNELS[ci], OUT_SIZE[ci], OUT_SIZE[ci]), dtype=torch.float32, device=target)
             outs[i] = t
-            ptrs[i] = t.data_ptr()
+            ptrs[ci] = t.data_ptr()
         stride = 0 if (image.shape[0] == 1 and b > 1) else 4 * 512 * 512
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        st = self._lib.tha4_full_pose(self._handle, image.data_ptr(), stride, pose.data_ptr(), b, ptrs, int(reuse),
-                                      C.c_void_p(stream))
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            st = self._lib.tha4_full_pose(self._handle, image.data_ptr(), stride, pose.data_ptr(), b, ptrs, int(reuse),
+                                          C.c_void_p(stream))
         _capi.check(self._lib, st, "tha4_full_pose")
         self._cache_key = key
+        self._cache_image = keep if key is not None else None
         return [outs[i] for i in wanted]

@@ -111,6 +111,27 @@ class HipStudentPoser(Poser):
         self._destroy_handle()
         self._state_dicts = None
 
+    def set_state_dicts(self, face_state_dict: Dict[str, np.ndarray], body_state_dict: Dict[str, np.ndarray]):
+        """Hot-swap the character: new student weights into the LIVE native handle -
+        ``tha4_student_set_weights`` overwrites the packed parameter blob in place, nothing is re-allocated (workspace,
+        max_batch, position axes stay).  Before the first call it just replaces what the lazy loaders will deliver."""
+        conv = lambda sd: {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+        face, body = conv(face_state_dict), conv(body_state_dict)
+        self.state_dict_loaders = {"face_morpher": lambda: face, "body_morpher": lambda: body}
+        self._state_dicts = {"face_morpher": face, "body_morpher": body}
+        if self._handle is not None:
+            weights, keep = _capi.build_student_weights(face, body)
+            st = self._lib.tha4_student_set_weights(self._handle, C.byref(weights))
+            _capi.check(self._lib, st, "tha4_student_set_weights")
+            del keep
+        return self
+
+    def load_character(self, module_file_names: Dict[str, str]):
+        """``set_state_dicts`` from two reference ``.pt`` files (keys "face_morpher" / "body_morpher", mode_14.py:14-15)."""
+        from .. import weights as _weights
+        return self.set_state_dicts(_weights.load_state_dict_file(module_file_names["face_morpher"]),
+                                    _weights.load_state_dict_file(module_file_names["body_morpher"]))
+
     def to(self, device: torch.device) -> "HipStudentPoser":
         device = torch.device(device)
         if device == self.device:

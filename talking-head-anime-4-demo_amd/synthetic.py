@@ -155,12 +155,20 @@ def full_param_shapes() -> Dict[str, Dict[str, tuple]]:
     return out
 
 
-def synth_full_weights(seed: int = 20260925) -> Dict[str, Dict[str, np.ndarray]]:
+def synth_full_weights(seed: int = 20260925, small_gain: float = 1.0, conv_gain: float = 1.0,
+                       film_gain: float = 1.0) -> Dict[str, Dict[str, np.ndarray]]:
     """Deterministic synthetic parameters (numpy PCG64) for all five networks, following SURVEY.md
     §8c: ordinary layers get He-normal conv weights / default-Linear-range weights / near-identity
     norm affines; every tensor the reference zero-initialises (ResBlock.conv1, attention.conv,
     U-Net last conv, coarse_image_conv, grid-change heads) gets N(0,(0.02/sqrt(fan_in))^2) weights
-    and N(0,0.01^2) biases so that warps stay at the +-0.06 scale of real models."""
+    and N(0,0.01^2) biases so that warps stay at the +-0.06 scale of real models.
+
+    The three gains (all 1.0 by default: the parameter set every committed `full_synth_*` fixture uses) build the
+    ADVERSARIAL-RANGE set of tests/golden/make_golden_full_batch.py: `small_gain` multiplies the zero-init family
+    (larger warps, a residual stream that is no longer dominated by the skip path), `conv_gain` the He-normal
+    convolutions that feed a normalisation layer (pre-normalisation activations and moments of O(conv_gain); the
+    network function is unchanged up to the eps of the norm, so the reference stays well conditioned), `film_gain` the FiLM projections `cond*_layers` (O(1) scale/shift modulation as in a trained model).
+    The same random stream is drawn whatever the gains are."""
     rng = np.random.default_rng(seed)
     out: Dict[str, Dict[str, np.ndarray]] = {}
     for net, shapes in full_param_shapes().items():
@@ -172,10 +180,13 @@ def synth_full_weights(seed: int = 20260925) -> Dict[str, Dict[str, np.ndarray]]
             if len(shp) == 4:
                 is_t = "upsample_blocks" in key
                 fan_in = (shp[0] if is_t else shp[1]) * shp[2] * shp[3]
-                std = 0.02 / math.sqrt(fan_in) if small else math.sqrt(2.0 / fan_in)
+                normed = ("sample_blocks" in key or "bottleneck_blocks" in key or key.endswith(".conv0.weight"))   # followed by IN / GN
+                std = small_gain * 0.02 / math.sqrt(fan_in) if small else (conv_gain if normed else 1.0) * math.sqrt(2.0 / fan_in)
                 a = rng.standard_normal(shp) * std
             elif len(shp) == 2:
                 a = rng.uniform(-1, 1, shp) / math.sqrt(shp[1])
+                if "cond0_layers" in key or "cond1_layers" in key:
+                    a = a * film_gain
             else:
                 is_norm_w = key.endswith(".weight") and ("norm" in key or key.endswith(".1.weight") or key.endswith(".4.weight")
                                                          or key == "body.last.0.weight")

@@ -145,3 +145,29 @@ def test_no_kernel_spills(built):
     assert not bad, bad
     student = [l for l in lines if "tha42v2" in l or "posebias" in l]
     assert all("scratch=0" in l for l in student), student
+
+
+def test_mode_12_surface_and_defaults():
+    """mode_12.create_poser (mode_12.py:169-202): three module keys, default files, declared output length 18."""
+    from tha4_amd.poser.modes import mode_12
+    names = {}
+    poser = mode_12.create_poser(torch.device("cpu"), module_file_names=names)
+    assert names == {n: f"data/tha4/{n}.pt" for n in ["eyebrow_decomposer", "eyebrow_morphing_combiner", "face_morpher"]}
+    assert [n.name for n in mode_12.Network] == list(names)
+    assert isinstance(poser, Poser) and poser.get_output_length() == 18 and poser.list_length == 22
+    assert poser.get_image_size() == 512 and poser.get_num_parameters() == 45
+    with pytest.raises(_capi.Tha4Error, match="no CPU path"):
+        poser.pose(torch.zeros(4, 512, 512), torch.zeros(45))
+
+
+def test_new_entry_points_validate_arguments(built):
+    lib = _capi.load_library()
+    assert lib.tha4_student_set_weights(None, None) == -1
+    assert lib.tha4_full_create_ex(None, 2, 0, 1, 3, None) == -1
+    assert lib.tha4_full_num_networks(None) == -1
+    # stateless image entry points refuse host pointers instead of launching on them
+    import ctypes as C
+    buf = (C.c_float * 16)()
+    out = (C.c_uint8 * 16)()
+    assert lib.tha4_display_rgba8(buf, 1, 2, 2, None, out, None) == -1
+    assert lib.tha4_ingest_rgba8(out, 1, 2, 2, buf, None) == -1

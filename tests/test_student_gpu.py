@@ -303,3 +303,51 @@ def test_pose_writes_into_caller_buffer(poser, dev, golden_io):
         poser.pose(image, poses[0], out=block[:, :, ::2])                          # wrong shape / not contiguous
     with pytest.raises(AssertionError):
         poser.pose(image, poses[0], output_index=1, out=block[0:1])
+
+
+def test_hot_swap_characters_in_place(dev, char_weights, char_io):
+    """tha4_student_set_weights (§8f row 3): swap lambda_00 -> lambda_01 -> lambda_00 into ONE live handle; frames are
+    bitwise those of a poser created for that character, and nothing is re-allocated (same native handle)."""
+    sds = {c: split_flat_weights(char_weights[c]) for c in ("lambda_00", "lambda_01")}
+    fresh = {c: mode_14.create_poser_from_state_dicts(dev, *sds[c]) for c in sds}
+    p = mode_14.create_poser_from_state_dicts(dev, *sds["lambda_00"])
+    image = {c: torch.from_numpy(char_io[c]["image_f32"]).to(dev) for c in sds}
+    pose = torch.from_numpy(char_io["lambda_00"]["poses"][2]).to(dev)
+    ref = {c: fresh[c].pose(image[c], pose) for c in sds}
+    assert torch.equal(p.pose(image["lambda_00"], pose), ref["lambda_00"])
+    handle = p._handle.value
+    for c in ("lambda_01", "lambda_00", "lambda_01"):
+        p.set_state_dicts(*sds[c])
+        assert p._handle.value == handle
+        assert torch.equal(p.pose(image[c], pose), ref[c]), c
+    # swap while frames are in flight on a side stream: set_weights waits for them
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        outs = [p.pose(image["lambda_01"], pose) for _ in range(8)]
+    p.set_state_dicts(*sds["lambda_00"])
+    after = p.pose(image["lambda_00"], pose)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref["lambda_01"]) for o in outs) and torch.equal(after, ref["lambda_00"])
+    # a wrong architecture is rejected and leaves the handle usable
+    bad_body = dict(sds["lambda_01"][1])
+    bad_body["siren_layers.0.1.linear.weight"] = bad_body["siren_layers.0.1.linear.weight"][:, :300]
+    with pytest.raises(_capi.Tha4Error):
+        p.set_state_dicts(sds["lambda_01"][0], bad_body)
+    for q in list(fresh.values()) + [p]:
+        q.free()
+
+
+def test_student_stream_switch_is_ordered(poser, dev, golden_io):
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    poses = torch.from_numpy(golden_io["poses"][:2]).to(dev)
+    base = [poser.pose(image, poses[i]).clone() for i in range(2)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs = []
+    for rep in range(4):
+        with torch.cuda.stream(s1):
+            outs.append((0, poser.pose(image, poses[0])))
+        with torch.cuda.stream(s2):
+            outs.append((1, poser.pose(image, poses[1])))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, base[i]) for i, o in outs)
