@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
-"""Benchmark of the student poser hot path (BASELINE.json configs[1]): lambda_00 distilled student,
-batch=1 real-time stream of random 45-dim poses on 512x512 RGBA, through the drop-in Poser API
-(tha4_amd.poser.modes.mode_14 -> include/tha4_hip.h -> gfx950 kernels).
+"""Benchmark of the poser hot path through the drop-in Poser API (tha4_amd.poser.modes -> include/tha4_hip.h -> gfx950
+kernels), for the configurations BASELINE.json names:
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py                                     configs[1]  lambda_00 student, batch-1 stream, 1 GPU (the headline)
+    python bench.py --model full                        configs[2]  full THA4 model, batch 1, lambda_00 image
+    torchrun ... bench.py --gpus 8 --batch 32           configs[3]  one student instance per GPU (lambda_00 / lambda_01
+                                                                    alternating by rank), batches of 32 poses, gather
+    torchrun ... bench.py --gpus 8 --model full --batch 8   configs[4]  full model, 8 random images + poses per GPU and step
+                                                                    (64 frames per step over 8 GPUs), frame-parallel, gather
 
-A step = one Poser.pose() call = one frame (batch 1), back-to-back on the rank's current stream,
-image and poses resident in HBM before the timed region.  With N>1 every rank poses K frames of its
-own (weak scaling, frames are independent) and finished frames are gathered to rank 0 in chunks
-over RCCL on a side stream (the only exchange the path has).  Rank 0 prints ONE JSON line.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W [...]
+
+A step = ONE Poser.pose() call on a batch of B frames (B = 1 by default), back-to-back on the rank's current stream,
+inputs resident in HBM before the timed region.  With N > 1 every rank runs K steps of its own (weak scaling: frames
+and character instances are independent, no collective on the compute path) and the finished frames - fp32, or RGBA8
+after the display epilogue with --rgba8-gather - are gathered to rank 0 chunk by chunk over RCCL on a side stream
+(the only exchange the path has; --no-gather skips it).  Timing: W untimed steps, then exactly K steps between
+barrier + synchronize on both sides, maximum over ranks; rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import json
 import os
+import platform
 import sys
 import time
 
@@ -25,17 +34,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import tha4_amd  # noqa: E402,F401
-from tha4_amd.poser.modes import mode_14  # noqa: E402
+from tha4_amd import synthetic  # noqa: E402
+from tha4_amd.poser.modes import mode_07, mode_14  # noqa: E402
 from tha4_amd.sharding import FrameShardedStream  # noqa: E402
 from tha4_amd.weights import split_flat_weights  # noqa: E402
 
-# Algorithmic work of the reference's student forward pass as written (SURVEY.md §8d, 2*MAC),
-# per 512x512 frame and per kernel of this implementation.
+# Algorithmic work of the reference's forward passes as written (SURVEY.md §8d, 2*MAC), per 512x512 frame and per
+# kernel of the student implementation.
 GFLOP_FRAME = 37.885
 GFLOP_KERNEL = {"face": 3.947, "level0": 6.924, "level1": 11.726, "level2": 15.288}
-# What the kernels actually execute after pose folding + commuting the x2 upsample with the next
-# level's first layer: stated separately, never used for `roofline.achieved`.
+# What the student kernels actually execute after pose folding + commuting the x2 upsample with the next level's
+# first layer: stated separately, never used for `roofline.achieved`.
 GFLOP_EXECUTED_FRAME = 27.46
+GFLOP_FULL_COLD = 645.90          # FlopCounterMode on the reference modules
+GFLOP_FULL_STEADY = 625.90        # eyebrow decomposer cached (mode_07.py:56-67)
 # The contractions issue v_mfma_f32_16x16x32_f16 on fp16 hi/lo halves of fp32 operands, three MFMAs per fp32-accurate
 # product block (hi*hi + hi*lo + lo*hi, fp32 accumulate).  `roofline.peak` is the dense fp16 MFMA peak of the
 # instruction actually issued (MI355X_MICROARCH.md: ~2.5 PFLOP/s); `roofline.achieved` stays ALGORITHMIC (every
@@ -43,15 +55,8 @@ GFLOP_EXECUTED_FRAME = 27.46
 PEAK_F16_MFMA_TFLOPS = 2500.0
 MFMA_PASSES = 3
 PEAK_FP32_MFMA_TFLOPS = 157.3      # v_mfma_f32_16x16x4_f32 dense peak (what an exact-fp32 single pass could reach)
-# HBM-side bytes per launch of each kernel from the PMC passes committed in profiles/r01_student_b1_profile.md
-# (FETCH_SIZE x 2 [gfx950 wide-read correction, MI355X_MICROARCH.md §HBM] + WRITE_SIZE, KiB -> bytes).
-# bench.py cannot run rocprofv3 on itself, so this is the profiled value for the same command line.
-PMC_TRAFFIC_BYTES = {"face": (1920 * 2 + 256) * 1024, "level0": (4178 * 2 + 12290) * 1024,
-                     "level1": (8516 * 2 + 24580) * 1024, "level2": (30730 * 2 + 4284) * 1024}
+DTYPE = "f32 (I/O and accumulate; contractions: fp16 hi/lo 3-pass operands on v_mfma_f32_16x16x32_f16, 22-bit operands)"
 KERNEL_NAMES = ["posebias", "face", "level0", "level1", "level2"]
-# full THA4 system (mode_07), SURVEY.md §8d: FlopCounterMode on the reference modules
-GFLOP_FULL_COLD = 645.90
-GFLOP_FULL_STEADY = 625.90
 
 POSE_LO = np.array([0.0] * 37 + [-1.0] * 7 + [0.0], dtype=np.float32)
 POSE_HI = np.ones(45, dtype=np.float32)
@@ -63,121 +68,158 @@ def make_poses(n, seed):
     return torch.from_numpy((POSE_LO + (POSE_HI - POSE_LO) * u).astype(np.float32))
 
 
-def load_fixture():
+def load_character(name):
+    """Student weights + image of one shipped character (tests/golden fixtures made from the reference's .pt / .png)."""
     g = os.path.join(ROOT, "tests", "golden")
-    w = dict(np.load(os.path.join(g, "student_lambda_00_weights.npz")))
-    io = np.load(os.path.join(g, "student_lambda_00_io.npz"))
+    w = dict(np.load(os.path.join(g, f"student_{name}_weights.npz")))
+    io = np.load(os.path.join(g, f"student_{name}_io.npz"))
     return w, io["image_f32"]
 
 
-def cpu_baseline(w, image, poses, budget_s):
-    """The CPU path timed beside the GPU path: the oracle's torch-functional restatement of the
-    reference (same ATen ops), fp32, all host cores.  Bounded sample (~budget_s of CPU work)."""
-    from oracle import student_oracle as so
-    so.student_forward_torch(w, image, poses[0].numpy(), "float32")      # warm-up (thread pool, allocator)
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        so.student_forward_torch(w, image, poses[n % poses.shape[0]].numpy(), "float32")
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 64:
-            break
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} frames of the same lambda_00 stream, oracle.student_forward_torch fp32 ({dt:.1f} s)",
-            "ms_per_frame": round(1e3 * dt / n, 2)}
+def newest_profile(pattern):
+    """HBM-side bytes come from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on
+    itself): the newest round's machine-readable summary, produced by tools/traffic_json.py from the PMC CSVs."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def measure_full(dev, image, frames, batch=1):
-    """BASELINE.json configs[2]: full THA4 model (5 networks), batch 1, synthetic seeded weights (the reference
-    checkout ships none), lambda_00 image.  Returns steady (eyebrow decomposer cached, mode_07.py:56-67) and cold fps."""
-    from tha4_amd import synthetic
-    from tha4_amd.poser.modes import mode_07
-    poser = mode_07.create_poser_from_state_dicts(dev, synthetic.synth_full_weights(), max_batch=batch)
-    poses = make_poses(8 * batch, seed=77).to(dev)
-    if batch > 1:
-        poses = poses.reshape(8, batch, 45)
-    with torch.no_grad():
-        for i in range(3):
-            poser.pose(image, poses[i])
-        out = {}
-        for name, changed, gflop in (("steady", False, GFLOP_FULL_STEADY), ("cold", True, GFLOP_FULL_COLD)):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for i in range(frames):
-                poser.pose(image, poses[i % 8], image_changed=changed)
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-            fps = frames * batch / dt
-            out[name] = {"fps": round(fps, 2), "ms_per_frame": round(1e3 * dt / (frames * batch), 3),
-                         "achieved_tflops": round(fps * gflop / 1e3, 2),
-                         "frac_of_f16_mfma_peak": round(fps * gflop / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
-                         "frac_of_split_ceiling": round(fps * gflop * MFMA_PASSES / 1e3 / PEAK_F16_MFMA_TFLOPS, 4)}
-    poser.free()
+def kernel_traffic_bytes(prof, name):
+    k = (prof or {}).get("kernels", {}).get(name)
+    if not k:
+        return None
+    return int(round((2.0 * k["fetch_kib"] + k["write_kib"]) * 1024))      # gfx950: FETCH_SIZE x2 (wide reads) + WRITE_SIZE
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(run_frame, what, budget_s, max_frames):
+    """The CPU path timed beside the GPU path (SURVEY.md §8d): the oracle's torch-functional restatement of the
+    reference (the same ATen ops the reference dispatches), fp32, `torch.set_num_threads(k)` for k in {1, 8, 32, all
+    physical cores}; the BEST k is the reported baseline (too many threads is slower for these small convolutions).
+    Bounded sample: ~budget_s of CPU work in total."""
+    phys = physical_cores()
+    ks = sorted({k for k in (1, 8, 32, phys) if k <= max(phys, 1)})
+    prev = torch.get_num_threads()
+    by = {}
+    per_k = budget_s / max(len(ks), 1)
+    try:
+        for k in ks:
+            torch.set_num_threads(k)
+            run_frame(0)                                           # warm-up (thread pool, allocator)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                run_frame(n)
+                n += 1
+                dt = time.perf_counter() - t0
+                if dt >= per_k or n >= max_frames:
+                    break
+            by[k] = {"frames": n, "seconds": round(dt, 2), "fps": round(n / dt, 4), "ms_per_frame": round(1e3 * dt / n, 1)}
+    finally:
+        torch.set_num_threads(prev)
+    best = max(by, key=lambda k: by[k]["fps"])
+    return {"value": by[best]["fps"], "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": f"{what}; {by[best]['frames']} frames at the best thread count ({sum(v['seconds'] for v in by.values()):.0f} s of CPU work over thread counts {ks})",
+            "ms_per_frame": by[best]["ms_per_frame"], "by_threads": {str(k): v for k, v in by.items()},
+            "cpu_model": cpu_model_string(), "physical_cores": phys, "logical_cpus": os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the two workloads: everything a step needs, resident in HBM
+# ------------------------------------------------------------------------------------------------------------------
+class StudentWork:
+    kind = "student"
+
+    def __init__(self, dev, rank, B, steps, characters):
+        name = characters if characters != "alternate" else ("lambda_00", "lambda_01")[rank % 2]
+        self.character = name
+        self.w, self.image_np = load_character(name)
+        face, body = split_flat_weights(self.w)
+        self.poser = mode_14.create_poser_from_state_dicts(dev, face, body, max_batch=max(B, 4))
+        self.image = torch.from_numpy(self.image_np).to(dev)
+        self.poses_cpu = make_poses(steps * B, seed=1234 + rank)
+        self.poses = self.poses_cpu.to(dev).reshape(steps, B, 45)
+        self.B = B
+        self.poser.get_modules()
+
+    def step(self, i, out=None):
+        return self.poser.pose(self.image, self.poses[i] if self.B > 1 else self.poses[i, 0], out=out)
+
+
+class FullWork:
+    kind = "full"
+
+    def __init__(self, dev, rank, B, steps, steady):
+        self.poser = mode_07.create_poser_from_state_dicts(dev, synthetic.synth_full_weights(), max_batch=B)
+        self.B, self.steady = B, steady
+        _, self.image_np = load_character("lambda_00")
+        if B == 1:
+            # configs[2]: the lambda_00 image; steady = image unchanged (decomposer cached), cold = it changes every frame
+            self.images = [torch.from_numpy(self.image_np).to(dev)]
+        else:
+            # configs[4]: B random images per step (SURVEY.md §8d config 5 recipe, seed 99 + rank); they change every
+            # batch, so the eyebrow-decomposer cache never hits (cold cost, 645.9 GFLOP/frame)
+            self.images = [torch.from_numpy(synthetic.random_rgba_images(B, seed=99 + 1000 * rank + j)).to(dev) for j in range(2)]
+        self.poses = make_poses(steps * B, seed=77 + rank).to(dev).reshape(steps, B, 45)
+        self.poser.get_modules()
+
+    def step(self, i, out=None):
+        if self.B == 1:
+            r = self.poser.pose(self.images[0], self.poses[i, 0], image_changed=not self.steady)
+        else:
+            r = self.poser.pose(self.images[i % 2], self.poses[i])
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+
+def timed_steps(work, lo, hi):
+    for i in range(lo, hi):
+        out = work.step(i)
     return out
-
-
-def cpu_baseline_full(image, budget_s):
-    """CPU path of the full model beside the GPU path: the oracle's torch-functional restatement of mode_07 (same ATen
-    ops, every frame cold as the reference would be for a new image), fp32, all host cores, bounded sample."""
-    from oracle import full_oracle as fo
-    from tha4_amd import synthetic
-    w = synthetic.synth_full_weights()
-    poses = make_poses(4, seed=77).numpy()
-    fo.full_forward_torch(w, image, poses[0], "float32")              # warm-up
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        fo.full_forward_torch(w, image, poses[n % 4], "float32")
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 16:
-            break
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} cold frames, oracle.full_forward_torch fp32, synthetic weights ({dt:.1f} s)", "ms_per_frame": round(1e3 * dt / n, 1)}
-
-
-def main_full(args):
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    _, image_np = load_fixture()
-    image = torch.from_numpy(image_np).to(dev)
-    r = measure_full(dev, image, args.steps, max(1, args.batch))
-    cpu = cpu_baseline_full(image_np, args.cpu_seconds) if args.cpu_seconds > 0 else None
-    print(json.dumps({
-        "metric": "frames/sec on 512x512 RGBA + 45-dim pose, full THA4 model", "value": r["steady"]["fps"], "unit": "frames/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": 3, "ms_per_step": round(r["steady"]["ms_per_frame"] * max(1, args.batch), 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic seeded weights (tha4_amd.synthetic, reference ships none); lambda_00 image fixture; random poses",
-        "config": {"workload": f"configs[2]: THA4 full model (face_morpher+rotator+editor), batch={max(1, args.batch)}, steady state (eyebrow decomposer cached)",
-                   "batch": max(1, args.batch)},
-        "roofline": {"bound": "mfma", "achieved": r["steady"]["achieved_tflops"], "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": r["steady"]["frac_of_f16_mfma_peak"], "frac_of_split_ceiling": r["steady"]["frac_of_split_ceiling"],
-                     "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate (k > 1 convolutions)",
-                     "traffic": None,
-                     "algorithmic_gflop_per_frame": GFLOP_FULL_STEADY},
-        "cold": r["cold"], "cpu_baseline": cpu}), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", choices=["student", "full"], default="student",
-                    help="student = BASELINE configs[1] (default, the headline metric); full = configs[2]")
-    ap.add_argument("--full-frames", type=int, default=30, help="student run: frames for the appended full-model measurement (0 = skip)")
+                    help="student = configs[1]/[3] (default: the headline metric); full = configs[2]/[4]")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="frames per Poser.pose() call (1 = configs[1]/[2]; 32 = configs[3]; 8..64 = configs[4] with --model full)")
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--gather-chunk", type=int, default=32, help="frames per RCCL gather (N>1)")
+    ap.add_argument("--batch", type=int, default=1, help="frames per Poser.pose() call (1 = configs[1]/[2]; 32 = configs[3]; 8 = configs[4] per GPU)")
+    ap.add_argument("--steps", type=int, default=None, help="timed pose() calls per rank (default 2000 student / 100 full)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed pose() calls per rank (default 200 student / 5 full)")
+    ap.add_argument("--characters", default=None, help="student: lambda_00 | lambda_01 | alternate (by rank; default for --batch > 1)")
+    ap.add_argument("--cold", action="store_true", help="full model, batch 1: the image changes every frame (no decomposer cache)")
+    ap.add_argument("--gather-chunk", type=int, default=32, help="frames per gather round (N>1; rounded to a multiple of --batch)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gather of finished frames")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
-    ap.add_argument("--profile-frames", type=int, default=100, help="frames for the per-kernel HIP-event pass")
-    ap.add_argument("--d2h-frames", type=int, default=500, help="frames for the secondary RGBA8 + D2H inclusive measurement (0 = skip)")
+    ap.add_argument("--rgba8-gather", action="store_true", help="N>1: display epilogue (sRGB, uint8 HWC) before the gather: 4x fewer bytes")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget in seconds of CPU work (0 disables; N=1 only)")
+    ap.add_argument("--profile-frames", type=int, default=100, help="student: steps for the per-kernel HIP-event pass")
+    ap.add_argument("--d2h-frames", type=int, default=500, help="student N=1 B=1: steps for the RGBA8 + D2H inclusive measurement (0 = skip)")
+    ap.add_argument("--exact-frames", type=int, default=500, help="student N=1 B=1: steps for the exact-fp32 generation A/B (0 = skip)")
+    ap.add_argument("--full-frames", type=int, default=30, help="student N=1 B=1: frames of the appended full-model measurement (0 = skip)")
     args = ap.parse_args()
-    if args.model == "full":
-        if args.steps == 2000:
-            args.steps = 100
-        return main_full(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -186,21 +228,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    w, image_np = load_fixture()
-    face_sd, body_sd = split_flat_weights(w)
+    student = args.model == "student"
     B = max(1, args.batch)
-    poser = mode_14.create_poser_from_state_dicts(dev, face_sd, body_sd, max_batch=max(B, 4))
-    image = torch.from_numpy(image_np).to(dev)
-    K, W = args.steps, args.warmup
-    poses_cpu = make_poses((K + W) * B, seed=1234 + rank)
-    poses = poses_cpu.to(dev)
-    if B > 1:
-        poses = poses.reshape(K + W, B, 45)           # one pose() call per step on a [B,45] batch, image shared
+    K = args.steps if args.steps is not None else (2000 if student else 100)
+    W = args.warmup if args.warmup is not None else (200 if student else 5)
+    characters = args.characters or ("lambda_00" if B == 1 else "alternate")
+    work = StudentWork(dev, rank, B, K + W, characters) if student else FullWork(dev, rank, B, K + W, steady=not args.cold)
+    gather = world > 1 and not args.no_gather
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -209,21 +249,21 @@ def main():
             torch.cuda.synchronize(dev)
 
     with torch.no_grad():
-        for i in range(W):
-            out = poser.pose(image, poses[i])
-        if world > 1 and not args.no_gather and B == 1:
-            chunk = args.gather_chunk
+        timed_steps(work, 0, W)
+        if gather:
+            from tha4_amd import image_io
+            chunk = max(B, args.gather_chunk // B * B)
+            shape, dtype = ((512, 512, 4), torch.uint8) if args.rgba8_gather else ((4, 512, 512), torch.float32)
 
-            def frame_fn(lo, hi):   # global frame ids of this rank start at rank*K
-                base = rank * K
+            def frame_fn(lo, hi):          # global frame ids of this rank start at rank*K*B; whole steps only
+                base = rank * K * B
                 blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
-                for i in range(lo, hi):
-                    poser.pose(image, poses[W + i - base], out=blk[i - lo:i - lo + 1])    # straight into the gather block
-                return blk
+                for f in range(lo, hi, B):                                   # straight into the gather block
+                    work.step(W + (f - base) // B, out=blk[f - lo:f - lo + B])
+                return image_io.to_display_rgba8(blk) if args.rgba8_gather else blk
 
-            stream = FrameShardedStream(frame_fn, total=K * world, frame_shape=(4, 512, 512), dtype=torch.float32,
-                                        device=dev, chunk=chunk, gather=True)
-            gathered = stream.allocate_result()       # rank 0: K*world frames (4 MiB each) - allocated outside the timed region
+            stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
+            gathered = stream.allocate_result()       # rank 0: all frames - allocated outside the timed region
             barrier()
             t0 = time.perf_counter()
             gathered = stream.run(gathered)
@@ -233,8 +273,7 @@ def main():
         else:
             barrier()
             t0 = time.perf_counter()
-            for i in range(K):
-                out = poser.pose(image, poses[W + i])
+            timed_steps(work, W, W + K)
             barrier()
             t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -243,79 +282,165 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    result = None
     if rank == 0:
-        total_frames = K * world * B
-        fps = total_frames / elapsed
-        # per-kernel durations from HIP events recorded on the launch stream inside the C ABI
-        poser.set_timing(True)
-        acc = np.zeros(len(KERNEL_NAMES))
-        whole = 0.0
-        nprof = max(1, args.profile_frames)
-        with torch.no_grad():
-            for i in range(nprof):
-                poser.pose(image, poses[W + (i % K)])
-                for k in range(len(KERNEL_NAMES)):
-                    acc[k] += poser.last_kernel_ms(k)
-                whole += poser.last_kernel_ms(-1)
-        poser.set_timing(False)
-        kernel_ms = {n: float(acc[k] / nprof) for k, n in enumerate(KERNEL_NAMES)}
-        dom = max(GFLOP_KERNEL, key=lambda n: kernel_ms[n])
-        achieved = GFLOP_KERNEL[dom] * B / kernel_ms[dom]        # GFLOP / ms = TFLOP/s
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_F16_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
-                    "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
-                    "frac_of_split_ceiling": round(achieved * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
-                    "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": PMC_TRAFFIC_BYTES.get(dom) if B == 1 else None, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_student_b1_profile.md)",
-                    "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
-                    "frame_event_ms": round(whole / nprof, 4),
-                    "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
-                    "whole_frame_frac": round(fps / world * GFLOP_FRAME / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
-                    "algorithmic_gflop_per_frame": GFLOP_FRAME, "executed_gflop_per_frame": GFLOP_EXECUTED_FRAME}
-        # SURVEY.md §8d config 2 also asks for the rate with the display epilogue + D2H of the RGBA8 frame included (what a
-        # puppeteer actually consumes): pose -> tha4_display_rgba8 -> async copy into a pinned ring, same stream.  Never `value`.
-        d2h = None
-        if world == 1 and B == 1 and args.d2h_frames > 0:
-            from tha4_amd import image_io
-            ring = [torch.empty((1, 512, 512, 4), dtype=torch.uint8).pin_memory() for _ in range(4)]
-            with torch.no_grad():
-                for i in range(8):
-                    ring[i % 4].copy_(image_io.to_display_rgba8(poser.pose(image, poses[W + i])), non_blocking=True)
-                torch.cuda.synchronize(dev)
-                t0d = time.perf_counter()
-                for i in range(args.d2h_frames):
-                    ring[i % 4].copy_(image_io.to_display_rgba8(poser.pose(image, poses[W + (i % K)])), non_blocking=True)
-                torch.cuda.synchronize(dev)
-                dtd = time.perf_counter() - t0d
-            d2h = {"fps": round(args.d2h_frames / dtd, 2), "frames": args.d2h_frames,
-                   "what": "pose + sRGB/uint8 display epilogue + async D2H of the 1 MiB RGBA8 frame into pinned host memory (PCIe-inclusive)"}
-        cpu = cpu_baseline(w, image_np, poses_cpu, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
-        full = None
-        if args.full_frames > 0 and world == 1:
-            try:
-                poser.free()
-                full = measure_full(dev, image, args.full_frames)
-            except Exception as e:      # the headline number must not depend on the secondary measurement
-                full = {"error": repr(e)}
+        fps = K * B * world / elapsed
         result = {
-            "metric": "frames/sec (whole job) on 512x512 RGBA + 45-dim pose, distilled student",
+            "metric": ("frames/sec (whole job) on 512x512 RGBA + 45-dim pose, " + ("distilled student" if student else "full THA4 model")),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic pose stream (seed 1234+rank, pose_parameters ranges); lambda_00 student weights + image fixture (tests/golden)",
-            "config": {"workload": ("configs[1]: lambda_00 distilled student, batch=1 real-time stream, 512x512 RGBA, one Poser.pose() per frame" if B == 1 else
-                                    f"configs[3]-style: one lambda_00 character instance per GPU, batch={B} pose stream per Poser.pose() call"),
-                       "frames_per_gpu": K * B, "batch": B, "parallelism": f"frame-parallel x{world}",
-                       "gather": bool(world > 1 and not args.no_gather and B == 1)},
-            "per_gpu_fps": round(fps / world, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "with_rgba8_d2h": d2h,
-            "full_model": full,
-        }
+            "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE, "per_gpu_fps": round(fps / world, 2)}
+        par = {"frames_per_gpu": K * B, "batch": B, "parallelism": f"frame-parallel x{world}",
+               "gather": ("rgba8" if args.rgba8_gather else "fp32") if gather else False}
+        if student:
+            result["data"] = ("synthetic pose stream (seed 1234+rank, pose_parameters ranges); shipped student weights + character image "
+                              "(tests/golden fixtures made from the reference's lambda_00 / lambda_01 .pt and .png)")
+            wl = ("configs[1]: lambda_00 distilled student, batch=1 real-time stream, 512x512 RGBA, one Poser.pose() per frame" if (B == 1 and characters == "lambda_00") else
+                  f"configs[3]: one distilled-student character instance per GPU ({characters}), batch={B} pose stream per Poser.pose() call")
+            result["config"] = dict(workload=wl, characters=characters, **par)
+            result.update(student_extras(args, work, dev, world, fps, K, W, B))
+        else:
+            result["data"] = ("synthetic seeded weights (tha4_amd.synthetic; the reference checkout ships none); " +
+                              ("lambda_00 image fixture" if B == 1 else "random 512x512 RGBA images (seed 99+, change every batch)") + "; random poses")
+            wl = (f"configs[2]: THA4 full model (5 networks), batch=1, lambda_00 image, {'cold (image changes every frame)' if args.cold else 'steady state (eyebrow decomposer cached)'}"
+                  if B == 1 else f"configs[4]: THA4 full model, batch={B} random images + poses per GPU and step ({B * world} frames per step), frame-parallel, decomposer never cached")
+            result["config"] = dict(workload=wl, **par)
+            result.update(full_extras(args, work, dev, world, fps, B))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def student_extras(args, work, dev, world, fps, K, W, B):
+    poser, image, poses = work.poser, work.image, work.poses
+    # per-kernel durations from HIP events recorded on the launch stream inside the C ABI
+    poser.set_timing(True)
+    acc = np.zeros(len(KERNEL_NAMES))
+    whole = 0.0
+    nprof = max(1, args.profile_frames)
+    with torch.no_grad():
+        for i in range(nprof):
+            work.step(W + (i % K))
+            for k in range(len(KERNEL_NAMES)):
+                acc[k] += poser.last_kernel_ms(k)
+            whole += poser.last_kernel_ms(-1)
+    poser.set_timing(False)
+    kernel_ms = {n: float(acc[k] / nprof) for k, n in enumerate(KERNEL_NAMES)}
+    dom = max(GFLOP_KERNEL, key=lambda n: kernel_ms[n])
+    achieved = GFLOP_KERNEL[dom] * B / kernel_ms[dom]        # GFLOP / ms = TFLOP/s
+    prof, prof_file = newest_profile("r*_student_b1_traffic.json")
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_F16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
+                "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
+                "frac_of_split_ceiling": round(achieved * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
+                "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": kernel_traffic_bytes(prof, dom) if B == 1 else None,
+                "traffic_unit": f"bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes in {prof_file}",
+                "traffic_per_frame": (sum(kernel_traffic_bytes(prof, n) or 0 for n in KERNEL_NAMES) if (B == 1 and prof) else None),
+                "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                "frame_event_ms": round(whole / nprof, 4),
+                "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
+                "whole_frame_frac": round(fps / world * GFLOP_FRAME / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
+                "algorithmic_gflop_per_frame": GFLOP_FRAME, "executed_gflop_per_frame": GFLOP_EXECUTED_FRAME}
+    out = {"roofline": roofline, "cpu_baseline": None}
+    single = world == 1 and B == 1
+    if single and args.exact_frames > 0:
+        # A/B: the exact-fp32 MFMA generation (v_mfma_f32_16x16x4_f32, THA4_STUDENT_EXACT_FP32) on the same stream
+        face, body = split_flat_weights(work.w)
+        exact = mode_14.create_poser_from_state_dicts(dev, face, body, exact_fp32=True)
+        with torch.no_grad():
+            for i in range(20):
+                exact.pose(image, poses[i, 0])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(args.exact_frames):
+                exact.pose(image, poses[W + (i % K), 0])
+            torch.cuda.synchronize(dev)
+            dte = time.perf_counter() - t0
+        exact.free()
+        roofline["exact_fp32_generation"] = {"fps": round(args.exact_frames / dte, 2), "frames": args.exact_frames,
+                                             "achieved_tflops": round(args.exact_frames / dte * GFLOP_FRAME / 1e3, 2),
+                                             "frac_of_fp32_mfma_peak": round(args.exact_frames / dte * GFLOP_FRAME / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                             "what": "same stream on the exact-fp32 kernels (v_mfma_f32_16x16x4_f32, csrc/siren_kernels.h)"}
+    if single and args.d2h_frames > 0:
+        # SURVEY.md §8d config 2 also asks for the rate with the display epilogue + D2H of the RGBA8 frame included (what a
+        # puppeteer actually consumes): pose -> tha4_display_rgba8 -> async copy into a pinned ring.  PCIe-inclusive: never `value`.
+        from tha4_amd import image_io
+        ring = [torch.empty((1, 512, 512, 4), dtype=torch.uint8).pin_memory() for _ in range(4)]
+        with torch.no_grad():
+            for i in range(8):
+                ring[i % 4].copy_(image_io.to_display_rgba8(work.step(W + i)), non_blocking=True)
+            torch.cuda.synchronize(dev)
+            t0d = time.perf_counter()
+            for i in range(args.d2h_frames):
+                ring[i % 4].copy_(image_io.to_display_rgba8(work.step(W + (i % K))), non_blocking=True)
+            torch.cuda.synchronize(dev)
+            dtd = time.perf_counter() - t0d
+        out["with_rgba8_d2h"] = {"fps": round(args.d2h_frames / dtd, 2), "frames": args.d2h_frames,
+                                 "what": "pose + sRGB/uint8 display epilogue + async D2H of the 1 MiB RGBA8 frame into pinned host memory (PCIe-inclusive)"}
+    if world == 1 and args.cpu_seconds > 0:
+        from oracle import student_oracle as so          # cpu_baseline leg only (oracle/ is test infrastructure)
+        w, image_np, poses_cpu = work.w, work.image_np, work.poses_cpu
+        out["cpu_baseline"] = cpu_baseline(lambda i: so.student_forward_torch(w, image_np, poses_cpu[i % poses_cpu.shape[0]].numpy(), "float32"),
+                                           f"{work.character} student stream, oracle.student_forward_torch fp32", args.cpu_seconds, 48)
+    if single and args.full_frames > 0:
+        try:      # secondary: configs[2] in the same process (the headline must not depend on it)
+            poser.free()
+            fw = FullWork(dev, 0, 1, args.full_frames + 3, steady=True)
+            out["full_model"] = measure_full_b1(fw, dev, args.full_frames)
+            fw.poser.free()
+        except Exception as e:
+            out["full_model"] = {"error": repr(e)}
+    return out
+
+
+def measure_full_b1(fw, dev, frames):
+    res = {}
+    with torch.no_grad():
+        for i in range(3):
+            fw.step(i)
+        for name, steady, gflop in (("steady", True, GFLOP_FULL_STEADY), ("cold", False, GFLOP_FULL_COLD)):
+            fw.steady = steady
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(frames):
+                fw.step(3 + i)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            f = frames / dt
+            res[name] = {"fps": round(f, 2), "ms_per_frame": round(1e3 * dt / frames, 3), "achieved_tflops": round(f * gflop / 1e3, 2),
+                         "frac_of_f16_mfma_peak": round(f * gflop / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
+                         "frac_of_split_ceiling": round(f * gflop * MFMA_PASSES / 1e3 / PEAK_F16_MFMA_TFLOPS, 4)}
+    return res
+
+
+def full_extras(args, work, dev, world, fps, B):
+    cold = args.cold or B > 1
+    gflop = GFLOP_FULL_COLD if cold else GFLOP_FULL_STEADY
+    ach = fps / world * gflop / 1e3
+    prof, prof_file = newest_profile("r*_full_b1_traffic.json")
+    per_frame = None
+    if prof and B == 1:
+        per_frame = prof.get("cold_frame_bytes" if cold else "steady_frame_bytes")
+    roofline = {"bound": "mfma", "kernel": "whole frame (static schedule of conv_tile / conv_small / attention / image kernels)",
+                "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
+                "frac_of_split_ceiling": round(ach * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
+                "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
+                "traffic": per_frame, "traffic_unit": f"bytes/frame = sum over the frame's launches of 2 x FETCH_SIZE + WRITE_SIZE ({prof_file})",
+                "algorithmic_gflop_per_frame": gflop}
+    out = {"roofline": roofline, "cpu_baseline": None}
+    if world == 1 and B == 1:
+        other = FullWork.__new__(FullWork)
+        other.__dict__.update(work.__dict__)
+        out["steady_and_cold"] = measure_full_b1(other, dev, max(10, min(50, args.steps or 50)))
+    if world == 1 and args.cpu_seconds > 0:
+        from oracle import full_oracle as fo             # cpu_baseline leg only
+        w = synthetic.synth_full_weights()
+        poses = make_poses(4, seed=77).numpy()
+        img = work.image_np
+        out["cpu_baseline"] = cpu_baseline(lambda i: fo.full_forward_torch(w, img, poses[i % 4], "float32"),
+                                           "cold frames of the full model, oracle.full_forward_torch fp32, synthetic weights", args.cpu_seconds, 12)
+    return out
 
 
 if __name__ == "__main__":

@@ -3,7 +3,9 @@ collective, finished frames gathered to rank 0 (RCCL over xGMI when the backend 
 
 The reference has no inference-time multi-GPU path (SURVEY.md §2 "Parallelism"); frames are
 independent, so the only exchange is the final gather of ``[n,4,512,512]`` blocks.
-The gather of chunk c is issued on a side stream and overlaps the compute of chunk c+1.
+The gather of chunk c is issued on a side stream and overlaps the compute of chunk c+1.  A "frame" is whatever
+``frame_fn`` produces per index: fp32 ``[4,512,512]`` posed frames, or - with the display epilogue applied before the
+exchange - ``uint8 [512,512,4]`` (a quarter of the bytes).
 Backend-agnostic: the unit tests run it with ``gloo`` on CPU and a stub frame function.
 """
 from __future__ import annotations
@@ -77,48 +79,47 @@ class FrameShardedStream:
                 raise RuntimeError(f"result buffer must be a contiguous {self.dtype} tensor of shape {want}")
         cuda = self.device.type == "cuda"
         side = torch.cuda.Stream(device=self.device) if (cuda and self.gather) else None
-        dst = dist.get_global_rank(self.group, 0) if (self.gather and self.group is not None) else 0
-        keep = []   # receive buffers stay alive until the side stream has drained
+        root = dist.get_global_rank(self.group, 0) if (self.gather and self.group is not None) else 0
+
+        def span(r, c):                      # global rows [a, b) rank r produces in round c (analytic: no size exchange)
+            rlo, rhi = shard_bounds(self.total, r, self.world)
+            a = min(rlo + c * self.chunk, rhi)
+            return a, min(a + self.chunk, rhi)
+
         for c in range(rounds):
-            a = min(self.lo + c * self.chunk, self.hi)
-            b = min(a + self.chunk, self.hi)
-            block = self.frame_fn(a, b) if b > a else self._empty(0)
-            if tuple(block.shape) != (b - a,) + self.frame_shape:
-                raise RuntimeError(f"frame_fn returned {tuple(block.shape)} for frames [{a},{b})")
+            a, b = span(self.rank, c)
+            block = self.frame_fn(a, b) if b > a else None
+            if block is not None and (tuple(block.shape) != (b - a,) + self.frame_shape or block.dtype != self.dtype):
+                raise RuntimeError(f"frame_fn returned {tuple(block.shape)} {block.dtype} for frames [{a},{b})")
             if not self.gather:
-                result[a - self.lo:b - self.lo] = block
+                if block is not None:
+                    result[a - self.lo:b - self.lo] = block
                 continue
-            # regular collective: every rank sends exactly `chunk` rows; valid counts are analytic
-            if block.shape[0] == self.chunk:
-                send = block
-            else:
-                send = torch.zeros((self.chunk,) + self.frame_shape, dtype=self.dtype, device=self.device)
-                send[:block.shape[0]] = block
+            spans = [span(r, c) for r in range(self.world)]
+            full_round = all(rb - ra == self.chunk for ra, rb in spans)
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(self.device))
-                send.record_stream(side)
+                if block is not None:
+                    block.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
-                recv, tails = None, []
-                if self.rank == 0:
-                    # full chunks land directly in their rows of `result` (no staging copy on the root, which also
-                    # has its own frames to compute); only a rank's ragged last chunk goes through a temporary
-                    recv = []
-                    for r in range(self.world):
-                        rlo, rhi = shard_bounds(self.total, r, self.world)
-                        ra = min(rlo + c * self.chunk, rhi)
-                        rb = min(ra + self.chunk, rhi)
-                        if rb - ra == self.chunk:
-                            recv.append(result[ra:rb])
-                        else:
-                            tmp = self._empty(self.chunk)
-                            recv.append(tmp)
-                            tails.append((tmp, ra, rb))
-                dist.gather(send, recv, dst=dst, group=self.group)
-                if self.rank == 0:
-                    for tmp, ra, rb in tails:
-                        if rb > ra:
-                            result[ra:rb] = tmp[:rb - ra]
-                    keep.append(tails)
+                if full_round:
+                    # regular round: ONE collective, every chunk lands directly in its rows of `result` on the root
+                    recv = [result[ra:rb] for ra, rb in spans] if self.rank == 0 else None
+                    dist.gather(block, recv, dst=root, group=self.group)
+                else:
+                    # ragged round (the tail of the stream): exact-size point-to-point transfers - a rank with a short
+                    # or empty tail sends only what it has (nothing is zero-padded to a full chunk)
+                    if self.rank == 0:
+                        if block is not None:
+                            result[a:b] = block
+                        ops = [dist.P2POp(dist.irecv, result[ra:rb], dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                          group=self.group)
+                               for r, (ra, rb) in enumerate(spans) if r != 0 and rb > ra]
+                    else:
+                        ops = [dist.P2POp(dist.isend, block, root, group=self.group)] if block is not None else []
+                    if ops:
+                        for req in dist.batch_isend_irecv(ops):
+                            req.wait()
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
         return result

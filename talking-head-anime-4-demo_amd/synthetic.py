@@ -199,3 +199,27 @@ def synth_full_weights(seed: int = 20260925, small_gain: float = 1.0, conv_gain:
     return out
 
 
+
+
+def random_rgba_images(n: int, seed: int = 99, size: int = 512) -> np.ndarray:
+    """`n` synthetic poser inputs [n,4,size,size] fp32 of the SURVEY.md §8d config-5 recipe: values U[-1,1) with the
+    alpha channel U[0,1) and RGB premultiplied, i.e. linear rgb ~ U[0,1), a ~ U[0,1), image = cat(rgb * a, a) * 2 - 1
+    (the convention of extract_pytorch_image_from_PIL_image, src/tha4/shion/base/image_util.py:127-149).  Drawn on a
+    size/8 lattice and bilinearly enlarged so that warps sample a band-limited image.  Benchmark / test input only."""
+    rng = np.random.default_rng(seed)
+    lo = rng.uniform(0.0, 1.0, size=(n, 4, size // 8, size // 8))
+    img = lo
+    for _ in range(3):                              # x2 bilinear, align_corners=False, edge clamped (three times: x8)
+        for axis in (2, 3):
+            m = img.shape[axis]
+            j = np.arange(2 * m)
+            src = (j + 0.5) / 2.0 - 0.5
+            i0 = np.clip(np.floor(src).astype(int), 0, m - 1)
+            i1 = np.clip(i0 + 1, 0, m - 1)
+            t = np.clip(src - np.floor(src), 0.0, 1.0)
+            t = np.where(src < 0, 0.0, t)
+            shape = [1, 1, 1, 1]
+            shape[axis] = 2 * m
+            img = np.take(img, i0, axis=axis) * (1.0 - t.reshape(shape)) + np.take(img, i1, axis=axis) * t.reshape(shape)
+    img[:, 0:3] *= img[:, 3:4]
+    return (img * 2.0 - 1.0).astype(np.float32)

@@ -29,7 +29,7 @@ def _frame(i):
     return torch.rand(2, 4, 4, generator=g)
 
 
-def _worker(rank, world, port, total, chunk, gather, q):
+def _worker(rank, world, port, total, chunk, gather, q, rgba8=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,13 +37,20 @@ def _worker(rank, world, port, total, chunk, gather, q):
 
     def frame_fn(lo, hi):
         calls.append((lo, hi))
-        return torch.stack([_frame(i) for i in range(lo, hi)])
+        blk = torch.stack([_frame(i) for i in range(lo, hi)])
+        return _to_u8(blk) if rgba8 else blk
 
-    s = FrameShardedStream(frame_fn, total, (2, 4, 4), torch.float32, torch.device("cpu"), chunk=chunk, gather=gather)
+    shape, dtype = ((4, 4, 2), torch.uint8) if rgba8 else ((2, 4, 4), torch.float32)
+    s = FrameShardedStream(frame_fn, total, shape, dtype, torch.device("cpu"), chunk=chunk, gather=gather)
     out = s.run(s.allocate_result()) if total % 2 else s.run()      # both entry points: caller-provided / internal buffer
     q.put((rank, s.local_range(), calls, None if out is None else out.clone()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _to_u8(blk):
+    """stand-in for the display epilogue: [n,2,4,4] fp32 -> [n,4,4,2] uint8 (HWC bytes), a quarter of the bytes"""
+    return (blk.permute(0, 2, 3, 1) * 255.0).to(torch.uint8).contiguous()
 
 
 def _free_port():
@@ -52,7 +59,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("total,chunk", [(11, 4), (8, 8), (1, 4), (5, 1)])
+@pytest.mark.parametrize("total,chunk", [(11, 4), (8, 8), (1, 4), (5, 1), (16, 4), (3, 8)])
 def test_two_rank_gather_reassembles_stream(total, chunk):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -117,3 +124,25 @@ def test_preallocated_result_is_validated():
     import pytest
     with pytest.raises(RuntimeError):
         s.run(torch.empty(4, 2, 4, 4))
+
+
+def test_two_rank_rgba8_gather():
+    """Display epilogue BEFORE the exchange: uint8 HWC frames gathered, same row placement."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    total, chunk = 13, 4
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, chunk, True, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = res[0][3]
+    assert full.dtype == torch.uint8 and full.shape == (total, 4, 4, 2)
+    for i in range(total):
+        assert torch.equal(full[i], _to_u8(_frame(i)[None])[0])

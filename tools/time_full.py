@@ -16,7 +16,9 @@ poses = torch.from_numpy(io["poses"]).to(dev)
 for i in range(3): p.pose(image, poses[i % 8])
 torch.cuda.synchronize()
 NFRAMES = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 20
-for name, changed in (("steady", False), ("cold", True)):
+MODES = {"steady": [("steady", False)], "cold": [("cold", True)], "both": [("steady", False), ("cold", True)]}[
+    sys.argv[sys.argv.index("--mode") + 1] if "--mode" in sys.argv else "both"]
+for name, changed in MODES:
     n = NFRAMES
     t0 = time.perf_counter()
     for i in range(n): p.pose(image, poses[i % 8], image_changed=changed)

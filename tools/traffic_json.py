@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, one pass each - together they abort rocprofv3 on this image) ->
+the machine-readable traffic summary bench.py reads from profiles/ (`roofline.traffic`).
+
+  student:  python tools/traffic_json.py student <fetch dir> <write dir> -o profiles/r02_student_b1_traffic.json
+  full:     python tools/traffic_json.py full <fetch dir> <write dir> --frames N [--cold-fetch D --cold-write D --cold-frames N] -o ...
+
+Per kernel: average KiB per launch (rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB).  HBM bytes = 2 x FETCH_SIZE
+(gfx950 wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+STUDENT = {"posebias_kernel": "posebias", "face16_kernel": "face", "level0_16_kernel": "level0", "level1_16_kernel": "level1",
+           "level2_16p_kernel": "level2", "level2_16_kernel": "level2", "student_front_kernel": "front"}
+
+
+def per_kernel(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", choices=["student", "full"])
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--cold-fetch")
+    ap.add_argument("--cold-write")
+    ap.add_argument("--cold-frames", type=int, default=0)
+    ap.add_argument("--command", default="")
+    ap.add_argument("-o", required=True)
+    a = ap.parse_args()
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per-launch averages; tools/traffic_json.py",
+           "command": a.command, "unit": "KiB per launch", "fetch_correction": "x2 (gfx950 wide reads, MI355X_MICROARCH.md HBM section)"}
+    fe, wr = per_kernel(a.fetch_dir, "FETCH_SIZE"), per_kernel(a.write_dir, "WRITE_SIZE")
+    if a.model == "student":
+        ks = {}
+        for k, short in STUDENT.items():
+            if k in fe:
+                ks[short] = {"fetch_kib": round(sum(fe[k]) / len(fe[k]), 2), "write_kib": round(sum(wr[k]) / len(wr[k]), 2), "launches": len(fe[k])}
+        out["kernels"] = ks
+    else:
+        def frame_bytes(fe, wr, frames):
+            return int(round(sum(2.0 * sum(v) for v in fe.values()) * 1024 / frames + sum(sum(v) for v in wr.values()) * 1024 / frames))
+        out["steady_frame_bytes"] = frame_bytes(fe, wr, a.frames)
+        out["steady_frames"] = a.frames
+        out["kernels"] = {k: {"fetch_kib": round(sum(v) / len(v), 2), "write_kib": round(sum(wr[k]) / max(1, len(wr[k])), 2), "launches_per_frame": round(len(v) / a.frames, 2)}
+                          for k, v in sorted(fe.items(), key=lambda kv: -sum(kv[1]))}
+        if a.cold_fetch:
+            out["cold_frame_bytes"] = frame_bytes(per_kernel(a.cold_fetch, "FETCH_SIZE"), per_kernel(a.cold_write, "WRITE_SIZE"), a.cold_frames)
+            out["cold_frames"] = a.cold_frames
+    with open(a.o, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
