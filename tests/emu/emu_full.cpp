@@ -1,10 +1,70 @@
-// CPU emulation harness for the full-model kernels (TEST INFRASTRUCTURE ONLY): runs conv_mfma /
-// norm_finalize / gemv / attention workgroup by workgroup on host buffers for tests/test_emu_full.py.
+// Per-op harness for the full-model kernels (TEST INFRASTRUCTURE ONLY), two builds of this one file:
+//   * default (clang++, -DTHA4_EMU implied): CPU SIMT emulation - runs conv_mfma / conv_tile / norm_finalize / gemv /
+//     attention workgroup by workgroup on host buffers (tests/test_emu_full.py, libtha4_emu_full.so);
+//   * -DOPS_DEVICE (hipcc --offload-arch=gfx950): the SAME drivers launch the real kernels on the GPU
+//     (tests/test_ops_device.py, -m gpu, libtha4_ops_device.so) - per-op DEVICE tests against torch fp64.
+#ifdef OPS_DEVICE
+#include <hip/hip_runtime.h>
+#else
 #define THA4_EMU 1
+#endif
 #include "full_conv16_kernels.h"
+#include "full_image_kernels.h"
 #include "full_layout.h"
 
+#include <vector>
+
 using namespace tha4;
+
+namespace {
+#ifdef OPS_DEVICE
+struct Mirror {                       // host vector <-> device buffer bookkeeping of one driver call
+  struct Item { void* d; void* h; size_t bytes; };
+  std::vector<Item> items;
+  template <class T> T* up(std::vector<T>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(v.size() * sizeof(T), 16)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    items.push_back({d, v.data(), v.size() * sizeof(T)});
+    return static_cast<T*>(d);
+  }
+  template <class T> T* up(const T* p, size_t n) {      // read-only caller memory
+    if (!p) return nullptr;
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(n * sizeof(T), 16)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, p, n * sizeof(T), hipMemcpyHostToDevice);
+    items.push_back({d, nullptr, 0});
+    return static_cast<T*>(d);
+  }
+  template <class T> void down(std::vector<T>& v) {
+    for (auto& it : items) if (it.h == v.data()) (void)hipMemcpy(v.data(), it.d, it.bytes, hipMemcpyDeviceToHost);
+  }
+  template <class T> void down(T* host, const T* dev, size_t n) { (void)hipMemcpy(host, dev, n * sizeof(T), hipMemcpyDeviceToHost); }
+  int sync() { return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess ? 0 : -9; }
+  ~Mirror() { for (auto& it : items) (void)hipFree(it.d); }
+};
+#define THA4_RUN(KERNEL, GRID, THREADS, LDS, ARGS)                                                                      \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), LDS, 0, ARGS);                                                      \
+  } while (0)
+#else
+struct Mirror {
+  template <class T> T* up(std::vector<T>& v) { return v.data(); }
+  template <class T> T* up(const T* p, size_t) { return const_cast<T*>(p); }
+  template <class T> void down(std::vector<T>&) {}
+  template <class T> void down(T* host, const T* dev, size_t n) { if (host != dev) std::memcpy(host, dev, n * sizeof(T)); }
+  int sync() { return 0; }
+};
+#define THA4_RUN(KERNEL, GRID, THREADS, LDS, ARGS)                                                   \
+  do {                                                                                               \
+    const dim3 g_ = (GRID);                                                                          \
+    for (unsigned bz_ = 0; bz_ < g_.z; ++bz_)                                                        \
+      for (unsigned by_ = 0; by_ < g_.y; ++by_)                                                      \
+        for (unsigned bx_ = 0; bx_ < g_.x; ++bx_) emu::run_block(KERNEL, g_, dim3(bx_, by_, bz_), THREADS, LDS, ARGS); \
+  } while (0)
+#endif
+}  // namespace
 
 extern "C" {
 
@@ -60,6 +120,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   std::vector<int> A((size_t)nb * 16, 0);
   if (act_out) std::memcpy(A.data(), act_out, sizeof(int) * cout);
   std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
+  Mirror M;
   const bool splitk = pg == 0;
   const bool tiled = pg >= 10;              // conv_tile_kernel<tmb, pg - 10>
   const int tpg = pg - 10;
@@ -72,6 +133,9 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   if (!splitk && !tiled && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
   const int stats_tiles = tiles_per_class * nclass;
   std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
+  float *dX0 = M.up(X0), *dX1 = c1 > 0 ? M.up(X1) : nullptr, *dR = residual ? M.up(R) : nullptr, *dB = M.up(B), *dO = M.up(O), *dST = M.up(ST);
+  int* dA = M.up(A);
+  float *dsc0 = scale ? M.up(sc0) : nullptr, *dsh0 = scale ? M.up(sh0) : nullptr, *dsc1 = scale ? M.up(sc1) : nullptr, *dsh1 = scale ? M.up(sh1) : nullptr;
   std::vector<ChannelSegment> segs = {{0, c0}};
   if (c1 > 0) segs.push_back({c0, c1});
   const int mtiles = (nb + tmb - 1) / tmb;
@@ -80,10 +144,10 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     ConvGeom g = kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1));
     std::vector<float> P = pack_conv_weight(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb);
     ConvArgs a{};
-    a.src[0] = ConvSrc{X0.data(), scale ? sc0.data() : nullptr, scale ? sh0.data() : nullptr, cb0, SRC_TENSOR, act_in};
+    a.src[0] = ConvSrc{dX0, dsc0, dsh0, cb0, SRC_TENSOR, act_in};
     a.nsrc = 1;
     if (c1 > 0) {
-      a.src[1] = ConvSrc{X1.data(), (scale && !vec1) ? sc1.data() : nullptr, (scale && !vec1) ? sh1.data() : nullptr, cb1,
+      a.src[1] = ConvSrc{dX1, (scale && !vec1) ? dsc1 : nullptr, (scale && !vec1) ? dsh1 : nullptr, cb1,
                           vec1 ? SRC_VECTOR : SRC_TENSOR, vec1 ? ACT_NONE : act_in};   // the pose vector is concatenated raw
       a.nsrc = 2;
     }
@@ -93,8 +157,8 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     a.in_stride = g.in_stride;
     a.tile_h = th; a.tile_w = tw; a.out_h = oh; a.out_w = ow;
     a.out_sy = g.out_sy; a.out_sx = g.out_sx; a.out_oy = g.out_oy; a.out_ox = g.out_ox;
-    a.w = P.data(); a.bias = bias ? B.data() : nullptr; a.residual = residual ? R.data() : nullptr; a.res_mode = IN_DIRECT;
-    a.act_out = act_out ? A.data() : nullptr; a.out = O.data(); a.stats = ST.data();
+    a.w = M.up(P); a.bias = bias ? dB : nullptr; a.residual = residual ? dR : nullptr; a.res_mode = IN_DIRECT;
+    a.act_out = act_out ? dA : nullptr; a.out = dO; a.stats = dST;
     a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
     a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
     std::vector<char> P16;
@@ -104,10 +168,10 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       tg = tile_geom(g, th, tw, tpg, tmb, tw_log2);
       if (!tg.ok) return -4;
       partial.assign((size_t)ksplit * n * mtiles * tg.tiles * tmb * 8 * tpg * 64 * 4, 0.f);
-      a.partial = partial.data(); a.ksplit = ksplit;
+      a.partial = M.up(partial); a.ksplit = ksplit;
       float inv = 1.f;
       P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb, &inv);
-      a.w16 = P16.data(); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
+      a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
       a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots;
     }
     const size_t lds = tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
@@ -116,33 +180,32 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     a.phase = phases == 1 ? 0 : ph + 1;
     const int run_tmb = a.phase == 2 ? 1 : tmb;          // phase 2 runs one output block per workgroup
     dim3 grid(n * tiles_per_class, a.phase == 2 ? nb : mtiles, a.phase == 1 ? ksplit : 1);
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-#define RUN(TM, PGV)                                                                                               \
-  if (tmb == TM && pg == PGV) {                                                                                     \
-    if (in_mode == IN_DIRECT) emu::run_block(conv_mfma_kernel<TM, PGV, IN_DIRECT>, grid, dim3(bx, by), 256, lds, a); \
-    else if (in_mode == IN_UP2) emu::run_block(conv_mfma_kernel<TM, PGV, IN_UP2>, grid, dim3(bx, by), 256, lds, a);  \
-    else emu::run_block(conv_mfma_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by), 256, lds, a);                       \
+#define RUN(TM, PGV)                                                                                        \
+  if (!tiled && !splitk && tmb == TM && pg == PGV) {                                                        \
+    if (in_mode == IN_DIRECT) THA4_RUN((conv_mfma_kernel<TM, PGV, IN_DIRECT>), grid, 256, lds, a);          \
+    else if (in_mode == IN_UP2) THA4_RUN((conv_mfma_kernel<TM, PGV, IN_UP2>), grid, 256, lds, a);           \
+    else THA4_RUN((conv_mfma_kernel<TM, PGV, IN_POOL2>), grid, 256, lds, a);                                \
   }
-        RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
-#define RUNT(TM, PGV)                                                                                                          \
-  if (tiled && run_tmb == TM && tpg == PGV) {                                                                                       \
-    if (in_mode == IN_DIRECT) emu::run_block(conv_tile_kernel<TM, PGV, IN_DIRECT>, grid, dim3(bx, by, bz), kTileThreads, lds, a);    \
-    else if (in_mode == IN_UP2) emu::run_block(conv_tile_kernel<TM, PGV, IN_UP2>, grid, dim3(bx, by, bz), kTileThreads, lds, a);     \
-    else emu::run_block(conv_tile_kernel<TM, PGV, IN_POOL2>, grid, dim3(bx, by, bz), kTileThreads, lds, a);                          \
-  }
-        RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 4) RUNT(1, 2) RUNT(1, 1)
-#undef RUNT
-        if (splitk && tmb == 4) {
-          if (in_mode == IN_DIRECT) emu::run_block(conv_splitk_kernel<4, IN_DIRECT>, grid, dim3(bx, by), 256, lds, a);
-          else if (in_mode == IN_UP2) emu::run_block(conv_splitk_kernel<4, IN_UP2>, grid, dim3(bx, by), 256, lds, a);
-          else emu::run_block(conv_splitk_kernel<4, IN_POOL2>, grid, dim3(bx, by), 256, lds, a);
-        }
+    RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
 #undef RUN
-      }
+#define RUNT(TM, PGV)                                                                                       \
+  if (tiled && run_tmb == TM && tpg == PGV) {                                                               \
+    if (in_mode == IN_DIRECT) THA4_RUN((conv_tile_kernel<TM, PGV, IN_DIRECT>), grid, kTileThreads, lds, a); \
+    else if (in_mode == IN_UP2) THA4_RUN((conv_tile_kernel<TM, PGV, IN_UP2>), grid, kTileThreads, lds, a);  \
+    else THA4_RUN((conv_tile_kernel<TM, PGV, IN_POOL2>), grid, kTileThreads, lds, a);                       \
+  }
+    RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 4) RUNT(1, 2) RUNT(1, 1)
+#undef RUNT
+    if (splitk && tmb == 4) {
+      if (in_mode == IN_DIRECT) THA4_RUN((conv_splitk_kernel<4, IN_DIRECT>), grid, 256, lds, a);
+      else if (in_mode == IN_UP2) THA4_RUN((conv_splitk_kernel<4, IN_UP2>), grid, 256, lds, a);
+      else THA4_RUN((conv_splitk_kernel<4, IN_POOL2>), grid, 256, lds, a);
+    }
     }
   }
+  if (M.sync() != 0) return -9;
+  M.down(O);
+  M.down(ST);
   for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * nb * opx * 16, cout, opx, out + (size_t)i * cout * opx);
   if (stats_out)
     for (int i = 0; i < n; ++i)
@@ -173,23 +236,35 @@ int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float
              int groups, float inv_count, float eps, const float* gamma, const float* beta, const float* film0,
              const float* film1, float* scale0, float* shift0, float* scale1, float* shift1) {
   NormArgs a{};
-  a.stats[0] = st0; a.tiles[0] = tiles0; a.cb[0] = cb0;
-  a.stats[1] = st1; a.tiles[1] = tiles1; a.cb[1] = cb1;
+  Mirror M;
+  std::vector<float> o0((size_t)n * cb0 * 16), h0(o0.size()), o1((size_t)n * std::max(cb1, 1) * 16), h1(o1.size());
+  a.stats[0] = M.up(st0, (size_t)n * tiles0 * cb0 * 16 * 2); a.tiles[0] = tiles0; a.cb[0] = cb0;
+  a.stats[1] = nsrc > 1 ? M.up(st1, (size_t)n * tiles1 * cb1 * 16 * 2) : nullptr; a.tiles[1] = tiles1; a.cb[1] = cb1;
   a.nsrc = nsrc; a.channels = channels; a.groups = groups; a.inv_count = inv_count; a.eps = eps;
-  a.gamma = gamma; a.beta = beta; a.film0 = film0; a.film1 = film1;
+  a.gamma = M.up(gamma, channels); a.beta = M.up(beta, channels);
+  a.film0 = M.up(film0, (size_t)n * 2 * channels); a.film1 = M.up(film1, (size_t)n * 2 * channels);
   a.film0_stride = 2 * channels; a.film1_stride = 2 * channels;
-  a.scale[0] = scale0; a.shift[0] = shift0; a.scale[1] = scale1; a.shift[1] = shift1;
+  a.scale[0] = M.up(o0); a.shift[0] = M.up(h0); a.scale[1] = M.up(o1); a.shift[1] = M.up(h1);
   const int ctot = (cb0 + (nsrc > 1 ? cb1 : 0)) * 16, S = std::max(1, kNormThreads / ctot);
   const size_t lds = ((size_t)S * ctot * 2 + 2 * ctot) * sizeof(double);
-  for (int i = 0; i < n; ++i) emu::run_block(norm_finalize_kernel, dim3(n), dim3(i), kNormThreads, lds, a);
+  THA4_RUN(norm_finalize_kernel, dim3(n), kNormThreads, lds, a);
+  if (M.sync() != 0) return -9;
+  M.down(o0); M.down(h0); M.down(o1); M.down(h1);
+  std::memcpy(scale0, o0.data(), o0.size() * sizeof(float));
+  std::memcpy(shift0, h0.data(), h0.size() * sizeof(float));
+  if (nsrc > 1) { std::memcpy(scale1, o1.data(), (size_t)n * cb1 * 16 * sizeof(float)); std::memcpy(shift1, h1.data(), (size_t)n * cb1 * 16 * sizeof(float)); }
   return 0;
 }
 
 int emu_gemv(int n, int rows, int k, const float* w, const float* bias, const float* x, int act_in, int act_out, float* y) {
-  GemvArgs a{w, bias, x, y, rows, k, (long long)k, act_in, act_out};
+  Mirror M;
+  std::vector<float> Y((size_t)n * rows, 0.f);
+  GemvArgs a{M.up(w, (size_t)rows * k), M.up(bias, (size_t)rows), M.up(x, (size_t)n * k), M.up(Y), rows, k, (long long)k, act_in, act_out};
   dim3 grid((rows + 3) / 4, n);
-  for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned bx = 0; bx < grid.x; ++bx) emu::run_block(gemv_kernel, grid, dim3(bx, by), 256, 0, a);
+  THA4_RUN(gemv_kernel, grid, 256, 0, a);
+  if (M.sync() != 0) return -9;
+  M.down(Y);
+  std::memcpy(y, Y.data(), Y.size() * sizeof(float));
   return 0;
 }
 
@@ -198,13 +273,53 @@ int emu_attention(int n, int channels, int heads, int tokens, const float* qkv, 
   const int cb3 = 3 * channels / 16, cb = channels / 16;
   std::vector<float> Q((size_t)n * cb3 * tokens * 16), O((size_t)n * cb * tokens * 16, 0.f);
   for (int i = 0; i < n; ++i) nchw_to_c16(qkv + (size_t)i * 3 * channels * tokens, 3 * channels, tokens, Q.data() + (size_t)i * cb3 * tokens * 16);
-  AttnArgs a{Q.data(), O.data(), channels, heads, tokens};
+  Mirror M;
+  AttnArgs a{M.up(Q), M.up(O), channels, heads, tokens};
   const size_t lds = (size_t)2 * tokens * kAttnRow * sizeof(f32x4);
   const dim3 grid(heads, n, tokens / kAttnQueries);
-  for (int i = 0; i < n; ++i)
-    for (int h = 0; h < heads; ++h)
-      for (unsigned z = 0; z < grid.z; ++z) emu::run_block(attention_kernel, grid, dim3(h, i, z), 256, lds, a);
+  THA4_RUN(attention_kernel, grid, 256, lds, a);
+  if (M.sync() != 0) return -9;
+  M.down(O);
   for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * cb * tokens * 16, channels, tokens, out + (size_t)i * channels * tokens);
+  return 0;
+}
+
+
+// U-Net tail (morpher_00.py:53-66 / upscaler_02.py:85-96): head NCHW [n][7][S][S] (direct 0-3 | grid 4-5 | alpha logit 6),
+// src NCHW [n][4][S][S] -> merged [n][4], alpha [n][1], warped [n][4], grid [n][2], direct [n][4]   (S = 256 or 512)
+int emu_unet_tail(int S, int n, const float* head, const float* src, float* merged, float* alpha, float* warped, float* grid, float* direct) {
+  const int P = S * S;
+  std::vector<float> H((size_t)n * P * 16, 0.f);
+  for (int i = 0; i < n; ++i) nchw_to_c16(head + (size_t)i * 7 * P, 7, P, H.data() + (size_t)i * P * 16);
+  std::vector<float> o0((size_t)n * 4 * P), o1((size_t)n * P), o2((size_t)n * 4 * P), o3((size_t)n * 2 * P), o4((size_t)n * 4 * P);
+  Mirror M;
+  ImgArgs a{};
+  a.head = M.up(H); a.in0 = M.up(src, (size_t)n * 4 * P); a.batch = n;
+  a.out[0] = M.up(o0); a.out[1] = M.up(o1); a.out[2] = M.up(o2); a.out[3] = M.up(o3); a.out[4] = M.up(o4);
+  const dim3 grid_((P + 255) / 256, n);
+  if (S == 256) THA4_RUN(unet_tail_kernel<256>, grid_, 256, 0, a);
+  else if (S == 512) THA4_RUN(unet_tail_kernel<512>, grid_, 256, 0, a);
+  else return -1;
+  if (M.sync() != 0) return -9;
+  M.down(o0); M.down(o1); M.down(o2); M.down(o3); M.down(o4);
+  std::memcpy(merged, o0.data(), o0.size() * 4); std::memcpy(alpha, o1.data(), o1.size() * 4); std::memcpy(warped, o2.data(), o2.size() * 4);
+  std::memcpy(grid, o3.data(), o3.size() * 4); std::memcpy(direct, o4.data(), o4.size() * 4);
+  return 0;
+}
+
+// upscaler input (mode_07.py:108-118, upscaler_02.py:78-83): rest [n][4][512][512], merged [n][4][256][256], grid [n][2][256][256]
+// -> the 14 channels [n][14][512][512]: rest | bilinear x2 (merged) | warp(rest, bilinear x2 (grid)) | bilinear x2 (grid)
+int emu_upscaler_input(int n, const float* rest, const float* merged, const float* grid, float* out14) {
+  const int P = 512 * 512;
+  std::vector<float> O((size_t)n * P * 16, 0.f);
+  Mirror M;
+  ImgArgs a{};
+  a.in0 = M.up(rest, (size_t)n * 4 * P); a.in1 = M.up(merged, (size_t)n * 4 * 256 * 256); a.in2 = M.up(grid, (size_t)n * 2 * 256 * 256);
+  a.c16_out = M.up(O); a.batch = n;
+  THA4_RUN(upscaler_input_kernel, dim3((P + 255) / 256, n), 256, 0, a);
+  if (M.sync() != 0) return -9;
+  M.down(O);
+  for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * P * 16, 14, P, out14 + (size_t)i * 14 * P);
   return 0;
 }
 

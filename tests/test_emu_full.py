@@ -272,3 +272,107 @@ def test_tile_conv_launch_plans(lib):
         seen_split |= ksplit > 1
         seen_ragged |= tiles * 128 * pg != th * tw
     assert seen_split and seen_ragged
+
+
+# ---- per-op edge cases; the same functions run on the device through tests/test_ops_device.py ----
+
+def test_norm_finalize_near_zero_variance(lib):
+    """InstanceNorm / GroupNorm(32) on channels whose variance (1e-8) is far below eps (1e-5) and below the fp32 noise of
+    their own second moment: the fp64 finalize must neither produce NaN nor amplify (normalization.py:90-95, unet.py:65-66)."""
+    rng = np.random.default_rng(11)
+    n, px, c = 2, 256, 64
+    x = (0.5 + 1e-4 * rng.standard_normal((n, c, px))).astype(np.float32)
+    x[:, 5] = 0.25                                         # an exactly constant channel
+    x[:, 6] = 0.0                                          # a dead channel
+    st, cb = _partials(x, 4)
+    gamma = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    for groups in (0, 32):
+        sc = np.zeros((n, cb * 16), np.float32); sh = np.zeros_like(sc)
+        lib.emu_norm(n, 1, P(st), 4, cb, None, 0, 0, c, groups, C.c_float(1.0 / px), C.c_float(1e-5), P(gamma), P(beta), None, None,
+                     P(sc), P(sh), None, None)
+        t = torch.from_numpy(x).double().reshape(n, c, 16, 16)
+        g64, b64 = torch.from_numpy(gamma).double(), torch.from_numpy(beta).double()
+        ref = (F.instance_norm(t, weight=g64, bias=b64, eps=1e-5) if groups == 0 else F.group_norm(t, 32, g64, b64, eps=1e-5)).reshape(n, c, px).numpy()
+        got = x.astype(np.float64) * sc[:, :c, None] + sh[:, :c, None]
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() < 2e-4, groups     # (x - mean) * rstd with x ~ 0.5: one fp32 ulp of x*scale is 3e-5 * rstd/300
+
+
+def test_attention_large_logits(lib):
+    """softmax over logits of +-1e3 (q, k of magnitude 30): max-subtraction keeps exp() in range (unet.py:192-202)."""
+    rng = np.random.default_rng(13)
+    n, Cc, heads, L = 1, 64, 2, 64
+    qkv = rng.standard_normal((n, 3 * Cc, L)).astype(np.float32)
+    qkv[:, :2 * Cc] *= 30.0
+    out = np.zeros((n, Cc, L), np.float32)
+    assert lib.emu_attention(n, Cc, heads, L, P(qkv), P(out)) == 0
+    t = torch.from_numpy(qkv).double()
+    q, kk, v = t.chunk(3, dim=1)
+    ch = Cc // heads
+    s = 1.0 / np.sqrt(np.sqrt(ch))
+    logits = torch.einsum("bct,bcs->bts", (q * s).reshape(n * heads, ch, L), (kk * s).reshape(n * heads, ch, L))
+    assert float(logits.abs().max()) > 500
+    ref = torch.einsum("bts,bcs->bct", torch.softmax(logits, -1), v.reshape(n * heads, ch, L)).reshape(n, Cc, L).numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() < 2e-3                  # near-one-hot rows: logit error 1e3 * 2^-23 * 32 terms -> weights move by ~1e-3
+
+
+def run_unet_tail(lib, S, head, src):
+    n = head.shape[0]
+    outs = [np.zeros((n, c, S, S), np.float32) for c in (4, 1, 4, 2, 4)]
+    assert lib.emu_unet_tail(S, n, P(head), P(src), *[P(o) for o in outs]) == 0
+    return outs
+
+
+def check_warp_blend_tail(lib, S):
+    """GridChangeApplier.apply + blend (image_processing_util.py:33-54, morpher_00.py:53-66) with offsets up to +-1.5
+    (three quarters of the image) so that every border clamps, against F.grid_sample in fp64."""
+    rng = np.random.default_rng(17)
+    n = 1
+    head = rng.standard_normal((n, 7, S, S)).astype(np.float32)
+    head[:, 4:6] = rng.uniform(-1.5, 1.5, (n, 2, S, S)).astype(np.float32)
+    head[:, 4, :, :4] = -1.5; head[:, 4, :, -4:] = 1.5; head[:, 5, :4] = -1.5; head[:, 5, -4:] = 1.5     # push all four rims outside
+    head[:, 4:6, S // 2, S // 2] = 0.0                                                               # and an exact identity tap
+    src = rng.standard_normal((n, 4, S, S)).astype(np.float32)
+    merged, alpha, warped, grid, direct = run_unet_tail(lib, S, head, src)
+    h64, s64 = torch.from_numpy(head).double(), torch.from_numpy(src).double()
+    ident = F.affine_grid(torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]], dtype=torch.float64), [n, 1, S, S], align_corners=False)
+    g = ident + h64[:, 4:6].permute(0, 2, 3, 1)
+    wref = F.grid_sample(s64, g, mode="bilinear", padding_mode="border", align_corners=False)
+    aref = torch.sigmoid(h64[:, 6:7])
+    assert np.abs(warped - wref.numpy()).max() < 3e-4     # tap weights from fp32 pixel coordinates (1 ulp of 512 = 6e-5) x gradient
+    assert np.abs(alpha - aref.numpy()).max() < 1e-6
+    assert np.array_equal(grid, head[:, 4:6]) and np.array_equal(direct, head[:, 0:4])
+    mref = h64[:, 0:4] * aref + wref * (1 - aref)
+    assert np.abs(merged - mref.numpy()).max() < 3e-4
+    assert np.abs(warped[0, :, S // 2, S // 2] - src[0, :, S // 2, S // 2]).max() < 1e-6      # identity tap reproduces the pixel
+    rim = np.abs(warped - wref.numpy())
+    assert max(rim[..., :4].max(), rim[..., -4:].max(), rim[..., :4, :].max(), rim[..., -4:, :].max()) < 3e-4
+
+
+def test_warp_blend_tail_borders(lib):
+    check_warp_blend_tail(lib, 256)
+
+
+def test_upscaler_input_bilinear_edges_and_warp(lib):
+    """F.interpolate(bilinear, align_corners=False) x2 on the first / last rows and columns (mode_07.py:108-115) and the
+    coarse warp of the upscaler input (upscaler_02.py:78-83)."""
+    rng = np.random.default_rng(19)
+    n = 1
+    rest = rng.standard_normal((n, 4, 512, 512)).astype(np.float32)
+    merged = rng.standard_normal((n, 4, 256, 256)).astype(np.float32)
+    grid = rng.uniform(-0.6, 0.6, (n, 2, 256, 256)).astype(np.float32)
+    out = np.zeros((n, 14, 512, 512), np.float32)
+    assert lib.emu_upscaler_input(n, P(rest), P(merged), P(grid), P(out)) == 0
+    r64 = torch.from_numpy(rest).double()
+    up_m = F.interpolate(torch.from_numpy(merged).double(), size=(512, 512), mode="bilinear", align_corners=False)
+    up_g = F.interpolate(torch.from_numpy(grid).double(), size=(512, 512), mode="bilinear", align_corners=False)
+    ident = F.affine_grid(torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]], dtype=torch.float64), [n, 1, 512, 512], align_corners=False)
+    w = F.grid_sample(r64, ident + up_g.permute(0, 2, 3, 1), mode="bilinear", padding_mode="border", align_corners=False)
+    assert np.array_equal(out[:, 0:4], rest)
+    e_m, e_g = np.abs(out[:, 4:8] - up_m.numpy()), np.abs(out[:, 12:14] - up_g.numpy())
+    assert e_m.max() < 2e-6 and e_g.max() < 1e-6
+    for band in (np.s_[..., 0:2, :], np.s_[..., 510:512, :], np.s_[..., :, 0:2], np.s_[..., :, 510:512]):      # edge-clamped taps
+        assert e_m[band].max() < 2e-6 and e_g[band].max() < 1e-6
+    assert np.abs(out[:, 8:12] - w.numpy()).max() < 5e-4

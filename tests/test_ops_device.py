@@ -1,0 +1,48 @@
+"""Per-op DEVICE tests: the drivers of tests/emu/emu_full.cpp compiled with hipcc -DOPS_DEVICE launch the
+real gfx950 kernels - convolutions of every kind / input mode / tiling (ragged 24x24 and 8x32 tiles, K split, pose-vector
+and concatenated sources), norm finalize (Instance / GroupNorm + FiLM, near-zero variance), gemv, attention (large
+logits), the warp + blend tail with offsets beyond every border and the bilinear x2 edges - against torch fp64.
+The test bodies are those of tests/test_emu_full.py (CPU emulator); only the library differs."""
+import ctypes as C
+import os
+
+import pytest
+
+import test_emu_full as T
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch  # noqa: F401  (its HIP runtime first, as for libtha4_hip.so)
+    path = os.path.join(HERE, "emu", "libtha4_ops_device.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+        g.build_ops_device()
+    return C.CDLL(path)
+
+
+@pytest.mark.parametrize("case", T.CASES)
+def test_conv_kernels_on_device(lib, case):
+    T.test_conv_kernel_matches_torch(lib, case)
+
+
+def test_norm_finalize_on_device(lib):
+    T.test_norm_finalize_instance_and_group(lib)
+    T.test_norm_finalize_near_zero_variance(lib)
+
+
+def test_gemv_and_attention_on_device(lib):
+    T.test_gemv_and_attention(lib)
+    T.test_attention_large_logits(lib)
+
+
+@pytest.mark.parametrize("size", [256, 512])
+def test_warp_blend_tail_borders_on_device(lib, size):
+    T.check_warp_blend_tail(lib, size)
+
+
+def test_upscaler_input_on_device(lib):
+    T.test_upscaler_input_bilinear_edges_and_warp(lib)

@@ -351,3 +351,31 @@ def test_student_stream_switch_is_ordered(poser, dev, golden_io):
             outs.append((1, poser.pose(image, poses[1])))
     torch.cuda.synchronize()
     assert all(torch.equal(o, base[i]) for i, o in outs)
+
+
+@pytest.mark.parametrize("gx,gy", [(1.5, 0.0), (-1.5, 0.0), (0.0, 1.5), (0.0, -1.5), (0.37, -0.61), (-1.1, 1.3)])
+def test_warp_border_clamp_per_op(dev, gx, gy, golden_io):
+    """The student's warp + blend stage in isolation (GridChangeApplier.apply, image_processing_util.py:33-54): weights whose
+    last_linear is zero except for its bias make grid_change a CONSTANT offset (gx, gy) - up to +-1.5, three quarters of
+    the image, so all four borders clamp - alpha = 0.25 and colour_change = c.  Every pixel of `warped` must equal
+    F.grid_sample(bilinear, border, align_corners=False) of the face-pasted image in fp64."""
+    import torch.nn.functional as F
+    w = so.random_student_weights(seed=21)
+    w["body.last_linear.weight"] = np.zeros_like(w["body.last_linear.weight"])
+    colour = np.array([0.3, -0.2, 0.1, 0.5], np.float32)
+    w["body.last_linear.bias"] = np.concatenate([[gx, gy, 0.25], colour]).astype(np.float32)
+    face, body = split_flat_weights(w)
+    p = mode_14.create_poser_from_state_dicts(dev, face, body)
+    image = golden_io["image_f32"]
+    pose = so.random_poses(1, seed=5)[0]
+    outs = [o[0].cpu().numpy() for o in p.get_posing_outputs(torch.from_numpy(image).to(dev), torch.from_numpy(pose).to(dev))]
+    assert np.abs(outs[4][0] - gx).max() < 1e-6 and np.abs(outs[4][1] - gy).max() < 1e-6 and np.abs(outs[1] - 0.25).max() < 1e-6
+    pasted = so.paste_face(image.astype(np.float64), outs[5].astype(np.float64))          # mode_14.py:72-78 with the device's face
+    ident = F.affine_grid(torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]], dtype=torch.float64), [1, 1, 512, 512], align_corners=False)
+    grid = ident + torch.tensor([gx, gy], dtype=torch.float64)
+    ref = F.grid_sample(torch.from_numpy(pasted)[None], grid, mode="bilinear", padding_mode="border", align_corners=False)[0].numpy()
+    err = np.abs(outs[3] - ref)
+    assert err.max() < 2e-4, err.max()                    # fp32 pixel coordinates: 1 ulp of 512 x image gradient
+    blended = 0.75 * ref + 0.25 * colour[:, None, None]
+    assert np.abs(outs[0] - blended).max() < 2e-4
+    p.free()
