@@ -1,0 +1,380 @@
+// Small-map convolution (16x16 .. 64x64 maps, 128-768 input channels): ONE launch per layer.
+//
+// These layers are ~40 % of a frame's launches and none of them has enough output tiles to fill 256 CUs; in round 1
+// they ran as  conv_tile_kernel phase 1 (K split over blockIdx.z, fp32 partials to a workspace)  ->  phase 2 (reduce +
+// epilogue)  ->  norm_finalize_kernel : three launches of 5-9 us each around ~0.5 us of matrix work.  Here
+//   * a workgroup owns 16*PG output positions x ONE output block (16 channels) and its 8 waves split K BETWEEN THEM:
+//     wave w takes the work units u = w, w+8, ... where a unit is a 32-channel K group (or, when there are fewer than
+//     8 K groups, a tap range of one).  Each wave stages the input window of its own K group into a wave-private LDS
+//     region - already normalised, activated, resampled, zero padded and split into fp16 hi + fp16 lo exactly like
+//     conv_tile_kernel does - and reads its weights straight from L2 into registers (fragment-linear pieces, one
+//     coalesced 16-byte load per lane and half), two 3-tap chunks in flight.  No workgroup barrier inside the K loop;
+//   * the eight partial accumulators are combined through LDS in wave order (fixed order: deterministic) and wave 0
+//     runs the usual epilogue (1/scale, bias, residual, activation, store, per-tile moments);
+//   * the normalisation that precedes the layer is folded in (fused_norm_table): every workgroup reduces the
+//     producer's per-tile moments itself - fp64, fixed order, Instance/GroupNorm(32) over a concatenation with both
+//     FiLM stages, the same arithmetic as norm_finalize_kernel - into an LDS table of per-channel scale/shift while
+//     its first loads are in flight.  The standalone finalize launch disappears for every tensor with few tiles.
+// Weights use the image of conv_tile_kernel<1,...> (full_layout.h pack_conv_weight16 with TMB = 1); numerics are
+// the same fp16 hi/lo split (three v_mfma_f32_16x16x32_f16 per 32-deep k step, fp32 accumulate).
+#pragma once
+#include "full_conv16_kernels.h"
+
+namespace tha4 {
+
+constexpr int kSmallWaves = 8;
+constexpr int kSmallThreads = kSmallWaves * 64;
+constexpr int kSmallMaxItems = 7;     // staging items (pixel, lane group) per lane and K group: window <= 112 pixels
+constexpr int kSmallTapChunk = 3;     // taps per register-resident weight chunk (two chunks in flight)
+
+// Per-channel scale/shift of the normalisation that precedes a convolution, computed by the consumer itself from the
+// producer's per-tile moments.  Mirrors norm_finalize_kernel (same fp64 arithmetic); all `nthreads` threads of the
+// workgroup must call it; `scratch` holds 2*ctot doubles and may alias memory that is not in use yet.  The caller
+// synchronises the workgroup afterwards before reading the table.
+THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, float* tab_sc, float* tab_sh, double* scratch) {
+  const FusedNorm& f = a.fnorm;
+  const int c0 = a.src[0].cb * 16;
+  const int ctot = c0 + (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR ? a.src[1].cb * 16 : 0);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  for (int c = tid; c < ctot; c += nthreads) {
+    const int s = c < c0 ? 0 : 1;
+    const int cl = c - (s ? c0 : 0);
+    const int cw = a.src[s].cb * 16;
+    const float* ps = f.stats[s] + ((size_t)n * f.tiles[s] * cw + cl) * 2;
+    double su = 0.0, sq = 0.0;
+    for (int t = 0; t < f.tiles[s]; ++t) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
+      su += (double)v[0];
+      sq += (double)v[1];
+    }
+    scratch[c] = su;
+    scratch[ctot + c] = sq;
+  }
+  __syncthreads();
+  for (int c = tid; c < ctot; c += nthreads) {
+    float sc = 0.f, sh = 0.f;
+    if (c < f.channels) {
+      double mean, var;
+      if (f.groups == 0) {
+        mean = scratch[c] * f.inv_count;
+        var = scratch[ctot + c] * f.inv_count - mean * mean;
+      } else {
+        const int gs = f.channels / f.groups;
+        const int gi = c / gs;
+        double su = 0.0, sq = 0.0;
+        for (int k = gi * gs; k < (gi + 1) * gs; ++k) { su += scratch[k]; sq += scratch[ctot + k]; }
+        mean = su * f.inv_count / gs;
+        var = sq * f.inv_count / gs - mean * mean;
+      }
+      const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)f.eps);
+      double k = (double)f.gamma[c] * rstd;
+      double b = (double)f.beta[c] - mean * k;
+      if (f.film0) {
+        const double s0 = f.film0[c], b0 = f.film0[f.channels + c];
+        k *= (1.0 + s0); b = b * (1.0 + s0) + b0;
+      }
+      if (f.film1) {
+        const double s1 = f.film1[(size_t)n * f.film1_stride + c], b1 = f.film1[(size_t)n * f.film1_stride + f.channels + c];
+        k *= (1.0 + s1); b = b * (1.0 + s1) + b1;
+      }
+      sc = (float)k;
+      sh = (float)b;
+    }
+    tab_sc[c] = sc;
+    tab_sh[c] = sh;
+  }
+}
+
+THA4_DEV int small_table_floats(const ConvArgs& a) {      // 2 x padded concatenated channels, 0 when nothing is fused
+  if (!a.fnorm.enabled) return 0;
+  int c = a.src[0].cb * 16;
+  if (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR) c += a.src[1].cb * 16;
+  return 2 * c;
+}
+
+template <int PG, int INMODE>
+__global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
+  constexpr bool kPool = INMODE == IN_POOL2;
+  constexpr int KI = kSmallMaxItems, TC = kSmallTapChunk;
+  THA4_DYN_LDS(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform_i32(tid >> 6);
+  const int p = lane & 15, g = lane >> 4, g4 = g * 4;
+
+  // ---- tile decomposition (16*PG output positions, TH x 2^twl) ------------------------------------
+  const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (PG * 16) >> twl;
+  const int tiles_x = (a.tile_w + TWW - 1) >> twl;
+  const int tiles_per_frame = tiles_x * ((a.tile_h + TWH - 1) / TWH);
+  const int n = blockIdx.x / tiles_per_frame;
+  const int tile = blockIdx.x % tiles_per_frame;
+  const int tile_y0 = (tile / tiles_x) * TWH, tile_x0 = (tile % tiles_x) << twl;
+  const int bo = blockIdx.y;                               // output block (16 channels)
+  const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (kPool ? a.in_h / 2 : a.in_h);
+  const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (kPool ? a.in_w / 2 : a.in_w);
+  const int in_px = a.in_h * a.in_w;
+  const int WW = a.win_w, NPX = a.win_h * a.win_w;
+  const int PLANE = tile_plane_bytes(NPX);
+  const int vy0 = tile_y0 * a.in_stride + a.win_dy0, vx0 = tile_x0 * a.in_stride + a.win_dx0;
+
+  int cbtot = 0;
+  for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
+  const int NQ = (cbtot + 1) >> 1;                         // 32-channel K groups
+  const int upq = a.units_per_q;                           // tap ranges per K group (1 unless NQ < 8)
+  const int tpu = (a.ntaps + upq - 1) / upq;               // taps per unit
+  const int nunits = NQ * upq;
+
+  // ---- LDS: [scale | shift table] [8 waves x (4 hi + 4 lo planes)]; the reduction buffer aliases the windows -----
+  const int tabf = small_table_floats(a);
+  float* tab_sc = reinterpret_cast<float*>(smem);
+  float* tab_sh = tab_sc + (tabf >> 1);
+  char* wins = smem + ((tabf * 4 + 127) & ~127);
+  char* win_hi = wins + wave * 8 * PLANE;
+  char* win_lo = win_hi + 4 * PLANE;
+  const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)bo * NQ * a.ntaps * 2048 + lane * 16;
+
+  // ---- per-lane output pixels ------------------------------------------------------------------
+  int ly[PG], lx[PG], boff[PG];
+  bool inside[PG];
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    const int i = pg * 16 + p;
+    ly[pg] = i >> twl;
+    lx[pg] = i & (TWW - 1);
+    boff[pg] = ((ly[pg] * a.in_stride) * WW + lx[pg] * a.in_stride) * 16 + g * PLANE;
+    inside[pg] = tile_y0 + ly[pg] < a.tile_h && tile_x0 + lx[pg] < a.tile_w;
+  }
+
+  // ---- staging items of this lane (geometry is the same for every K group) ----------------------
+  const int sg = lane & 3;
+  const int nitems = NPX * 4;
+  struct Offsets { int v[KI]; } go;
+#pragma unroll
+  for (int k = 0; k < KI; ++k) {
+    const int item = lane + k * 64;
+    const int px = item >> 2;
+    const int wy = px / WW, wx = px - wy * WW;
+    const int vy = vy0 + wy, vx = vx0 + wx;
+    const bool ok = item < nitems && (unsigned)vy < (unsigned)vh && (unsigned)vx < (unsigned)vw;
+    int o;
+    if (INMODE == IN_DIRECT) o = vy * a.in_w + vx;
+    else if (INMODE == IN_UP2) o = (vy >> 1) * a.in_w + (vx >> 1);
+    else o = (2 * vy) * a.in_w + 2 * vx;
+    go.v[k] = ok ? o * 64 + sg * 16 : -1;
+  }
+
+  struct QuadCtx { const char* base; f32x4 sc, sh; int act; int kind; bool fused; int tab; };
+  auto quad_ctx = [&](int q) -> QuadCtx {
+    QuadCtx c;
+    c.base = nullptr; c.act = ACT_NONE; c.kind = SRC_TENSOR; c.fused = false; c.tab = 0;
+    c.sc = f32x4{1.f, 1.f, 1.f, 1.f};
+    c.sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q >= cbtot) return c;                              // phantom quad of an odd channel-block count
+    int s = 0, ql = q;
+    if (a.nsrc > 1 && q >= a.src[0].cb) { s = 1; ql = q - a.src[0].cb; }
+    const ConvSrc& S = a.src[s];
+    c.act = S.act; c.kind = S.kind;
+    if (a.fnorm.enabled && S.kind == SRC_TENSOR) {
+      c.fused = true;
+      c.tab = q * 16 + sg * 4;                             // table index = padded channel of the concatenation
+    } else if (S.scale) {
+      c.sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + sg * 4);
+      c.sh = *reinterpret_cast<const f32x4*>(S.shift + ((size_t)n * S.cb + ql) * 16 + sg * 4);
+    }
+    c.base = reinterpret_cast<const char*>(S.kind == SRC_VECTOR ? S.data + ((size_t)n * S.cb + ql) * 16
+                                                                : S.data + ((size_t)n * S.cb + ql) * (size_t)in_px * 16);
+    return c;
+  };
+  auto bind_table = [&](QuadCtx& c) {                      // after the table barrier
+    if (!c.fused) return;
+    c.sc = *reinterpret_cast<const f32x4*>(tab_sc + c.tab);
+    c.sh = *reinterpret_cast<const f32x4*>(tab_sh + c.tab);
+  };
+  auto activate = [&](const f32x4& r, const QuadCtx& c) -> f32x4 { return apply_act4(r, c.sc, c.sh, c.act); };
+
+  f32x4 rawA[KI], rawB[KI];
+  QuadCtx cA, cB;
+  // raw loads of one K group's window (activation is applied when the window is written: the table may not exist yet)
+  auto load_window = [&](int Q) {
+    cA = quad_ctx(2 * Q);
+    cB = quad_ctx(2 * Q + 1);
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int o = go.v[k];
+      rawA[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      rawB[k] = rawA[k];
+      if (o < 0) continue;
+      if (cA.base) rawA[k] = cA.kind == SRC_VECTOR ? *reinterpret_cast<const f32x4*>(cA.base + sg * 16) : *reinterpret_cast<const f32x4*>(cA.base + (unsigned)o);
+      if (cB.base) rawB[k] = cB.kind == SRC_VECTOR ? *reinterpret_cast<const f32x4*>(cB.base + sg * 16) : *reinterpret_cast<const f32x4*>(cB.base + (unsigned)o);
+    }
+  };
+  // IN_POOL2: the three other samples of the 2x2 window are fetched and activated here (AvgPool2d of the ACTIVATED tensor, unet.py:58)
+  auto pooled = [&](const QuadCtx& c, int o, const f32x4& v00) -> f32x4 {
+    const float* ptr = reinterpret_cast<const float*>(c.base + (unsigned)o);
+    const f32x4 a00 = activate(v00, c);
+    const f32x4 a01 = activate(*reinterpret_cast<const f32x4*>(ptr + 16), c);
+    const f32x4 a10 = activate(*reinterpret_cast<const f32x4*>(ptr + (size_t)a.in_w * 16), c);
+    const f32x4 a11 = activate(*reinterpret_cast<const f32x4*>(ptr + (size_t)a.in_w * 16 + 16), c);
+    return ((a00 + a01) + (a10 + a11)) * 0.25f;
+  };
+  auto write_window = [&]() {
+    bind_table(cA);
+    bind_table(cB);
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int item = lane + k * 64;
+      if (item >= nitems) continue;
+      f32x4 va = rawA[k], vb = rawB[k];
+      const int o = go.v[k];
+      if (o < 0) {                                         // zero padding is applied AFTER normalisation + activation
+        va = f32x4{0.f, 0.f, 0.f, 0.f};
+        vb = va;
+      } else {
+        if (cA.base) va = (kPool && cA.kind == SRC_TENSOR) ? pooled(cA, o, va) : activate(va, cA);
+        if (cB.base) vb = (kPool && cB.kind == SRC_TENSOR) ? pooled(cB, o, vb) : activate(vb, cB);
+      }
+      f16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = (_Float16)va[j];
+        lo[j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[j], va[j]);
+        hi[4 + j] = (_Float16)vb[j];
+        lo[4 + j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[4 + j], vb[j]);
+      }
+      const int off = sg * PLANE + (item >> 2) * 16;
+      *reinterpret_cast<f16x8*>(win_hi + off) = hi;
+      *reinterpret_cast<f16x8*>(win_lo + off) = lo;
+    }
+  };
+
+  // weights of one chunk of <= TC taps of K group Q, straight from L2: fragment-linear pieces [Q][tap][hi 1 KiB | lo 1 KiB]
+  struct WChunk { f16x8 h[TC], l[TC]; };
+  auto load_weights = [&](int Q, int t0, int t1, WChunk& w) {
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+      const int t = min(t0 + i, t1 - 1);                    // past the range: re-read the last tap (never multiplied)
+      const char* pc = gw + ((size_t)Q * a.ntaps + t) * 2048;
+      w.h[i] = *reinterpret_cast<const f16x8*>(pc);
+      w.l[i] = *reinterpret_cast<const f16x8*>(pc + 1024);
+    }
+  };
+
+  f32x4 acc[PG];
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) acc[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mac_chunk = [&](int t0, int t1, const WChunk& w) {
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+      const int t = t0 + i;
+      if (t >= t1) break;
+      const int toff = ((a.tap_dy[t] - a.win_dy0) * WW + (a.tap_dx[t] - a.win_dx0)) * 16;
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(win_hi + boff[pg] + toff);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(win_lo + boff[pg] + toff);
+        acc[pg] = mfma16h(w.h[i], bh, acc[pg]);
+        acc[pg] = mfma16h(w.h[i], bl, acc[pg]);
+        acc[pg] = mfma16h(w.l[i], bh, acc[pg]);
+      }
+    }
+  };
+
+  // ---- first unit's loads go out before the normalisation table is built -------------------------
+  int u = wave;
+  int curQ = -1;
+  WChunk w0, w1;
+  if (u < nunits) {
+    curQ = u / upq;
+    load_window(curQ);
+    const int t0 = (u % upq) * tpu;
+    load_weights(curQ, t0, min(a.ntaps, t0 + tpu), w0);
+  }
+  if (a.fnorm.enabled) {
+    fused_norm_table(a, n, tid, kSmallThreads, tab_sc, tab_sh, reinterpret_cast<double*>(wins));
+    __syncthreads();                                       // table complete; scratch (aliasing the windows) no longer read
+  }
+  bool staged = false;
+  for (; u < nunits; u += kSmallWaves) {
+    const int Q = u / upq;
+    const int t0 = (u % upq) * tpu, t1 = min(a.ntaps, t0 + tpu);
+    if (Q != curQ) { load_window(Q); curQ = Q; staged = false; }
+    if (!staged) { write_window(); staged = true; }        // wave-private LDS: program order + waitcnt, no barrier
+    // two register-resident weight chunks in flight: w0 arrives (prologue / previous unit / previous pair) while w1 is
+    // requested, and the next pair's w0 is requested as soon as this pair's w0 has been consumed
+    for (int t = t0; t < t1; t += 2 * TC) {
+      if (t + TC < t1) load_weights(Q, t + TC, t1, w1);
+      mac_chunk(t, t1, w0);
+      if (t + 2 * TC < t1) load_weights(Q, t + 2 * TC, t1, w0);
+      if (t + TC < t1) mac_chunk(t + TC, t1, w1);
+    }
+    // prefetch the next unit's window + first chunk under nothing (MFMAs above are already issued): keeps one round trip per unit
+    const int un = u + kSmallWaves;
+    if (un < nunits) {
+      const int Qn = un / upq;
+      if (Qn != curQ) { load_window(Qn); curQ = Qn; staged = false; }
+      const int tn = (un % upq) * tpu;
+      load_weights(Qn, tn, min(a.ntaps, tn + tpu), w0);
+    }
+  }
+
+  // ---- combine the eight K slices in wave order, epilogue on wave 0 -----------------------------------
+  __syncthreads();                                         // every wave is done with its window: the region is reused
+  f32x4* red = reinterpret_cast<f32x4*>(wins);             // [wave][pg][64]
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) red[(wave * PG + pg) * 64 + lane] = acc[pg];
+  __syncthreads();
+  if (wave != 0) return;
+  const int out_px = a.out_h * a.out_w;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    f32x4 s = red[(0 * PG + pg) * 64 + lane];
+#pragma unroll
+    for (int w2 = 1; w2 < kSmallWaves; ++w2) s = s + red[(w2 * PG + pg) * 64 + lane];
+    if (!inside[pg]) continue;                             // ragged tile: position outside the map
+    const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
+    const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
+    f32x4 v = s * a.w16_inv_scale + bias;
+    if (a.residual) {
+      if (a.res_mode == IN_DIRECT) {
+        v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
+      } else if (a.res_mode == IN_UP2) {
+        const int rw = a.out_w >> 1, rpx = out_px >> 2;
+        v = v + *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
+      } else {
+        const int rw = a.out_w * 2;
+        const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
+        const f32x4 r = ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
+                         (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
+        v = v + r;
+      }
+    }
+    if (a.act_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
+    }
+    *reinterpret_cast<f32x4*>(a.out + off) = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]); }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = ssum[j], q = ssq[j];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        s += lane_read(s, lane ^ m);
+        q += lane_read(q, lane ^ m);
+      }
+      if (p == 0) {
+        float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
+        dst[0] = s;
+        dst[1] = q;
+      }
+    }
+  }
+}
+
+}  // namespace tha4

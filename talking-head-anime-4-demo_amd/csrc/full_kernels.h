@@ -33,6 +33,23 @@ struct ConvSrc {
   int act;              // activation applied after scale/shift (before zero padding / pooling)
 };
 
+// Normalisation folded into the consumer (full_conv_small_kernels.h fused_norm_table): instead of reading per-(n, c)
+// scale/shift vectors produced by norm_finalize_kernel, the convolution reduces the producer's per-tile moments itself.
+struct FusedNorm {
+  const float* stats[2];   // per source: partial sums [n][tiles][cb*16][2] written by the producer's epilogue
+  int tiles[2];
+  int channels;            // real channels of the (concatenated) normalised tensor
+  int groups;              // 0: InstanceNorm2d, > 0: GroupNorm(groups)
+  float inv_count;         // 1 / pixels per channel
+  float eps;
+  const float* gamma;      // [channels]
+  const float* beta;
+  const float* film0;      // [2*channels] constant (scale | shift) or null
+  const float* film1;      // [n][film1_stride] per-frame (scale | shift) or null
+  long long film1_stride;
+  int enabled;
+};
+
 struct ConvArgs {
   ConvSrc src[2];
   int nsrc;
@@ -67,6 +84,8 @@ struct ConvArgs {
   float* partial;        // split-K workspace [ksplit][batch][mtile][tile][TMB][8*PG][64] f32x4, or null
   int ksplit;            // K splits (phase 1 grid z)
   int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue
+  FusedNorm fnorm;       // conv_tile_kernel / conv_small_kernel: normalisation of the tensor sources computed in the prologue
+  int units_per_q;       // conv_small_kernel: tap ranges per K group (1, 2, 4 or 8: spreads few K groups over the 8 waves)
 #ifdef THA4_PHASE_TIMING
   long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
 #endif
