@@ -40,6 +40,71 @@ constexpr int kTileMaxItems = 5;     // staging items (pixel, g) per thread and 
 // (4 consecutive lanes = 4 planes of one pixel) hit distinct banks
 constexpr int tile_plane_bytes(int win_px) { return (win_px * 16 + 127) / 128 * 128 + 32; }
 
+// Per-channel scale/shift of the normalisation that precedes a convolution, computed by the consumer itself from the
+// producer's per-tile moments.  Mirrors norm_finalize_kernel (same fp64 arithmetic); all `nthreads` threads of the
+// workgroup must call it; `scratch` holds 2*ctot doubles and may alias memory that is not in use yet.  The caller
+// synchronises the workgroup afterwards before reading the table.
+THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, float* tab_sc, float* tab_sh, double* scratch) {
+  const FusedNorm& f = a.fnorm;
+  const int c0 = a.src[0].cb * 16;
+  const int ctot = c0 + (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR ? a.src[1].cb * 16 : 0);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  for (int c = tid; c < ctot; c += nthreads) {
+    const int s = c < c0 ? 0 : 1;
+    const int cl = c - (s ? c0 : 0);
+    const int cw = a.src[s].cb * 16;
+    const float* ps = f.stats[s] + ((size_t)n * f.tiles[s] * cw + cl) * 2;
+    double su = 0.0, sq = 0.0;
+    for (int t = 0; t < f.tiles[s]; ++t) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
+      su += (double)v[0];
+      sq += (double)v[1];
+    }
+    scratch[c] = su;
+    scratch[ctot + c] = sq;
+  }
+  __syncthreads();
+  for (int c = tid; c < ctot; c += nthreads) {
+    float sc = 0.f, sh = 0.f;
+    if (c < f.channels) {
+      double mean, var;
+      if (f.groups == 0) {
+        mean = scratch[c] * f.inv_count;
+        var = scratch[ctot + c] * f.inv_count - mean * mean;
+      } else {
+        const int gs = f.channels / f.groups;
+        const int gi = c / gs;
+        double su = 0.0, sq = 0.0;
+        for (int k = gi * gs; k < (gi + 1) * gs; ++k) { su += scratch[k]; sq += scratch[ctot + k]; }
+        mean = su * f.inv_count / gs;
+        var = sq * f.inv_count / gs - mean * mean;
+      }
+      const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)f.eps);
+      double k = (double)f.gamma[c] * rstd;
+      double b = (double)f.beta[c] - mean * k;
+      if (f.film0) {
+        const double s0 = f.film0[c], b0 = f.film0[f.channels + c];
+        k *= (1.0 + s0); b = b * (1.0 + s0) + b0;
+      }
+      if (f.film1) {
+        const double s1 = f.film1[(size_t)n * f.film1_stride + c], b1 = f.film1[(size_t)n * f.film1_stride + f.channels + c];
+        k *= (1.0 + s1); b = b * (1.0 + s1) + b1;
+      }
+      sc = (float)k;
+      sh = (float)b;
+    }
+    tab_sc[c] = sc;
+    tab_sh[c] = sh;
+  }
+}
+
+THA4_DEV int fused_table_floats(const ConvArgs& a) {      // 2 x padded concatenated channels, 0 when nothing is fused
+  if (!a.fnorm.enabled) return 0;
+  int c = a.src[0].cb * 16;
+  if (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR) c += a.src[1].cb * 16;
+  return 2 * c;
+}
+
 template <int TMB, int PG, int INMODE>
 __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   constexpr bool kPool = INMODE == IN_POOL2;
@@ -78,6 +143,9 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   char* ring = smem + 8 * PLANE;
   const int D = a.ring_slots;                                            // ring depth (2..4)
   float* red = reinterpret_cast<float*>(ring + D * slot_bytes);          // [8 waves][TMB*16][2]
+  // normalisation folded into this kernel (FusedNorm): per-channel scale | shift table behind `red`
+  float* tab_sc = red + kTileWaves * TMB * 16 * 2;
+  float* tab_sh = tab_sc + (fused_table_floats(a) >> 1);
   const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
 
   // ---- per-lane output pixels ------------------------------------------------------------------
@@ -129,7 +197,10 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     if (a.nsrc > 1 && q >= a.src[0].cb) { s = 1; ql = q - a.src[0].cb; }
     const ConvSrc& S = a.src[s];
     c.act = S.act; c.kind = S.kind;
-    if (S.scale) {
+    if (a.fnorm.enabled && S.kind == SRC_TENSOR) {          // table index = padded channel of the concatenation
+      c.sc = *reinterpret_cast<const f32x4*>(tab_sc + q * 16 + sg * 4);
+      c.sh = *reinterpret_cast<const f32x4*>(tab_sh + q * 16 + sg * 4);
+    } else if (S.scale) {
       c.sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + sg * 4);
       c.sh = *reinterpret_cast<const f32x4*>(S.shift + ((size_t)n * S.cb + ql) * 16 + sg * 4);
     }
@@ -212,6 +283,10 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     for (int i = 0; i < D - 1 && issued < nchunks; ++i) {  // D-1 chunks ahead; the D-th slot is the one being read
       fetch(issued++, islot);
       islot = islot + 1 == D ? 0 : islot + 1;
+    }
+    if (a.fnorm.enabled) {                                 // scale/shift table from the producer's moments (scratch: the window region)
+      fused_norm_table(a, n, tid, kTileThreads, tab_sc, tab_sh, reinterpret_cast<double*>(smem));
+      __syncthreads();
     }
     load_window(q_begin, go);
     THA4_CSTAMP();                                         // 1: first window loads issued

@@ -27,71 +27,6 @@ constexpr int kSmallThreads = kSmallWaves * 64;
 constexpr int kSmallMaxItems = 7;     // staging items (pixel, lane group) per lane and K group: window <= 112 pixels
 constexpr int kSmallTapChunk = 3;     // taps per register-resident weight chunk (two chunks in flight)
 
-// Per-channel scale/shift of the normalisation that precedes a convolution, computed by the consumer itself from the
-// producer's per-tile moments.  Mirrors norm_finalize_kernel (same fp64 arithmetic); all `nthreads` threads of the
-// workgroup must call it; `scratch` holds 2*ctot doubles and may alias memory that is not in use yet.  The caller
-// synchronises the workgroup afterwards before reading the table.
-THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, float* tab_sc, float* tab_sh, double* scratch) {
-  const FusedNorm& f = a.fnorm;
-  const int c0 = a.src[0].cb * 16;
-  const int ctot = c0 + (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR ? a.src[1].cb * 16 : 0);
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  for (int c = tid; c < ctot; c += nthreads) {
-    const int s = c < c0 ? 0 : 1;
-    const int cl = c - (s ? c0 : 0);
-    const int cw = a.src[s].cb * 16;
-    const float* ps = f.stats[s] + ((size_t)n * f.tiles[s] * cw + cl) * 2;
-    double su = 0.0, sq = 0.0;
-    for (int t = 0; t < f.tiles[s]; ++t) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
-      su += (double)v[0];
-      sq += (double)v[1];
-    }
-    scratch[c] = su;
-    scratch[ctot + c] = sq;
-  }
-  __syncthreads();
-  for (int c = tid; c < ctot; c += nthreads) {
-    float sc = 0.f, sh = 0.f;
-    if (c < f.channels) {
-      double mean, var;
-      if (f.groups == 0) {
-        mean = scratch[c] * f.inv_count;
-        var = scratch[ctot + c] * f.inv_count - mean * mean;
-      } else {
-        const int gs = f.channels / f.groups;
-        const int gi = c / gs;
-        double su = 0.0, sq = 0.0;
-        for (int k = gi * gs; k < (gi + 1) * gs; ++k) { su += scratch[k]; sq += scratch[ctot + k]; }
-        mean = su * f.inv_count / gs;
-        var = sq * f.inv_count / gs - mean * mean;
-      }
-      const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)f.eps);
-      double k = (double)f.gamma[c] * rstd;
-      double b = (double)f.beta[c] - mean * k;
-      if (f.film0) {
-        const double s0 = f.film0[c], b0 = f.film0[f.channels + c];
-        k *= (1.0 + s0); b = b * (1.0 + s0) + b0;
-      }
-      if (f.film1) {
-        const double s1 = f.film1[(size_t)n * f.film1_stride + c], b1 = f.film1[(size_t)n * f.film1_stride + f.channels + c];
-        k *= (1.0 + s1); b = b * (1.0 + s1) + b1;
-      }
-      sc = (float)k;
-      sh = (float)b;
-    }
-    tab_sc[c] = sc;
-    tab_sh[c] = sh;
-  }
-}
-
-THA4_DEV int small_table_floats(const ConvArgs& a) {      // 2 x padded concatenated channels, 0 when nothing is fused
-  if (!a.fnorm.enabled) return 0;
-  int c = a.src[0].cb * 16;
-  if (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR) c += a.src[1].cb * 16;
-  return 2 * c;
-}
-
 template <int PG, int INMODE>
 __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   constexpr bool kPool = INMODE == IN_POOL2;
@@ -125,7 +60,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   const int nunits = NQ * upq;
 
   // ---- LDS: [scale | shift table] [8 waves x (4 hi + 4 lo planes)]; the reduction buffer aliases the windows -----
-  const int tabf = small_table_floats(a);
+  const int tabf = fused_table_floats(a);
   float* tab_sc = reinterpret_cast<float*>(smem);
   float* tab_sh = tab_sc + (tabf >> 1);
   char* wins = smem + ((tabf * 4 + 127) & ~127);
@@ -298,7 +233,11 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     const int Q = u / upq;
     const int t0 = (u % upq) * tpu, t1 = min(a.ntaps, t0 + tpu);
     if (Q != curQ) { load_window(Q); curQ = Q; staged = false; }
-    if (!staged) { write_window(); staged = true; }        // wave-private LDS: program order + waitcnt, no barrier
+    if (!staged) {                                         // wave-private LDS: program order, no workgroup barrier
+      write_window();
+      staged = true;
+      THA4_WAVE_SYNC();
+    }
     // two register-resident weight chunks in flight: w0 arrives (prologue / previous unit / previous pair) while w1 is
     // requested, and the next pair's w0 is requested as soon as this pair's w0 has been consumed
     for (int t = t0; t < t1; t += 2 * TC) {

@@ -521,23 +521,69 @@ __global__ void __launch_bounds__(256) conv_splitk_kernel(ConvArgs a) {
 // ResnetBlock output (resnet_block.py:63-67): out = actA(A*sa+ha) + (B*sb+hb) on C16 tensors of equal
 // shape; scale/shift are per (n, channel) vectors or null (identity).  One thread per 16-byte quad.
 // ---------------------------------------------------------------------------------------------
+struct FusedInstanceNorm {   // InstanceNorm2d(affine) scale/shift computed by the consumer from the producer's per-tile moments
+  const float* stats;        // [n][tiles][cb*16][2] or null (not fused)
+  int tiles;
+  float inv_count, eps;
+  const float* gamma;
+  const float* beta;
+};
+
 struct AffineAddArgs {
   const float* a; const float* sa; const float* ha; int act_a;
   const float* b; const float* sb; const float* hb;
   float* out;
   int cb, px;
+  FusedInstanceNorm fa, fb;  // when .stats is set it replaces sa/ha (sb/hb)
 };
 
+// scale/shift of channel c of frame n from per-tile moments (same fp64 arithmetic as norm_finalize_kernel, groups == 0)
+THA4_DEV void instance_norm_from_moments(const FusedInstanceNorm& f, int n, int cw, int c, float& sc, float& sh) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float* ps = f.stats + ((size_t)n * f.tiles * cw + c) * 2;
+  double su = 0.0, sq = 0.0;
+  for (int t = 0; t < f.tiles; ++t) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
+    su += (double)v[0];
+    sq += (double)v[1];
+  }
+  const double mean = su * f.inv_count;
+  const double var = sq * f.inv_count - mean * mean;
+  const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)f.eps);
+  const double kk = (double)f.gamma[c] * rstd;
+  sc = (float)kk;
+  sh = (float)((double)f.beta[c] - mean * kk);
+}
+
 __global__ void __launch_bounds__(256) affine_add_kernel(AffineAddArgs k) {
+  THA4_DYN_LDS(smem);                                      // 256 B: fused path: scale_a | shift_a | scale_b | shift_b of this workgroup's channel block
+  float (*tab)[16] = reinterpret_cast<float (*)[16]>(smem);
   const size_t quads = (size_t)k.cb * k.px * 4;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
+  const bool fused = k.fa.stats || k.fb.stats;             // the host guarantees px*4 % 256 == 0: one channel block per workgroup
+  if (fused) {
+    const int blk = (int)(((size_t)blockIdx.x * 256) / ((size_t)k.px * 4));
+    const int t = threadIdx.x;
+    if (t < 32) {
+      const int c = blk * 16 + (t & 15);
+      float sc = 1.f, sh = 0.f;
+      const FusedInstanceNorm& f = t < 16 ? k.fa : k.fb;
+      if (f.stats) instance_norm_from_moments(f, n, k.cb * 16, c, sc, sh);
+      tab[t < 16 ? 0 : 2][t & 15] = sc;
+      tab[t < 16 ? 1 : 3][t & 15] = sh;
+    }
+    __syncthreads();
+  }
   if (i >= quads) return;
   const int c4 = (int)(i / ((size_t)k.px * 4)) * 16 + (int)(i & 3) * 4;     // first channel of this quad
   const size_t off = ((size_t)n * quads + i) * 4;
   f32x4 va = *reinterpret_cast<const f32x4*>(k.a + off);
   f32x4 vb = *reinterpret_cast<const f32x4*>(k.b + off);
-  if (k.sa) {
+  if (k.fa.stats) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) va[j] = fmaf(va[j], tab[0][(c4 & 15) + j], tab[1][(c4 & 15) + j]);
+  } else if (k.sa) {
     const f32x4 s = *reinterpret_cast<const f32x4*>(k.sa + (size_t)n * k.cb * 16 + c4);
     const f32x4 h = *reinterpret_cast<const f32x4*>(k.ha + (size_t)n * k.cb * 16 + c4);
 #pragma unroll
@@ -545,7 +591,10 @@ __global__ void __launch_bounds__(256) affine_add_kernel(AffineAddArgs k) {
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) va[j] = apply_act(va[j], k.act_a);
-  if (k.sb) {
+  if (k.fb.stats) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = fmaf(vb[j], tab[2][(c4 & 15) + j], tab[3][(c4 & 15) + j]);
+  } else if (k.sb) {
     const f32x4 s = *reinterpret_cast<const f32x4*>(k.sb + (size_t)n * k.cb * 16 + c4);
     const f32x4 h = *reinterpret_cast<const f32x4*>(k.hb + (size_t)n * k.cb * 16 + c4);
 #pragma unroll

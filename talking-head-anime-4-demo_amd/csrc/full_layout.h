@@ -161,7 +161,7 @@ struct TileGeom {
   int ring_slots = 2;            // LDS weight ring depth: as deep (<= 4) as the LDS left by the window allows
   size_t lds = 0;
 };
-inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB, int tw_log2) {
+inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB, int tw_log2, size_t extra_lds = 0) {
   TileGeom t;
   const int px = 8 * PG * 16;
   t.tw_log2 = tw_log2;
@@ -187,10 +187,10 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   const size_t slot = (size_t)t.taps_per_chunk * TMB * 2048, red = 8 * (size_t)TMB * 16 * 2 * sizeof(float);
   // deeper while it costs no occupancy: never push a workgroup that fits twice on a CU (<= 80 KiB) over that line
   t.ring_slots = 2;
-  const size_t base = 8 * plane + 2 * slot + red;
+  const size_t base = 8 * plane + 2 * slot + red + extra_lds;     // extra_lds: scale/shift table of a fused normalisation
   const size_t cap = base <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
-  while (t.ring_slots < 4 && 8 * plane + (t.ring_slots + 1) * slot + red <= cap) ++t.ring_slots;
-  t.lds = 8 * plane + t.ring_slots * slot + red;
+  while (t.ring_slots < 4 && 8 * plane + (t.ring_slots + 1) * slot + red + extra_lds <= cap) ++t.ring_slots;
+  t.lds = 8 * plane + t.ring_slots * slot + red + extra_lds;
   t.ok = t.lds <= 160 * 1024;
   return t;
 }
@@ -240,6 +240,72 @@ inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TM
     ksplit = (nq + per - 1) / per;                     // every split gets at least one K group
   }
   best.ksplit = ksplit;
+  return best;
+}
+
+// Launch plan of conv_small_kernel<PG> (full_conv_small_kernels.h): a workgroup = 16*PG output positions (TH x 2^twl) x one
+// output block, its 8 waves split the K groups (x tap ranges when there are fewer than 8 groups).
+struct SmallPlan {
+  bool ok = false;
+  int pg = 1, tw_log2 = 4, th = 0;
+  int tiles = 0;                 // pixel tiles per frame (and per parity class)
+  float efficiency = 0.f;
+  int win_h = 0, win_w = 0, dy0 = 0, dx0 = 0;
+  int units_per_q = 1;
+  size_t lds = 0;                // without the fused-norm table
+};
+inline SmallPlan small_geom(const ConvGeom& g, int tile_h, int tile_w, int pg, int tw_log2) {
+  SmallPlan t;
+  t.pg = pg; t.tw_log2 = tw_log2;
+  const int tw = 1 << tw_log2;
+  t.th = 16 * pg / tw;
+  if (t.th < 1 || t.th * tw != 16 * pg) return t;
+  t.tiles = ((tile_h + t.th - 1) / t.th) * ((tile_w + tw - 1) / tw);
+  t.efficiency = (float)(tile_h * tile_w) / (float)(t.tiles * 16 * pg);
+  int dy_lo = g.dy[0], dy_hi = g.dy[0], dx_lo = g.dx[0], dx_hi = g.dx[0];
+  for (int i = 1; i < g.ntaps; ++i) {
+    dy_lo = std::min(dy_lo, g.dy[i]); dy_hi = std::max(dy_hi, g.dy[i]);
+    dx_lo = std::min(dx_lo, g.dx[i]); dx_hi = std::max(dx_hi, g.dx[i]);
+  }
+  t.dy0 = dy_lo; t.dx0 = dx_lo;
+  t.win_h = (t.th - 1) * g.in_stride + (dy_hi - dy_lo) + 1;
+  t.win_w = (tw - 1) * g.in_stride + (dx_hi - dx_lo) + 1;
+  const int npx = t.win_h * t.win_w;
+  if (npx * 4 > 7 * 64) return t;                      // kSmallMaxItems staging items per lane
+  const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
+  t.lds = 64 * plane;                                  // 8 waves x (4 hi + 4 lo planes); the 8*PG KiB reduction buffer aliases them
+  t.ok = true;
+  return t;
+}
+inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int nb, int nq, int want_wgs = 256) {
+  SmallPlan best;
+  float best_eff = 0.f;
+  for (int pg : {4, 2, 1})
+    for (int twl : {4, 3, 2}) {
+      const SmallPlan t = small_geom(g, tile_h, tile_w, pg, twl);
+      if (t.ok) best_eff = std::max(best_eff, t.efficiency);
+    }
+  if (best_eff == 0.f) return best;
+  // the largest tile (fewest re-reads of the weights) that still gives every CU a workgroup, else the smallest tile
+  auto pick = [&](int pg) {
+    SmallPlan b;
+    for (int twl : {4, 3, 2}) {
+      const SmallPlan t = small_geom(g, tile_h, tile_w, pg, twl);
+      if (t.ok && t.efficiency >= 0.9f * best_eff && (!b.ok || t.win_h * t.win_w < b.win_h * b.win_w)) b = t;
+    }
+    return b;
+  };
+  const int want = std::getenv("THA4_SMALL_WANT_WGS") ? std::atoi(std::getenv("THA4_SMALL_WANT_WGS")) : want_wgs;   // tuning aid
+  for (int pg : {4, 2, 1}) {
+    const SmallPlan t = pick(pg);
+    if (!t.ok) continue;
+    best = t;
+    if ((long)t.tiles * nb >= want) break;
+  }
+  if (!best.ok) return best;
+  int upq = 1;
+  while (nq * upq < 8 && upq * 2 <= g.ntaps) upq *= 2;  // few K groups: split each one's taps over several waves
+  best.units_per_q = upq;
   return best;
 }
 

@@ -20,6 +20,7 @@
 
 #include "full_image_kernels.h"
 #include "full_conv16_kernels.h"
+#include "full_conv_small_kernels.h"
 #include "full_kernels.h"
 #include "full_layout.h"
 
@@ -41,8 +42,16 @@ struct FTensor {           // C16 feature map in the workspace
 };
 
 struct Pending {           // transform a consumer applies while loading a tensor
-  size_t scale_off = (size_t)-1, shift_off = (size_t)-1;   // workspace offsets of [n][cb*16]
-  bool has() const { return scale_off != (size_t)-1; }
+  size_t scale_off = (size_t)-1, shift_off = (size_t)-1;   // workspace offsets of [n][cb*16] (written by norm_finalize_kernel)
+  // ... or FUSED: no finalize launch; the consumer reduces the producer's per-tile moments itself (FusedNorm)
+  bool fused = false;
+  size_t stats_off[2] = {0, 0};
+  int tiles[2] = {0, 0};
+  int channels = 0, groups = 0;
+  float inv_count = 0.f;
+  size_t gamma_off = 0, beta_off = 0, film0_off = (size_t)-1, film1_off = (size_t)-1;
+  long long film1_stride = 0;
+  bool has() const { return fused || scale_off != (size_t)-1; }
 };
 
 constexpr size_t kNone = (size_t)-1;
@@ -147,6 +156,17 @@ class FullModel {
     THA4_TCASE(1, 4) THA4_TCASE(1, 2) THA4_TCASE(1, 1)
 #undef THA4_TCASE
   }
+  template <int PGV>
+  static void launch_small(int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    if (inmode == IN_DIRECT) hipLaunchKernelGGL((conv_small_kernel<PGV, IN_DIRECT>), grid, dim3(kSmallThreads), lds, s, a);
+    else if (inmode == IN_UP2) hipLaunchKernelGGL((conv_small_kernel<PGV, IN_UP2>), grid, dim3(kSmallThreads), lds, s, a);
+    else hipLaunchKernelGGL((conv_small_kernel<PGV, IN_POOL2>), grid, dim3(kSmallThreads), lds, s, a);
+  }
+  static void dispatch_small(int pg, int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    if (pg == 4) return launch_small<4>(inmode, a, grid, lds, s);
+    if (pg == 2) return launch_small<2>(inmode, a, grid, lds, s);
+    return launch_small<1>(inmode, a, grid, lds, s);
+  }
   static hipError_t allow_all_conv_lds() {
     hipError_t e = hipSuccess;
     auto set = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
@@ -163,6 +183,12 @@ class FullModel {
     THA4_TALLOW(4, 4) THA4_TALLOW(4, 2) THA4_TALLOW(4, 1) THA4_TALLOW(2, 4) THA4_TALLOW(2, 2) THA4_TALLOW(2, 1)
     THA4_TALLOW(1, 4) THA4_TALLOW(1, 2) THA4_TALLOW(1, 1)
 #undef THA4_TALLOW
+#define THA4_SALLOW(PGV)                                                           \
+  set(reinterpret_cast<const void*>(conv_small_kernel<PGV, IN_DIRECT>));           \
+  set(reinterpret_cast<const void*>(conv_small_kernel<PGV, IN_UP2>));              \
+  set(reinterpret_cast<const void*>(conv_small_kernel<PGV, IN_POOL2>));
+    THA4_SALLOW(4) THA4_SALLOW(2) THA4_SALLOW(1)
+#undef THA4_SALLOW
     set(reinterpret_cast<const void*>(attention_kernel));
     return e;
   }
@@ -195,9 +221,16 @@ class FullModel {
     bool tiled = false;
     TilePlan plan;
     const int nq = (cbtot + 1) / 2;
+    // normalisation folded into this convolution? (all tensor sources come from ONE norm() call)
+    const Pending* fpend = nullptr;
+    int ctab = 0;
+    for (auto& sx : srcs)
+      if (!sx.vector) { ctab += sx.t.cb * 16; if (sx.pend.fused) fpend = &sx.pend; }
+    const size_t table_bytes = fpend ? (size_t)2 * ctab * sizeof(float) : 0;
     if ((kind != K_SAME1 || std::getenv("THA4_TILE_1X1")) && !std::getenv("THA4_NO_TILE_CONV")) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
       plan = plan_tile_conv(g0, th, tw, tmb, mtiles, nq);
+      if (plan.ok && table_bytes && !tile_geom(g0, th, tw, plan.pg, tmb, plan.geom.tw_log2, table_bytes).ok) plan.ok = false;
       // a half-filled chip without K split: halve the output tile instead (the window is staged twice as often, but
       // no partial-sum traffic and no second launch)
       if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles < 200) {
@@ -207,14 +240,30 @@ class FullModel {
       tiled = plan.ok;
       if (std::getenv("THA4_NO_TILE_SPLITK") && plan.ksplit > 1) tiled = false;
     }
+    // small maps (the tile plan would split K over two launches) and 1x1 convolutions: conv_small_kernel, K split across
+    // the waves of one workgroup, ONE launch
+    bool small = false;
+    SmallPlan sp;
+    {
+      const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
+      const int max1x1 = std::getenv("THA4_SMALL_1X1_MAX_PX") ? std::atoi(std::getenv("THA4_SMALL_1X1_MAX_PX")) : 64 * 64;
+      const bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
+      if (want && !std::getenv("THA4_NO_SMALL_CONV")) {
+        sp = plan_small_conv(g0, th, tw, nb, nq);
+        small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
+      }
+      if (small) { tiled = false; tmb = 1; mtiles = nb; }
+    }
     // fallbacks (1x1 convolutions): small maps (<= 32x32) one pixel group per workgroup with K split over its 4 waves
     // (conv_splitk_kernel), otherwise the exact-fp32 pixel-tiled kernel (conv_mfma_kernel)
-    const bool splitk = !tiled && tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
+    const bool splitk = !small && !tiled && tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
+    if (fpend && !small && !tiled) { if (error.empty()) error = "internal: a fused normalisation needs the tile / small convolution kernels"; return FTensor(); }
     int pg = 1;
-    if (tiled) pg = plan.pg;
+    if (small) pg = sp.pg;
+    else if (tiled) pg = plan.pg;
     else if (!splitk && tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
-    if (!tiled && tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
-    const int tiles = tiled ? plan.geom.tiles : splitk ? tile_px / 16 : tile_px / (64 * pg);
+    if (!small && !tiled && tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
+    const int tiles = small ? sp.tiles : tiled ? plan.geom.tiles : splitk ? tile_px / 16 : tile_px / (64 * pg);
     const int ksplit = tiled ? plan.ksplit : 1;
     if (tiled && ksplit > 1) {
       partial_floats = std::max(partial_floats, (size_t)ksplit * mtiles * tiles * tmb * 8 * pg * 64 * 4);
@@ -222,8 +271,8 @@ class FullModel {
     const int conv_index = conv_counter++;
     if (std::getenv("THA4_DUMP_SCHEDULE"))
       std::fprintf(stderr, "conv #%d kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d ksplit=%d twl=%d\n", conv_index, (int)kind, ih,
-                   iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles * ksplit, (int)tiled, ksplit,
-                   tiled ? plan.geom.tw_log2 : 0);
+                   iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles * ksplit, small ? 2 : (int)tiled, ksplit,
+                   small ? sp.tw_log2 : tiled ? plan.geom.tw_log2 : 0);
     FTensor out = new_tensor(nb, oh, ow);
     if (want_stats) {
       out.stats_tiles = tiles * nclass;
@@ -243,8 +292,17 @@ class FullModel {
       size_t w_off = 0, lds = 0;
       int cq = 1;
       ConvArgs a{};
-      if (tiled) {
-        const TileGeom tg = tile_geom(g, th, tw, pg, tmb, plan.geom.tw_log2);
+      if (small) {
+        const SmallPlan sg = small_geom(g, th, tw, sp.pg, sp.tw_log2);
+        if (!sg.ok || sg.tiles != sp.tiles) { if (error.empty()) error = "small conv geometry differs between parity classes"; return FTensor(); }
+        float inv = 1.f;
+        const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, 1, &inv);
+        w_off = add_param(p16.data(), p16.size());
+        lds = ((table_bytes + 127) & ~(size_t)127) + sg.lds;
+        a.w16_inv_scale = inv; a.wg_tw_log2 = sg.tw_log2; a.win_h = sg.win_h; a.win_w = sg.win_w;
+        a.win_dy0 = sg.dy0; a.win_dx0 = sg.dx0; a.units_per_q = sp.units_per_q;
+      } else if (tiled) {
+        const TileGeom tg = tile_geom(g, th, tw, pg, tmb, plan.geom.tw_log2, table_bytes);
         float inv = 1.f;
         const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb, &inv);
         w_off = add_param(p16.data(), p16.size());
@@ -269,6 +327,7 @@ class FullModel {
       a.stats_tiles = out.stats_tiles; a.stats_tile0 = cls * tiles;
       a.nb = nb; a.chunk_quads = cq;
       std::vector<Src> sv = srcs;
+      const Pending fp = fpend ? *fpend : Pending();
       const FTensor outc = out;
       const bool has_res = residual != nullptr;
       const FTensor resc = has_res ? *residual : FTensor();
@@ -283,6 +342,16 @@ class FullModel {
           c.src[i].scale = s.pend.has() ? Wk(s.pend.scale_off) : nullptr;
           c.src[i].shift = s.pend.has() ? Wk(s.pend.shift_off) : nullptr;
         }
+        if (fp.fused) {
+          FusedNorm& fn = c.fnorm;
+          fn.enabled = 1;
+          for (int i = 0; i < 2; ++i) { fn.stats[i] = fp.tiles[i] ? Wk(fp.stats_off[i]) : nullptr; fn.tiles[i] = fp.tiles[i]; }
+          fn.channels = fp.channels; fn.groups = fp.groups; fn.inv_count = fp.inv_count; fn.eps = 1e-5f;
+          fn.gamma = P(fp.gamma_off); fn.beta = P(fp.beta_off);
+          fn.film0 = fp.film0_off == kNone ? nullptr : P(fp.film0_off);
+          fn.film1 = fp.film1_off == kNone ? nullptr : Wk(fp.film1_off);
+          fn.film1_stride = fp.film1_stride;
+        }
         c.w = P(w_off);
         c.w16 = P<char>(w_off);
         c.partial = ksplit > 1 ? Wk(partial_off) : nullptr;
@@ -296,7 +365,9 @@ class FullModel {
         c.out = Wk(outc.off);
         c.stats = outc.stats_tiles ? Wk(outc.stats_off) : nullptr;
         c.batch = f.batch;
-        if (splitk) {
+        if (small) {
+          dispatch_small(pg, in_mode, c, dim3(f.batch * tiles, nb, 1), lds, f.stream);
+        } else if (splitk) {
           const dim3 grid(f.batch * tiles, mtiles);
           if (in_mode == IN_DIRECT) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_DIRECT>), grid, dim3(256), 16 * 1024, f.stream, c);
           else if (in_mode == IN_UP2) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_UP2>), grid, dim3(256), 16 * 1024, f.stream, c);
@@ -323,12 +394,25 @@ class FullModel {
                             const HostTensor& gamma, const HostTensor& beta, size_t film0_off = kNone,
                             size_t film1_off = kNone, long long film1_stride = 0) {
     std::vector<Pending> out(srcs.size());
+    const size_t g_off = add_param(gamma.data, sizeof(float) * channels);
+    const size_t b_off = add_param(beta.data, sizeof(float) * channels);
+    // few tiles: no finalize launch - every consumer reduces the per-tile moments itself (FusedNorm / FusedInstanceNorm)
+    int total_tiles = 0;
+    for (auto& t : srcs) total_tiles += t.stats_tiles;
+    const int fuse_max = std::getenv("THA4_FUSED_NORM_MAX_TILES") ? std::atoi(std::getenv("THA4_FUSED_NORM_MAX_TILES")) : 64;
+    if (total_tiles <= fuse_max && srcs.size() <= 2 && !std::getenv("THA4_NO_SMALL_CONV") && !std::getenv("THA4_NO_TILE_CONV")) {
+      Pending p;
+      p.fused = true;
+      for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].stats_off; p.tiles[i] = srcs[i].stats_tiles; }
+      p.channels = channels; p.groups = groups; p.inv_count = 1.0f / (float)(srcs[0].h * srcs[0].w);
+      p.gamma_off = g_off; p.beta_off = b_off; p.film0_off = film0_off; p.film1_off = film1_off; p.film1_stride = film1_stride;
+      for (auto& o : out) o = p;
+      return out;
+    }
     for (size_t i = 0; i < srcs.size(); ++i) {
       out[i].scale_off = alloc_work((size_t)srcs[i].cb * 16);
       out[i].shift_off = alloc_work((size_t)srcs[i].cb * 16);
     }
-    const size_t g_off = add_param(gamma.data, sizeof(float) * channels);
-    const size_t b_off = add_param(beta.data, sizeof(float) * channels);
     const std::vector<FTensor> sv = srcs;
     const std::vector<Pending> pv = out;
     int cbt = 0;
@@ -353,14 +437,25 @@ class FullModel {
   }
 
   FTensor affine_add(std::vector<Op>& ops, const FTensor& A, Pending pa, int act_a, const FTensor& B, Pending pb) {
+    if (((pa.fused && pa.groups) || (pb.fused && pb.groups) || (A.px() * 4) % 256 != 0) && (pa.fused || pb.fused)) {
+      if (error.empty()) error = "internal: affine_add supports fused InstanceNorm on maps of >= 64 pixels only";
+      return FTensor();
+    }
     FTensor out = new_tensor(A.cb, A.h, A.w);
     ops.push_back([=](const Frame& f) {
       AffineAddArgs k{};
-      k.a = Wk(A.off); k.sa = pa.has() ? Wk(pa.scale_off) : nullptr; k.ha = pa.has() ? Wk(pa.shift_off) : nullptr; k.act_a = act_a;
-      k.b = Wk(B.off); k.sb = pb.has() ? Wk(pb.scale_off) : nullptr; k.hb = pb.has() ? Wk(pb.shift_off) : nullptr;
+      auto mat = [&](const Pending& p) { return p.has() && !p.fused; };
+      auto fin = [&](const Pending& p, FusedInstanceNorm& fi) {       // InstanceNorm only (resnet_block.py:52-67)
+        if (!p.fused) return;
+        fi.stats = Wk(p.stats_off[0]); fi.tiles = p.tiles[0]; fi.inv_count = p.inv_count; fi.eps = 1e-5f;
+        fi.gamma = P(p.gamma_off); fi.beta = P(p.beta_off);
+      };
+      k.a = Wk(A.off); k.sa = mat(pa) ? Wk(pa.scale_off) : nullptr; k.ha = mat(pa) ? Wk(pa.shift_off) : nullptr; k.act_a = act_a;
+      k.b = Wk(B.off); k.sb = mat(pb) ? Wk(pb.scale_off) : nullptr; k.hb = mat(pb) ? Wk(pb.shift_off) : nullptr;
+      fin(pa, k.fa); fin(pb, k.fb);
       k.out = Wk(out.off); k.cb = A.cb; k.px = A.px();
       const size_t quads = (size_t)A.cb * A.px() * 4;
-      hipLaunchKernelGGL(affine_add_kernel, dim3((unsigned)((quads + 255) / 256), f.batch), dim3(256), 0, f.stream, k);
+      hipLaunchKernelGGL(affine_add_kernel, dim3((unsigned)((quads + 255) / 256), f.batch), dim3(256), 256, f.stream, k);
     });
     return out;
   }

@@ -23,6 +23,15 @@
 #define THA4_SCHED_FENCE()
 #endif
 
+// wave-level ordering point for wave-PRIVATE LDS traffic (one lane writes, another lane of the same wave reads): the
+// hardware executes a wave's DS instructions in program order, so nothing is needed but a fence for the compiler's
+// scheduler; the fiber emulator runs lanes one after the other and needs a real rendezvous
+#ifdef THA4_EMU
+#define THA4_WAVE_SYNC() ((void)emu::shfl(0.0f, 0))
+#else
+#define THA4_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 namespace tha4 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -9,6 +9,7 @@
 #define THA4_EMU 1
 #endif
 #include "full_conv16_kernels.h"
+#include "full_conv_small_kernels.h"
 #include "full_image_kernels.h"
 #include "full_layout.h"
 
@@ -66,7 +67,25 @@ struct Mirror {
 #endif
 }  // namespace
 
+namespace {
+// normalisation folded into the NEXT emu_conv call (FusedNorm): host pointers, consumed once
+struct FusedSpec {
+  bool set = false;
+  const float* stats[2]; int tiles[2]; int channels, groups; float inv_count;
+  const float* gamma; const float* beta; const float* film0; const float* film1;
+} g_fused;
+}  // namespace
+
 extern "C" {
+
+// stats0/1: per-tile moments [n][tiles][cb*16][2] of the two sources; film0 [2*channels] constant, film1 [n][2*channels]
+void emu_set_fused_norm(const float* stats0, int tiles0, const float* stats1, int tiles1, int channels, int groups, float inv_count,
+                        const float* gamma, const float* beta, const float* film0, const float* film1) {
+  g_fused.set = true;
+  g_fused.stats[0] = stats0; g_fused.tiles[0] = tiles0; g_fused.stats[1] = stats1; g_fused.tiles[1] = tiles1;
+  g_fused.channels = channels; g_fused.groups = groups; g_fused.inv_count = inv_count;
+  g_fused.gamma = gamma; g_fused.beta = beta; g_fused.film0 = film0; g_fused.film1 = film1;
+}
 
 // Generic convolution driver.  All tensors NCHW on the Python side; converted to C16 here.
 //  kind: 0 conv kxk stride 1 'same', 1 conv 4x4 stride 2 pad 1, 2 convT 4x4 stride 2 pad 1
@@ -122,15 +141,25 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
   Mirror M;
   const bool splitk = pg == 0;
-  const bool tiled = pg >= 10;              // conv_tile_kernel<tmb, pg - 10>
-  const int tpg = pg - 10;
+  const bool small = pg >= 20;              // conv_small_kernel<pg - 20> (tmb must be 1; `ksplit` carries units_per_q, 0 = planner's)
+  const bool tiled = pg >= 10 && !small;    // conv_tile_kernel<tmb, pg - 10>
+  const int tpg = pg - 10, spg = pg - 20;
+  const FusedSpec fused = g_fused;
+  g_fused.set = false;
+  const size_t table_bytes = fused.set ? (size_t)2 * (cb0 + (c1 > 0 && !vec1 ? cb1 : 0)) * 16 * sizeof(float) : 0;
+  SmallPlan sp0;
+  if (small) {
+    if (tmb != 1) return -5;
+    sp0 = small_geom(kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0)), th, tw, spg, tw_log2);
+    if (!sp0.ok) return -4;
+  }
   TileGeom tg0;
   if (tiled) {
-    tg0 = tile_geom(kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0)), th, tw, tpg, tmb, tw_log2);
+    tg0 = tile_geom(kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0)), th, tw, tpg, tmb, tw_log2, table_bytes);
     if (!tg0.ok) return -4;
   }
-  const int tiles_per_class = splitk ? th * tw / 16 : (tiled ? tg0.tiles : (th * tw / 16) / (4 * pg));
-  if (!splitk && !tiled && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
+  const int tiles_per_class = small ? sp0.tiles : splitk ? th * tw / 16 : (tiled ? tg0.tiles : (th * tw / 16) / (4 * pg));
+  if (!small && !splitk && !tiled && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
   const int stats_tiles = tiles_per_class * nclass;
   std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
   float *dX0 = M.up(X0), *dX1 = c1 > 0 ? M.up(X1) : nullptr, *dR = residual ? M.up(R) : nullptr, *dB = M.up(B), *dO = M.up(O), *dST = M.up(ST);
@@ -144,6 +173,16 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     ConvGeom g = kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1));
     std::vector<float> P = pack_conv_weight(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb);
     ConvArgs a{};
+    if (fused.set) {
+      FusedNorm& fn = a.fnorm;
+      fn.enabled = 1;
+      fn.stats[0] = M.up(fused.stats[0], (size_t)n * fused.tiles[0] * cb0 * 16 * 2); fn.tiles[0] = fused.tiles[0];
+      fn.stats[1] = fused.stats[1] ? M.up(fused.stats[1], (size_t)n * fused.tiles[1] * cb1 * 16 * 2) : nullptr; fn.tiles[1] = fused.tiles[1];
+      fn.channels = fused.channels; fn.groups = fused.groups; fn.inv_count = fused.inv_count; fn.eps = 1e-5f;
+      fn.gamma = M.up(fused.gamma, (size_t)fused.channels); fn.beta = M.up(fused.beta, (size_t)fused.channels);
+      fn.film0 = M.up(fused.film0, (size_t)2 * fused.channels); fn.film1 = M.up(fused.film1, (size_t)n * 2 * fused.channels);
+      fn.film1_stride = 2 * fused.channels;
+    }
     a.src[0] = ConvSrc{dX0, dsc0, dsh0, cb0, SRC_TENSOR, act_in};
     a.nsrc = 1;
     if (c1 > 0) {
@@ -164,8 +203,19 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     std::vector<char> P16;
     std::vector<float> partial;
     TileGeom tg;
+    SmallPlan sg;
+    if (small) {
+      sg = small_geom(g, th, tw, spg, tw_log2);
+      if (!sg.ok) return -4;
+      float inv = 1.f;
+      P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, 1, &inv);
+      a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = sg.tw_log2; a.win_h = sg.win_h; a.win_w = sg.win_w;
+      a.win_dy0 = sg.dy0; a.win_dx0 = sg.dx0;
+      const int nq = (cb0 + cb1 + 1) / 2;
+      a.units_per_q = ksplit > 0 ? ksplit : plan_small_conv(g, th, tw, nb, nq).units_per_q;
+    }
     if (tiled) {
-      tg = tile_geom(g, th, tw, tpg, tmb, tw_log2);
+      tg = tile_geom(g, th, tw, tpg, tmb, tw_log2, table_bytes);
       if (!tg.ok) return -4;
       partial.assign((size_t)ksplit * n * mtiles * tg.tiles * tmb * 8 * tpg * 64 * 4, 0.f);
       a.partial = M.up(partial); a.ksplit = ksplit;
@@ -174,8 +224,20 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
       a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots;
     }
-    const size_t lds = tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
+    const size_t lds = small ? ((table_bytes + 127) & ~(size_t)127) + sg.lds : tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
     const int phases = tiled && ksplit > 1 ? 2 : 1;
+    if (small) {
+      const dim3 sgrid(n * tiles_per_class, nb, 1);
+#define RUNS(PGV)                                                                                            \
+  if (spg == PGV) {                                                                                          \
+    if (in_mode == IN_DIRECT) THA4_RUN((conv_small_kernel<PGV, IN_DIRECT>), sgrid, kSmallThreads, lds, a);   \
+    else if (in_mode == IN_UP2) THA4_RUN((conv_small_kernel<PGV, IN_UP2>), sgrid, kSmallThreads, lds, a);    \
+    else THA4_RUN((conv_small_kernel<PGV, IN_POOL2>), sgrid, kSmallThreads, lds, a);                         \
+  }
+      RUNS(1) RUNS(2) RUNS(4)
+#undef RUNS
+      continue;
+    }
     for (int ph = 0; ph < phases; ++ph) {
     a.phase = phases == 1 ? 0 : ph + 1;
     const int run_tmb = a.phase == 2 ? 1 : tmb;          // phase 2 runs one output block per workgroup
@@ -228,6 +290,15 @@ int emu_plan_tile_conv(int kind, int k, int tile_h, int tile_w, int tmb, int mti
   const TilePlan p = plan_tile_conv(g, tile_h, tile_w, tmb, mtiles, nq);
   out[0] = p.ok; out[1] = p.pg; out[2] = p.ksplit; out[3] = p.geom.tw_log2; out[4] = p.geom.th; out[5] = p.geom.tiles;
   out[6] = p.geom.win_h; out[7] = p.geom.win_w; out[8] = p.geom.taps_per_chunk; out[9] = p.geom.ring_slots; out[10] = (int)p.geom.lds;
+  return 0;
+}
+
+// Launch plan of conv_small_kernel: out = {ok, pg, tw_log2, th, tiles, win_h, win_w, units_per_q, lds_bytes, workgroups}
+int emu_plan_small_conv(int kind, int k, int tile_h, int tile_w, int nb, int nq, int* out) {
+  const ConvGeom g = kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0));
+  const SmallPlan p = plan_small_conv(g, tile_h, tile_w, nb, nq);
+  out[0] = p.ok; out[1] = p.pg; out[2] = p.tw_log2; out[3] = p.th; out[4] = p.tiles; out[5] = p.win_h; out[6] = p.win_w;
+  out[7] = p.units_per_q; out[8] = (int)p.lds; out[9] = p.tiles * nb;
   return 0;
 }
 

@@ -120,6 +120,19 @@ CASES = [
     (0, 3, 2, 12, 0, "relu", 64, 0, False, 24, 24, 32, True, False, False, True, (5, 2)),   # ragged 8x32 tiles (cols 24..31 masked) + split-K
     (2, 4, 2, 11, 0, "relu", 64, 0, False, 12, 12, 32, False, False, False, True, (4, 2)),  # convT on a 12x12 map: ragged + split-K, 4 classes
     (1, 4, 2, 11, 0, "relu", 32, 0, False, 48, 48, 32, False, False, False, True, (3, 1)),  # 4x4 s2 -> 24x24 in 16x8 tiles (34x18 window)
+    # conv_small_kernel (pg = 20 + PG, tmb = 1): K split across the 8 waves of a workgroup, weights from L2 to registers
+    # last field: (log2 tile width, units per K group; 0 = the planner's choice)
+    (0, 3, 1, 21, 0, "relu", 96, 0, False, 16, 16, 32, True, True, False, True, (4, 0)),    # 3x3, 1x16 row tiles, 3 K groups -> tap split x4, residual
+    (0, 3, 1, 22, 0, "silu", 64, 64, False, 16, 16, 48, True, False, False, True, (4, 1)),  # PG=2, concat of two tensors, 4 K groups on 4 waves
+    (0, 3, 1, 24, 0, "relu", 160, 27, True, 24, 24, 32, False, False, False, True, (3, 0)),  # PG=4: 24x24 in 8x8 tiles, tensor ++ pose vector, 6 K groups
+    (0, 3, 1, 21, 0, "relu", 288, 0, False, 16, 16, 16, True, False, False, True, (4, 0)),   # 9 K groups: wave 0 runs two units (prefetch path)
+    (0, 1, 1, 22, 0, "none", 256, 0, False, 16, 16, 64, True, True, False, True, (4, 0)),    # 1x1 (attention projection + residual), 8 K groups
+    (0, 1, 1, 24, 0, "none", 48, 0, False, 16, 32, 40, True, False, False, False, (4, 0)),   # 1x1 skip, odd quad count, 2 K groups on 2 waves
+    (1, 4, 1, 21, 0, "relu", 64, 0, False, 32, 32, 32, False, False, False, True, (3, 0)),   # 4x4 stride 2 -> 16x16, 2x8 tiles (6x18 window), 16 taps
+    (2, 4, 1, 22, 0, "relu", 64, 0, False, 16, 16, 32, False, False, False, True, (4, 0)),   # convT 4x4 s2: four parity classes
+    (0, 3, 1, 21, 1, "silu", 64, 0, False, 8, 8, 32, True, False, False, True, (4, 0)),      # nearest-up x2 on load
+    (0, 3, 1, 22, 2, "silu", 64, 0, False, 32, 32, 32, True, False, False, True, (4, 0)),    # avg-pool 2x2 on load
+    (0, 3, 1, 24, 0, "relu", 32, 0, False, 20, 20, 16, True, False, True, False, (3, 0)),    # ragged 20x20 in 8x8 tiles, per-channel output activations
 ]
 
 
@@ -376,3 +389,78 @@ def test_upscaler_input_bilinear_edges_and_warp(lib):
     for band in (np.s_[..., 0:2, :], np.s_[..., 510:512, :], np.s_[..., :, 0:2], np.s_[..., :, 510:512]):      # edge-clamped taps
         assert e_m[band].max() < 2e-6 and e_g[band].max() < 1e-6
     assert np.abs(out[:, 8:12] - w.numpy()).max() < 5e-4
+
+
+def _norm_ref(x, channels, groups, gamma, beta, f0, f1):
+    """InstanceNorm / GroupNorm (+ two FiLM stages) of [n][c][h][w] in fp64 (unet.py:90-97,157-163)."""
+    t = torch.from_numpy(x).double()
+    g64, b64 = torch.from_numpy(gamma).double(), torch.from_numpy(beta).double()
+    h = F.instance_norm(t, weight=g64, bias=b64, eps=1e-5) if groups == 0 else F.group_norm(t, groups, g64, b64, eps=1e-5)
+    if f0 is not None:
+        ft = torch.from_numpy(f0).double()
+        h = h * (1 + ft[None, :channels, None, None]) + ft[None, channels:, None, None]
+    if f1 is not None:
+        ft = torch.from_numpy(f1).double()
+        h = h * (1 + ft[:, :channels, None, None]) + ft[:, channels:, None, None]
+    return h
+
+
+FUSED_CASES = [
+    # pg  k  act     c0   c1   h   w  cout groups film  tiles (twl, x)
+    (21, 3, "relu", 64, 0, 16, 16, 32, 0, False, 4, (4, 0)),      # conv_small + InstanceNorm/ReLU (encoder-decoder bottleneck)
+    (22, 3, "silu", 64, 32, 16, 16, 32, 32, True, 2, (4, 0)),     # conv_small + GroupNorm(32) over a concatenation (groups of 3 straddle it) + both FiLM stages
+    (24, 1, "none", 128, 0, 16, 16, 48, 32, False, 8, (4, 0)),    # 1x1 qkv projection after GroupNorm
+    (12, 3, "silu", 64, 32, 32, 32, 32, 32, True, 4, (4, 1)),     # conv_tile_kernel<2,2> with the table in its prologue
+    (11, 3, "relu", 48, 0, 16, 16, 32, 0, False, 2, (4, 2)),      # conv_tile_kernel K split (phase 1 builds the table, phase 2 skips it)
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_with_fused_norm(lib, case):
+    """The normalisation folded into the consumer convolution (FusedNorm): the kernel reduces the producer's per-tile moments
+    itself.  Reference: torch norm (+FiLM) -> activation -> conv in fp64."""
+    pg, k, act_in, c0, c1, h, w, cout, groups, film, tiles, (twl, extra) = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    n = 2
+    x0 = (rng.standard_normal((n, c0, h, w)) * 1.7 + 0.4).astype(np.float32)
+    x1 = (rng.standard_normal((n, c1, h, w)) * 0.6 - 0.2).astype(np.float32) if c1 else None
+    cin = c0 + c1
+    gamma = (1 + 0.2 * rng.standard_normal(cin)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(cin)).astype(np.float32)
+    f0 = (0.3 * rng.standard_normal(2 * cin)).astype(np.float32) if film else None
+    f1 = (0.3 * rng.standard_normal((n, 2 * cin))).astype(np.float32) if film else None
+    st0, cb0 = _partials(x0.reshape(n, c0, h * w), tiles)
+    st1 = _partials(x1.reshape(n, c1, h * w), tiles * 2)[0] if c1 else None
+    weight = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    xin = np.concatenate([x0, x1], 1) if c1 else x0
+    hn = torch_act(_norm_ref(xin, cin, groups, gamma, beta, f0, f1), act_in)
+    ref = F.conv2d(hn, torch.from_numpy(weight).double(), torch.from_numpy(bias).double(), padding=k // 2).numpy()
+    lib.emu_set_fused_norm(P(st0), tiles, P(st1), tiles * 2 if c1 else 0, cin, groups, C.c_float(1.0 / (h * w)), P(gamma), P(beta), P(f0), P(f1))
+    tmb = 1 if pg >= 20 else 2
+    out, stats = run_conv(lib, 0, k, tmb, pg, 0, act_in, x0, x1, False, None, None, weight, bias, None, None, 1, twl,
+                          extra if pg < 20 else 0)
+    assert np.abs(out - ref).max() < 5e-5, np.abs(out - ref).max()
+    assert np.abs(stats[..., 0] - ref.sum(axis=(2, 3))).max() < 2e-3
+
+
+def test_small_conv_launch_plans(lib):
+    """plan_small_conv over the small-map shapes of the full model: every map tiles, the window fits the staging budget,
+    LDS <= 160 KiB, and few K groups are spread over the waves by tap ranges."""
+    out = (C.c_int * 10)()
+    for (kind, k, th, tw, cin, cout) in [(0, 3, 16, 16, 256, 256), (0, 3, 16, 16, 512, 512), (0, 3, 16, 16, 524, 512), (0, 3, 24, 24, 539, 512),
+                                         (0, 3, 32, 32, 256, 256), (0, 3, 32, 32, 512, 256), (0, 1, 16, 16, 256, 768), (0, 1, 32, 32, 512, 256),
+                                         (1, 4, 16, 16, 256, 512), (1, 4, 24, 24, 256, 512), (1, 4, 32, 32, 128, 256), (1, 4, 64, 64, 64, 128),
+                                         (2, 4, 16, 16, 512, 256), (2, 4, 24, 24, 512, 256), (2, 4, 64, 64, 128, 64), (0, 3, 64, 64, 128, 128),
+                                         (0, 3, 48, 48, 256, 256), (0, 1, 64, 64, 384, 256)]:
+        nb = (cout + 15) // 16
+        nq = ((cin + 15) // 16 + 1) // 2
+        lib.emu_plan_small_conv(kind, k, th, tw, nb, nq, out)
+        ok, pg, twl, tile_h, tiles, win_h, win_w, upq, lds, wgs = list(out)
+        assert ok, (kind, k, th, tw, cin, cout)
+        assert pg in (1, 2, 4) and 16 * pg == tile_h << twl
+        assert tiles == -(-th // tile_h) * -(-tw // (1 << twl)) and wgs == tiles * nb
+        assert win_h * win_w * 4 <= 7 * 64 and lds + 8192 <= 160 * 1024
+        ntaps = {0: k * k, 1: 16, 2: 4}[kind]
+        assert upq in (1, 2, 4, 8) and upq <= max(1, ntaps) and (nq * upq >= 8 or upq * 2 > ntaps)
+        assert wgs >= 64, (th, tw, cin, cout, wgs)

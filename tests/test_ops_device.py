@@ -17,11 +17,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.fixture(scope="module")
 def lib():
     import torch  # noqa: F401  (its HIP runtime first, as for libtha4_hip.so)
-    path = os.path.join(HERE, "emu", "libtha4_ops_device.so")
-    if not os.path.exists(path):
-        import __graft_entry__ as g
-        g.build_ops_device()
-    return C.CDLL(path)
+    import __graft_entry__ as g
+    return C.CDLL(g.build_ops_device())          # no-op when the in-tree .so is newer than its sources
+
+
+@pytest.mark.parametrize("case", T.FUSED_CASES)
+def test_fused_norm_convs_on_device(lib, case):
+    T.test_conv_with_fused_norm(lib, case)
 
 
 @pytest.mark.parametrize("case", T.CASES)
