@@ -47,24 +47,52 @@ constexpr int tile_plane_bytes(int win_px) { return (win_px * 16 + 127) / 128 * 
 THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, float* tab_sc, float* tab_sh, double* scratch) {
   const FusedNorm& f = a.fnorm;
   const int c0 = a.src[0].cb * 16;
-  const int ctot = c0 + (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR ? a.src[1].cb * 16 : 0);
+  const int ctot = c0 + (a.nsrc > 1 && a.src[1].kind == SRC_TENSOR ? a.src[1].cb * 16 : 0);     // <= 2 * nthreads (host-checked)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  for (int c = tid; c < ctot; c += nthreads) {
+  constexpr int MAXC = 2, TB = 8;
+  // ONE memory round trip: every global value this thread's channels need - the moments of all tiles (TB loads in flight
+  // per batch), gamma, beta and both FiLM rows - is requested before anything is consumed
+  float gam[MAXC], bet[MAXC], s0v[MAXC], b0v[MAXC], s1v[MAXC], b1v[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * nthreads;
+    gam[i] = 0.f; bet[i] = 0.f; s0v[i] = 0.f; b0v[i] = 0.f; s1v[i] = 0.f; b1v[i] = 0.f;
+    if (c < ctot && c < f.channels) {
+      gam[i] = f.gamma[c];
+      bet[i] = f.beta[c];
+      if (f.film0) { s0v[i] = f.film0[c]; b0v[i] = f.film0[f.channels + c]; }
+      if (f.film1) { s1v[i] = f.film1[(size_t)n * f.film1_stride + c]; b1v[i] = f.film1[(size_t)n * f.film1_stride + f.channels + c]; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * nthreads;
+    if (c >= ctot) continue;
     const int s = c < c0 ? 0 : 1;
     const int cl = c - (s ? c0 : 0);
     const int cw = a.src[s].cb * 16;
-    const float* ps = f.stats[s] + ((size_t)n * f.tiles[s] * cw + cl) * 2;
+    const int nt = f.tiles[s];
+    const float* ps = f.stats[s] + ((size_t)n * nt * cw + cl) * 2;
     double su = 0.0, sq = 0.0;
-    for (int t = 0; t < f.tiles[s]; ++t) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
-      su += (double)v[0];
-      sq += (double)v[1];
+    for (int t0 = 0; t0 < nt; t0 += TB) {
+      f32x2 v[TB];
+#pragma unroll
+      for (int u2 = 0; u2 < TB; ++u2) v[u2] = *reinterpret_cast<const f32x2*>(ps + (size_t)min(t0 + u2, nt - 1) * cw * 2);
+#pragma unroll
+      for (int u2 = 0; u2 < TB; ++u2) {                    // fixed order; tiles past the last one are re-reads, dropped by the select
+        const bool keep = t0 + u2 < nt;
+        su += keep ? (double)v[u2][0] : 0.0;
+        sq += keep ? (double)v[u2][1] : 0.0;
+      }
     }
     scratch[c] = su;
     scratch[ctot + c] = sq;
   }
   __syncthreads();
-  for (int c = tid; c < ctot; c += nthreads) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * nthreads;
+    if (c >= ctot) continue;
     float sc = 0.f, sh = 0.f;
     if (c < f.channels) {
       double mean, var;
@@ -80,16 +108,10 @@ THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, 
         var = sq * f.inv_count / gs - mean * mean;
       }
       const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)f.eps);
-      double k = (double)f.gamma[c] * rstd;
-      double b = (double)f.beta[c] - mean * k;
-      if (f.film0) {
-        const double s0 = f.film0[c], b0 = f.film0[f.channels + c];
-        k *= (1.0 + s0); b = b * (1.0 + s0) + b0;
-      }
-      if (f.film1) {
-        const double s1 = f.film1[(size_t)n * f.film1_stride + c], b1 = f.film1[(size_t)n * f.film1_stride + f.channels + c];
-        k *= (1.0 + s1); b = b * (1.0 + s1) + b1;
-      }
+      double k = (double)gam[i] * rstd;
+      double b = (double)bet[i] - mean * k;
+      if (f.film0) { k *= (1.0 + (double)s0v[i]); b = b * (1.0 + (double)s0v[i]) + (double)b0v[i]; }
+      if (f.film1) { k *= (1.0 + (double)s1v[i]); b = b * (1.0 + (double)s1v[i]) + (double)b1v[i]; }
       sc = (float)k;
       sh = (float)b;
     }

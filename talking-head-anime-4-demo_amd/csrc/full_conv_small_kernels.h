@@ -41,10 +41,22 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (PG * 16) >> twl;
   const int tiles_x = (a.tile_w + TWW - 1) >> twl;
   const int tiles_per_frame = tiles_x * ((a.tile_h + TWH - 1) / TWH);
-  const int n = blockIdx.x / tiles_per_frame;
-  const int tile = blockIdx.x % tiles_per_frame;
+  // 1-D grid of batch * tiles * nb workgroups.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2):
+  // all pixel tiles of one output block share that block's weights, so they are mapped to ONE XCD (block bo -> XCD
+  // bo % 8) and every weight is fetched from HBM / MALL once per frame instead of once per XCD
+  const int G = a.batch * tiles_per_frame;                 // workgroups per output block
+  int bo, tl;
+  if ((a.nb & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    bo = xcd + 8 * (slot / G);
+    tl = slot % G;
+  } else {
+    bo = blockIdx.x / G;
+    tl = blockIdx.x % G;
+  }
+  const int n = tl / tiles_per_frame;
+  const int tile = tl % tiles_per_frame;
   const int tile_y0 = (tile / tiles_x) * TWH, tile_x0 = (tile % tiles_x) << twl;
-  const int bo = blockIdx.y;                               // output block (16 channels)
   const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (kPool ? a.in_h / 2 : a.in_h);
   const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (kPool ? a.in_w / 2 : a.in_w);
   const int in_px = a.in_h * a.in_w;
@@ -215,14 +227,45 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   };
 
   // ---- first unit's loads go out before the normalisation table is built -------------------------
+  // three register-resident weight chunks (3 taps each: a whole 3x3 K group) are in flight per wave; longer tap ranges
+  // (4x4 stride 2: 16 taps) roll through the three slots
   int u = wave;
   int curQ = -1;
-  WChunk w0, w1;
+  WChunk w0, w1, w2;
+  auto load_unit_head = [&](int Q, int t0, int t1) {       // the first three chunks of a unit
+    load_weights(Q, t0, t1, w0);
+    if (t0 + TC < t1) load_weights(Q, t0 + TC, t1, w1);
+    if (t0 + 2 * TC < t1) load_weights(Q, t0 + 2 * TC, t1, w2);
+  };
   if (u < nunits) {
     curQ = u / upq;
     load_window(curQ);
     const int t0 = (u % upq) * tpu;
-    load_weights(curQ, t0, min(a.ntaps, t0 + tpu), w0);
+    load_unit_head(curQ, t0, min(a.ntaps, t0 + tpu));
+  }
+  // wave 0 runs the epilogue: its residual values are requested now, not after the reduction
+  const int out_px = a.out_h * a.out_w;
+  constexpr bool kPrefetchRes = !(PG == 4 && kPool);       // (the one instantiation without a spare register keeps the load in the epilogue)
+  auto load_residual = [&](int pg) -> f32x4 {
+    const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
+    if (a.res_mode == IN_DIRECT)
+      return *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4);
+    if (a.res_mode == IN_UP2) {                            // ResBlock x_resample = Upsample (unet.py:46): nearest
+      const int rw = a.out_w >> 1, rpx = out_px >> 2;
+      return *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
+    }
+    const int rw = a.out_w * 2;                            // x_resample = Downsample = AvgPool2d(2,2) (unet.py:58)
+    const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
+    return ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
+            (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
+  };
+  f32x4 resv[kPrefetchRes ? PG : 1];
+  if (kPrefetchRes) {
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      resv[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (wave == 0 && a.residual && inside[pg]) resv[pg] = load_residual(pg);
+    }
   }
   if (a.fnorm.enabled) {
     fused_norm_table(a, n, tid, kSmallThreads, tab_sc, tab_sh, reinterpret_cast<double*>(wins));
@@ -238,21 +281,25 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
       staged = true;
       THA4_WAVE_SYNC();
     }
-    // two register-resident weight chunks in flight: w0 arrives (prologue / previous unit / previous pair) while w1 is
-    // requested, and the next pair's w0 is requested as soon as this pair's w0 has been consumed
-    for (int t = t0; t < t1; t += 2 * TC) {
-      if (t + TC < t1) load_weights(Q, t + TC, t1, w1);
+    for (int t = t0; t < t1; t += 3 * TC) {                // slots are refilled as soon as their MFMAs are issued
       mac_chunk(t, t1, w0);
-      if (t + 2 * TC < t1) load_weights(Q, t + 2 * TC, t1, w0);
-      if (t + TC < t1) mac_chunk(t + TC, t1, w1);
+      if (t + 3 * TC < t1) load_weights(Q, t + 3 * TC, t1, w0);
+      if (t + TC < t1) {
+        mac_chunk(t + TC, t1, w1);
+        if (t + 4 * TC < t1) load_weights(Q, t + 4 * TC, t1, w1);
+      }
+      if (t + 2 * TC < t1) {
+        mac_chunk(t + 2 * TC, t1, w2);
+        if (t + 5 * TC < t1) load_weights(Q, t + 5 * TC, t1, w2);
+      }
     }
-    // prefetch the next unit's window + first chunk under nothing (MFMAs above are already issued): keeps one round trip per unit
+    // the next unit's window + weights are requested before this wave idles: one memory round trip per unit
     const int un = u + kSmallWaves;
     if (un < nunits) {
       const int Qn = un / upq;
       if (Qn != curQ) { load_window(Qn); curQ = Qn; staged = false; }
       const int tn = (un % upq) * tpu;
-      load_weights(Qn, tn, min(a.ntaps, tn + tpu), w0);
+      load_unit_head(Qn, tn, min(a.ntaps, tn + tpu));
     }
   }
 
@@ -263,7 +310,6 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   for (int pg = 0; pg < PG; ++pg) red[(wave * PG + pg) * 64 + lane] = acc[pg];
   __syncthreads();
   if (wave != 0) return;
-  const int out_px = a.out_h * a.out_w;
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -271,25 +317,12 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   for (int pg = 0; pg < PG; ++pg) {
     f32x4 s = red[(0 * PG + pg) * 64 + lane];
 #pragma unroll
-    for (int w2 = 1; w2 < kSmallWaves; ++w2) s = s + red[(w2 * PG + pg) * 64 + lane];
+    for (int w2i = 1; w2i < kSmallWaves; ++w2i) s = s + red[(w2i * PG + pg) * 64 + lane];
     if (!inside[pg]) continue;                             // ragged tile: position outside the map
     const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
     const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
     f32x4 v = s * a.w16_inv_scale + bias;
-    if (a.residual) {
-      if (a.res_mode == IN_DIRECT) {
-        v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
-      } else if (a.res_mode == IN_UP2) {
-        const int rw = a.out_w >> 1, rpx = out_px >> 2;
-        v = v + *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
-      } else {
-        const int rw = a.out_w * 2;
-        const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
-        const f32x4 r = ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
-                         (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
-        v = v + r;
-      }
-    }
+    if (a.residual) v = v + (kPrefetchRes ? resv[kPrefetchRes ? pg : 0] : load_residual(pg));
     if (a.act_out) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);

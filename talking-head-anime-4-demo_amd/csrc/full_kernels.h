@@ -541,18 +541,25 @@ struct AffineAddArgs {
 THA4_DEV void instance_norm_from_moments(const FusedInstanceNorm& f, int n, int cw, int c, float& sc, float& sh) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const float* ps = f.stats + ((size_t)n * f.tiles * cw + c) * 2;
+  const float gam = f.gamma[c], bet = f.beta[c];           // requested together with the moments: one memory round trip
   double su = 0.0, sq = 0.0;
-  for (int t = 0; t < f.tiles; ++t) {
-    const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
-    su += (double)v[0];
-    sq += (double)v[1];
+  for (int t0 = 0; t0 < f.tiles; t0 += 8) {                // eight tile loads in flight, added in tile order
+    f32x2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(ps + (size_t)min(t0 + u, f.tiles - 1) * cw * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool keep = t0 + u < f.tiles;
+      su += keep ? (double)v[u][0] : 0.0;
+      sq += keep ? (double)v[u][1] : 0.0;
+    }
   }
   const double mean = su * f.inv_count;
   const double var = sq * f.inv_count - mean * mean;
   const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)f.eps);
-  const double kk = (double)f.gamma[c] * rstd;
+  const double kk = (double)gam * rstd;
   sc = (float)kk;
-  sh = (float)((double)f.beta[c] - mean * kk);
+  sh = (float)((double)bet - mean * kk);
 }
 
 __global__ void __launch_bounds__(256) affine_add_kernel(AffineAddArgs k) {

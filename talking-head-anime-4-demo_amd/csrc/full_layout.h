@@ -277,7 +277,7 @@ inline SmallPlan small_geom(const ConvGeom& g, int tile_h, int tile_w, int pg, i
   t.ok = true;
   return t;
 }
-inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int nb, int nq, int want_wgs = 256) {
+inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int nb, int nq, int max_wgs = 256) {
   SmallPlan best;
   float best_eff = 0.f;
   for (int pg : {4, 2, 1})
@@ -286,7 +286,9 @@ inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int 
       if (t.ok) best_eff = std::max(best_eff, t.efficiency);
     }
   if (best_eff == 0.f) return best;
-  // the largest tile (fewest re-reads of the weights) that still gives every CU a workgroup, else the smallest tile
+  // One workgroup per CU is all this kernel's registers allow, so a grid larger than the chip runs in rounds (288
+  // workgroups cost twice 256): take the tile size that comes closest to `max_wgs` from below; maps that cannot be
+  // covered in one round stay on conv_tile_kernel's two-launch K split (measured: profiles/r02_full_b1_reading.md)
   auto pick = [&](int pg) {
     SmallPlan b;
     for (int twl : {4, 3, 2}) {
@@ -295,12 +297,12 @@ inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int 
     }
     return b;
   };
-  const int want = std::getenv("THA4_SMALL_WANT_WGS") ? std::atoi(std::getenv("THA4_SMALL_WANT_WGS")) : want_wgs;   // tuning aid
-  for (int pg : {4, 2, 1}) {
+  const int cap = std::getenv("THA4_SMALL_MAX_WGS") ? std::atoi(std::getenv("THA4_SMALL_MAX_WGS")) : max_wgs;   // tuning aid
+  for (int pg : {1, 2, 4}) {
     const SmallPlan t = pick(pg);
-    if (!t.ok) continue;
+    if (!t.ok || (long)t.tiles * nb > cap) continue;
     best = t;
-    if ((long)t.tiles * nb >= want) break;
+    break;                                             // pg ascending = workgroup count descending: the first fit is the largest
   }
   if (!best.ok) return best;
   int upq = 1;

@@ -246,8 +246,12 @@ class FullModel {
     SmallPlan sp;
     {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
-      const int max1x1 = std::getenv("THA4_SMALL_1X1_MAX_PX") ? std::atoi(std::getenv("THA4_SMALL_1X1_MAX_PX")) : 64 * 64;
-      const bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
+      // where it wins (per-layer breakdown in profiles/r02_full_b1_reading.md): 3x3 / 1x1 / transposed-conv classes on maps
+      // the tile plan would split over two launches, not the 16-tap stride-2 convolutions (their 108-pixel window per 16
+      // outputs makes staging dominate) and not average-pooled inputs (four dependent samples per staged item)
+      const int max1x1 = std::getenv("THA4_SMALL_1X1_MAX_PX") ? std::atoi(std::getenv("THA4_SMALL_1X1_MAX_PX")) : 32 * 32;
+      bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
+      if (!std::getenv("THA4_SMALL_ALL_KINDS") && (kind == K_S2K4 || in_mode == IN_POOL2)) want = false;
       if (want && !std::getenv("THA4_NO_SMALL_CONV")) {
         sp = plan_small_conv(g0, th, tw, nb, nq);
         small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
@@ -366,7 +370,7 @@ class FullModel {
         c.stats = outc.stats_tiles ? Wk(outc.stats_off) : nullptr;
         c.batch = f.batch;
         if (small) {
-          dispatch_small(pg, in_mode, c, dim3(f.batch * tiles, nb, 1), lds, f.stream);
+          dispatch_small(pg, in_mode, c, dim3(f.batch * tiles * nb, 1, 1), lds, f.stream);
         } else if (splitk) {
           const dim3 grid(f.batch * tiles, mtiles);
           if (in_mode == IN_DIRECT) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_DIRECT>), grid, dim3(256), 16 * 1024, f.stream, c);

@@ -227,7 +227,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     const size_t lds = small ? ((table_bytes + 127) & ~(size_t)127) + sg.lds : tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
     const int phases = tiled && ksplit > 1 ? 2 : 1;
     if (small) {
-      const dim3 sgrid(n * tiles_per_class, nb, 1);
+      const dim3 sgrid(n * tiles_per_class * nb, 1, 1);
 #define RUNS(PGV)                                                                                            \
   if (spg == PGV) {                                                                                          \
     if (in_mode == IN_DIRECT) THA4_RUN((conv_small_kernel<PGV, IN_DIRECT>), sgrid, kSmallThreads, lds, a);   \

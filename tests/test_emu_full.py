@@ -133,6 +133,7 @@ CASES = [
     (0, 3, 1, 21, 1, "silu", 64, 0, False, 8, 8, 32, True, False, False, True, (4, 0)),      # nearest-up x2 on load
     (0, 3, 1, 22, 2, "silu", 64, 0, False, 32, 32, 32, True, False, False, True, (4, 0)),    # avg-pool 2x2 on load
     (0, 3, 1, 24, 0, "relu", 32, 0, False, 20, 20, 16, True, False, True, False, (3, 0)),    # ragged 20x20 in 8x8 tiles, per-channel output activations
+    (0, 1, 1, 21, 0, "none", 64, 0, False, 16, 16, 128, True, False, False, True, (4, 0)),   # 8 output blocks: XCD-aware (block -> XCD) workgroup order
 ]
 
 
@@ -445,22 +446,27 @@ def test_conv_with_fused_norm(lib, case):
 
 
 def test_small_conv_launch_plans(lib):
-    """plan_small_conv over the small-map shapes of the full model: every map tiles, the window fits the staging budget,
-    LDS <= 160 KiB, and few K groups are spread over the waves by tap ranges."""
+    """plan_small_conv over the small-map shapes of the full model: the chosen tile covers the map in ONE round of
+    workgroups (<= 256: one workgroup per CU is all the kernel's registers allow), the window fits the staging budget,
+    LDS <= 160 KiB, few K groups are spread over the waves by tap ranges; shapes that need more than one round are
+    refused (they stay on conv_tile_kernel's K split)."""
     out = (C.c_int * 10)()
-    for (kind, k, th, tw, cin, cout) in [(0, 3, 16, 16, 256, 256), (0, 3, 16, 16, 512, 512), (0, 3, 16, 16, 524, 512), (0, 3, 24, 24, 539, 512),
-                                         (0, 3, 32, 32, 256, 256), (0, 3, 32, 32, 512, 256), (0, 1, 16, 16, 256, 768), (0, 1, 32, 32, 512, 256),
-                                         (1, 4, 16, 16, 256, 512), (1, 4, 24, 24, 256, 512), (1, 4, 32, 32, 128, 256), (1, 4, 64, 64, 64, 128),
-                                         (2, 4, 16, 16, 512, 256), (2, 4, 24, 24, 512, 256), (2, 4, 64, 64, 128, 64), (0, 3, 64, 64, 128, 128),
-                                         (0, 3, 48, 48, 256, 256), (0, 1, 64, 64, 384, 256)]:
+    one_round = [(0, 3, 16, 16, 256, 256), (0, 3, 16, 16, 512, 512), (0, 3, 16, 16, 524, 512), (0, 3, 32, 32, 256, 256), (0, 3, 32, 32, 512, 256),
+                 (0, 1, 16, 16, 256, 768), (0, 1, 16, 16, 256, 256), (0, 1, 32, 32, 512, 256), (2, 4, 16, 16, 512, 256), (2, 4, 24, 24, 512, 256),
+                 (2, 4, 32, 32, 256, 128), (2, 4, 64, 64, 128, 64)]
+    refused = [(0, 3, 24, 24, 539, 512), (0, 3, 64, 64, 128, 128), (0, 3, 48, 48, 256, 256), (2, 4, 96, 96, 128, 64), (2, 4, 48, 48, 256, 128)]
+    for (kind, k, th, tw, cin, cout) in one_round + refused:
         nb = (cout + 15) // 16
         nq = ((cin + 15) // 16 + 1) // 2
         lib.emu_plan_small_conv(kind, k, th, tw, nb, nq, out)
         ok, pg, twl, tile_h, tiles, win_h, win_w, upq, lds, wgs = list(out)
+        if (kind, k, th, tw, cin, cout) in refused:
+            assert not ok, (kind, k, th, tw, cin, cout)
+            continue
         assert ok, (kind, k, th, tw, cin, cout)
         assert pg in (1, 2, 4) and 16 * pg == tile_h << twl
         assert tiles == -(-th // tile_h) * -(-tw // (1 << twl)) and wgs == tiles * nb
         assert win_h * win_w * 4 <= 7 * 64 and lds + 8192 <= 160 * 1024
         ntaps = {0: k * k, 1: 16, 2: 4}[kind]
         assert upq in (1, 2, 4, 8) and upq <= max(1, ntaps) and (nq * upq >= 8 or upq * 2 > ntaps)
-        assert wgs >= 64, (th, tw, cin, cout, wgs)
+        assert 128 <= wgs <= 256, (th, tw, cin, cout, wgs)
