@@ -218,6 +218,28 @@ THA4_DEV void z16_layer(const char*& gw, const float*& scl, char* ring, int& slo
       *reinterpret_cast<f32x4*>(zframe + z_offset(mbase + b, w.lane >> 4, pix0[pg] + p, npix)) = acc[b][pg] * inv;
 }
 
+// The pose-folded first-layer bias of one network, computed by the CONSUMER: pb[c] = (b[c] + sum_k Wpose[k][c] pose[n][k])
+// * scale for the NB*16 channels of network `net` of frame n, into LDS.  Same arithmetic (and summation order) as
+// posebias_kernel, which generation 2 no longer launches: all 45 loads of a channel are independent and go out with the
+// first weight chunk, so the fold costs a barrier instead of a 7 us launch in front of every frame.
+#ifndef THA4_PB_FOLD
+#define THA4_PB_FOLD 1      // 0: A/B build - posebias_kernel is launched and the kernels read its result from HBM as in round 1
+#endif
+constexpr int pb_lds_bytes(int nb) { return nb * 16 * (int)sizeof(float); }
+template <int NB, int THREADS>
+THA4_DEV void pose_bias_to_lds(const StudentDev& d, int net, int n, float* pb) {
+  constexpr int W = NB * 16;
+  if (!THA4_PB_FOLD) return;
+  for (int c = threadIdx.x; c < W; c += THREADS) {
+    const float* wp = d.wpose[net] + c;
+    const float* pose = d.pose + (size_t)n * kPose;
+    float s[3] = {d.bias1[net][c], 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kPose; ++k) s[k % 3] = fmaf(wp[(size_t)k * W], pose[k], s[k % 3]);
+    pb[c] = (s[0] + (s[1] + s[2])) * d.pb_scale;
+  }
+}
+
 template <class G, int NB>
 THA4_DEV void first16_pos(const float* wx, const float* wy, const float* pb, const float (&x)[G::PG], const float (&y)[G::PG],
                           char* act, const WaveCtx& w) {
@@ -322,7 +344,10 @@ __global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
   const float* scl = d.s_face;
   int slot = 0;
   fetch2k<CQ * kNBF, G::WAVES>(gw, ring, w.wave, w.lane);
-  first16_pos<G, kNBF>(d.wx[0], d.wy[0], d.pbias + (size_t)n * kPbStride + kPbFace, px, py, act, w);
+  float* pb = reinterpret_cast<float*>(smem + G::SLOT);     // ring slot 1 is idle until the first streamed layer prefetches into it
+  pose_bias_to_lds<kNBF, G::THREADS>(d, 0, n, pb);
+  if (THA4_PB_FOLD) __syncthreads();
+  first16_pos<G, kNBF>(d.wx[0], d.wy[0], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbFace, px, py, act, w);
   __syncthreads();
 #pragma unroll 1
   for (int l = 0; l < 6; ++l) sine16_layer<G, kNBF, kKGF, 1, CQ, CQ * kNBF>(gw, bias, scl, ring, slot, act, w);
@@ -370,7 +395,10 @@ __global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
   const float* scl = d.s_l0;
   int slot = 0;
   fetch2k<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
-  first16_pos<G, kNB0>(d.wx[1], d.wy[1], d.pbias + (size_t)n * kPbStride + kPbL0, px, py, act, w);
+  float* pb = reinterpret_cast<float*>(smem + G::SLOT);     // ring slot 1 is idle until the first streamed layer prefetches into it
+  pose_bias_to_lds<kNB0, G::THREADS>(d, 1, n, pb);
+  if (THA4_PB_FOLD) __syncthreads();
+  first16_pos<G, kNB0>(d.wx[1], d.wy[1], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL0, px, py, act, w);
   __syncthreads();
   sine16_layer<G, kNB0, kKG0, HBA, 1, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
   sine16_layer<G, kNB1, kKG0, HBA, 1, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
@@ -402,8 +430,10 @@ __global__ void __launch_bounds__(NS* MS * 64) level1_16_kernel(StudentDev d) {
   const float* scl = d.s_l1;
   int slot = 0;
   fetch2k<Cfg::kP1, G::WAVES>(gw, ring, w.wave, w.lane);
-  first16_up<G, kNB1>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, d.wx[2], d.wy[2],
-                      d.pbias + (size_t)n * kPbStride + kPbL1, X0, Y, px, py, act, w);
+  float* pb = reinterpret_cast<float*>(smem + G::SLOT);     // ring slot 1 is idle until the first streamed layer prefetches into it
+  pose_bias_to_lds<kNB1, G::THREADS>(d, 2, n, pb);
+  if (THA4_PB_FOLD) __syncthreads();
+  first16_up<G, kNB1>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, d.wx[2], d.wy[2], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL1, X0, Y, px, py, act, w);
   __syncthreads();
   sine16_layer<G, kNB1, kKG1, 1, CQA, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
   sine16_layer<G, kNB2, kKG1, 1, CQA, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
@@ -476,8 +506,10 @@ __global__ void __launch_bounds__(NS* MS * 64) level2_16_kernel(StudentDev d) {
   const float* scl = d.s_l2;
   int slot = 0;
   fetch2k<CQ * kNB2, G::WAVES>(gw, ring, w.wave, w.lane);
-  first16_up<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
-                      d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, act, w);
+  float* pb = reinterpret_cast<float*>(smem + G::SLOT);     // ring slot 1 is idle until the first streamed layer prefetches into it
+  pose_bias_to_lds<kNB2, G::THREADS>(d, 3, n, pb);
+  if (THA4_PB_FOLD) __syncthreads();
+  first16_up<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py, act, w);
   __syncthreads();
   sine16_layer<G, kNB2, kKG2, 1, CQ, CQ * kNB2>(gw, bias, scl, ring, slot, act, w);
   sine16_layer<G, kNB2, kKG2, 1, CQ, kKG2>(gw, bias, scl, ring, slot, act, w);
@@ -550,11 +582,12 @@ struct Level2PCfg {
   static constexpr int kHidden = kNB2 * kKG2;                         // pieces of one 96->96 layer
   static constexpr int kPieces = 2 * kHidden + kKG2;                  // + head (1 block x 3 groups)
   static constexpr int kWeightBytes = kPieces * 2048;
-  static constexpr int LDS = kWeightBytes + 16;                       // + the strip ticket counter
+  static constexpr int LDS = kWeightBytes + 16;                       // + the strip ticket counter (+ pb_lds_bytes(kNB2) at launch)
   static constexpr int THREADS = WAVES * 64;
   static constexpr int PX = WAVES * PGW * PG * 16;
   using G = Geo16<WAVES, 1, PG, kKG2, 1>;
   static_assert((kImg * kImg) % PX == 0, "a frame must be a whole number of workgroups");
+  static_assert(LDS + 16 * kNB2 * 4 <= 80 * 1024, "two workgroups per CU must still fit");
 };
 
 template <int WAVES, int PGW, int PG>
@@ -570,6 +603,9 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   // strip does not change its bytes.
   int* ticket = reinterpret_cast<int*>(smem + Cfg::kWeightBytes);
   if (threadIdx.x == 0) *ticket = WAVES;                               // strips 0..WAVES-1 are taken statically
+  // a workgroup's strips all belong to one frame (STRIPS is a multiple of PGW * WAVES): its pose-folded bias goes to LDS
+  float* pb = reinterpret_cast<float*>(smem + Cfg::LDS);
+  pose_bias_to_lds<kNB2, WAVES * 64>(d, 3, (xcd_tile(blockIdx.x, gridDim.x) * PGW * WAVES) / STRIPS, pb);
   __syncthreads();
   const char* w1 = smem + w.lane * 16;
   const char* w2 = w1 + (size_t)Cfg::kHidden * 2048;
@@ -591,8 +627,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
       py[pg] = d.pos512[Y[pg]];
     }
     f16x8 xh[kKG2][PG], xl[kKG2][PG];
-    first16_up_to<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3],
-                           d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py,
+    first16_up_to<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py,
                            [&](int pg, int b, const f32x4& v) { put_rows<PG>(xh, xl, pg, b, v); }, w);
     const float* bias = d.b_l2;
 #pragma unroll
@@ -659,6 +694,12 @@ constexpr int kFaceMS = FaceG::MS, kL0MS = L0G::MS, kL1MS = L1G::MS, kL2MS = L2G
 #define THA4_L216_KERNEL v2::level2_16_kernel<THA4_L216_CFG>
 template <class G>
 constexpr int blocks_for(int batch, int side) { return batch * (side * side) / G::PX; }
+// dynamic LDS of each launch.  The streamed kernels park their pose-folded bias vector in ring slot 1 (idle until the first
+// streamed layer prefetches into it); the weights-resident level 2 has no ring and appends it.
+constexpr int kFaceLds = FaceG::LDS, kL0Lds = L0G::LDS, kL1Lds = L1G::LDS, kL2Lds = L2G::LDS, kL2PLds = L2P::LDS + pb_lds_bytes(kNB2);
+static_assert(pb_lds_bytes(kNB0) <= L0G::SLOT && pb_lds_bytes(kNBF) <= FaceG::SLOT && pb_lds_bytes(kNB1) <= L1G::SLOT && pb_lds_bytes(kNB2) <= L2G::SLOT,
+              "the bias vector must fit a ring slot");
+
 }  // namespace cfg
 
 // ---- host packer -------------------------------------------------------------------------------------

@@ -234,11 +234,11 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   if (e == hipSuccess) e = allow_lds(THA4_L0_KERNEL, cfg::L0G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L1_KERNEL, cfg::L1G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L2_KERNEL, cfg::L2G::LDS);
-  if (e == hipSuccess) e = allow_lds(THA4_FACE16_KERNEL, v2::cfg::FaceG::LDS);
-  if (e == hipSuccess) e = allow_lds(THA4_L016_KERNEL, v2::cfg::L0G::LDS);
-  if (e == hipSuccess) e = allow_lds(THA4_L116_KERNEL, v2::cfg::L1G::LDS);
-  if (e == hipSuccess) e = allow_lds(THA4_L216_KERNEL, v2::cfg::L2G::LDS);
-  if (e == hipSuccess) e = allow_lds(THA4_L216P_KERNEL, v2::cfg::L2P::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_FACE16_KERNEL, v2::cfg::kFaceLds);
+  if (e == hipSuccess) e = allow_lds(THA4_L016_KERNEL, v2::cfg::kL0Lds);
+  if (e == hipSuccess) e = allow_lds(THA4_L116_KERNEL, v2::cfg::kL1Lds);
+  if (e == hipSuccess) e = allow_lds(THA4_L216_KERNEL, v2::cfg::kL2Lds);
+  if (e == hipSuccess) e = allow_lds(THA4_L216P_KERNEL, v2::cfg::kL2PLds);
   if (e != hipSuccess) {
     cleanup();
     return fail(THA4_ERR_HIP, std::string("tha4_student_create: ") + hipGetErrorString(e));
@@ -289,7 +289,8 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
 
   const bool t = h->timing && h->ev_valid;
   if (t) HIP_TRY(hipEventRecord(h->ev[0], s));
-  hipLaunchKernelGGL(posebias_kernel, dim3(cfg::posebias_blocks(), batch), dim3(kPoseBiasBlock), 0, s, d);
+  // generation 2 folds the pose bias into each kernel's prologue (pose_bias_to_lds); the exact-fp32 generation keeps the launch
+  if (h->exact_fp32 || !THA4_PB_FOLD) hipLaunchKernelGGL(posebias_kernel, dim3(cfg::posebias_blocks(), batch), dim3(kPoseBiasBlock), 0, s, d);
   if (t) HIP_TRY(hipEventRecord(h->ev[1], s));
   if (h->exact_fp32) {
     hipLaunchKernelGGL((THA4_FACE_KERNEL), dim3(cfg::blocks_for<cfg::FaceG>(batch, 128)), dim3(cfg::FaceG::THREADS),
@@ -305,20 +306,20 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
                        cfg::L2G::LDS, s, d);
   } else {
     hipLaunchKernelGGL((THA4_FACE16_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::FaceG>(batch, 128)), dim3(v2::cfg::FaceG::THREADS),
-                       v2::cfg::FaceG::LDS, s, d);
+                       v2::cfg::kFaceLds, s, d);
     if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
     hipLaunchKernelGGL((THA4_L016_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L0G>(batch, 128)), dim3(v2::cfg::L0G::THREADS),
-                       v2::cfg::L0G::LDS, s, d);
+                       v2::cfg::kL0Lds, s, d);
     if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
     hipLaunchKernelGGL((THA4_L116_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L1G>(batch, 256)), dim3(v2::cfg::L1G::THREADS),
-                       v2::cfg::L1G::LDS, s, d);
+                       v2::cfg::kL1Lds, s, d);
     if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
     if (THA4_L2_RESIDENT)
       hipLaunchKernelGGL((THA4_L216P_KERNEL), dim3(batch * (512 * 512) / v2::cfg::L2P::PX), dim3(v2::cfg::L2P::THREADS),
-                         v2::cfg::L2P::LDS, s, d);
+                         v2::cfg::kL2PLds, s, d);
     else
       hipLaunchKernelGGL((THA4_L216_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L2G>(batch, 512)), dim3(v2::cfg::L2G::THREADS),
-                         v2::cfg::L2G::LDS, s, d);
+                         v2::cfg::kL2Lds, s, d);
   }
   if (t) {
     HIP_TRY(hipEventRecord(h->ev[5], s));

@@ -140,12 +140,12 @@ int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
     for (int b = first_block; b < first_block + nblocks; ++b) {
       switch (kernel) {
         case 0: emu::run_block(posebias_kernel, dim3(grid, 1), dim3(b, 0), kPoseBiasBlock, 0, e->dev); break;
-        case 1: emu::run_block(THA4_FACE16_KERNEL, dim3(grid), dim3(b), v2::cfg::FaceG::THREADS, v2::cfg::FaceG::LDS, e->dev); break;
-        case 2: emu::run_block(THA4_L016_KERNEL, dim3(grid), dim3(b), v2::cfg::L0G::THREADS, v2::cfg::L0G::LDS, e->dev); break;
-        case 3: emu::run_block(THA4_L116_KERNEL, dim3(grid), dim3(b), v2::cfg::L1G::THREADS, v2::cfg::L1G::LDS, e->dev); break;
+        case 1: emu::run_block(THA4_FACE16_KERNEL, dim3(grid), dim3(b), v2::cfg::FaceG::THREADS, v2::cfg::kFaceLds, e->dev); break;
+        case 2: emu::run_block(THA4_L016_KERNEL, dim3(grid), dim3(b), v2::cfg::L0G::THREADS, v2::cfg::kL0Lds, e->dev); break;
+        case 3: emu::run_block(THA4_L116_KERNEL, dim3(grid), dim3(b), v2::cfg::L1G::THREADS, v2::cfg::kL1Lds, e->dev); break;
         case 4:
-          if (THA4_L2_RESIDENT) emu::run_block(THA4_L216P_KERNEL, dim3(grid), dim3(b), v2::cfg::L2P::THREADS, v2::cfg::L2P::LDS, e->dev);
-          else emu::run_block(THA4_L216_KERNEL, dim3(grid), dim3(b), v2::cfg::L2G::THREADS, v2::cfg::L2G::LDS, e->dev);
+          if (THA4_L2_RESIDENT) emu::run_block(THA4_L216P_KERNEL, dim3(grid), dim3(b), v2::cfg::L2P::THREADS, v2::cfg::kL2PLds, e->dev);
+          else emu::run_block(THA4_L216_KERNEL, dim3(grid), dim3(b), v2::cfg::L2G::THREADS, v2::cfg::kL2Lds, e->dev);
           break;
       }
     }
