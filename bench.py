@@ -326,15 +326,20 @@ def student_extras(args, work, dev, world, fps, K, W, B):
             whole += poser.last_kernel_ms(-1)
     poser.set_timing(False)
     kernel_ms = {n: float(acc[k] / nprof) for k, n in enumerate(KERNEL_NAMES)}
-    dom = max(GFLOP_KERNEL, key=lambda n: kernel_ms[n])
-    achieved = GFLOP_KERNEL[dom] * B / kernel_ms[dom]        # GFLOP / ms = TFLOP/s
+    gflop = dict(GFLOP_KERNEL)
+    if kernel_ms["face"] < 0.012 * B:       # face + level 0 share one launch (v2::front16_kernel): event slot 1 is empty, slot 2 is the merged kernel
+        kernel_ms["front (level0 + face, one launch)"] = kernel_ms.pop("level0")
+        gflop["front (level0 + face, one launch)"] = gflop.pop("level0") + gflop.pop("face")
+        kernel_ms["face"] = 0.0
+    dom = max(gflop, key=lambda n: kernel_ms[n])
+    achieved = gflop[dom] * B / kernel_ms[dom]        # GFLOP / ms = TFLOP/s
     prof, prof_file = newest_profile("r*_student_b1_traffic.json")
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_F16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
                 "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
                 "frac_of_split_ceiling": round(achieved * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
                 "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": kernel_traffic_bytes(prof, dom) if B == 1 else None,
+                "traffic": kernel_traffic_bytes(prof, dom.split(" ")[0]) if B == 1 else None,
                 "traffic_unit": f"bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes in {prof_file}",
                 "traffic_per_frame": (sum(kernel_traffic_bytes(prof, n) or 0 for n in KERNEL_NAMES) if (B == 1 and prof) else None),
                 "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},

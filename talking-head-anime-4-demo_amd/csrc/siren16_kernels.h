@@ -329,11 +329,9 @@ struct Face16Cfg {
 };
 
 template <int NS, int MS, int PG, int CQ>
-__global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
+THA4_DEV void face16_body(const StudentDev& d, char* smem, const WaveCtx& w) {
   using G = typename Face16Cfg<NS, MS, PG, CQ>::G;
   constexpr int S = kFaceSize, NPIX = S * S;
-  THA4_DYN_LDS(smem);
-  const WaveCtx w = wave_ctx<G>();
   char* ring = smem;
   char* act = smem + 2 * G::SLOT + w.ns * G::ACT_BYTES;
   int pix0[PG], X0[PG], Y[PG];
@@ -356,7 +354,7 @@ __global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
   zero_acc<1, PG>(a1);
   // head: ONE block; only row-split 0 computes, its piece is the first of every group (MS folded: NB = 1)
   gemm16_stream<Geo16<NS, 1, PG, kKGF, Face16Cfg<NS, MS, PG, CQ>::kSlotPieces>, 1, 1, kKGF, 1, kKGF, 0>(gw, ring, slot, act, a1,
-                                                                                                   WaveCtx{w.lane, w.wave, w.ns, 0}, w.ms == 0);
+                                                                                                   WaveCtx{w.lane, w.wave, w.ns, 0, w.blk, w.nblk}, w.ms == 0);
   if (w.ms == 0 && w.lane < 16) {
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias);
     const float inv = *scl;
@@ -370,6 +368,12 @@ __global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
   }
 }
 
+template <int NS, int MS, int PG, int CQ>
+__global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
+  THA4_DYN_LDS(smem);
+  face16_body<NS, MS, PG, CQ>(d, smem, wave_ctx<typename Face16Cfg<NS, MS, PG, CQ>::G>());
+}
+
 // ---- level 0 ----------------------------------------------------------------------------------------
 template <int NS, int MS, int PG, int HBA, int CQB>
 struct Level016Cfg {   // HBA: block slices per group of the 24/12-block layers; CQB: groups per chunk of the z layer
@@ -379,12 +383,10 @@ struct Level016Cfg {   // HBA: block slices per group of the 24/12-block layers;
 };
 
 template <int NS, int MS, int PG, int HBA, int CQB>
-__global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
+THA4_DEV void level0_16_body(const StudentDev& d, char* smem, const WaveCtx& w) {
   using Cfg = Level016Cfg<NS, MS, PG, HBA, CQB>;
   using G = typename Cfg::G;
   constexpr int S = 128, NPIX = S * S;
-  THA4_DYN_LDS(smem);
-  const WaveCtx w = wave_ctx<G>();
   char* ring = smem;
   char* act = smem + 2 * G::SLOT + w.ns * G::ACT_BYTES;
   int pix0[PG], X0[PG], Y[PG];
@@ -403,6 +405,33 @@ __global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
   sine16_layer<G, kNB0, kKG0, HBA, 1, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
   sine16_layer<G, kNB1, kKG0, HBA, 1, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
   z16_layer<G, kNB1, kKG1, 1, CQB>(gw, scl, ring, slot, act, d.z1 + (size_t)n * kNB1 * NPIX * 16, NPIX, pix0, w);
+}
+
+template <int NS, int MS, int PG, int HBA, int CQB>
+__global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
+  THA4_DYN_LDS(smem);
+  level0_16_body<NS, MS, PG, HBA, CQB>(d, smem, wave_ctx<typename Level016Cfg<NS, MS, PG, HBA, CQB>::G>());
+}
+
+// Face morpher and body level 0 in ONE launch: the face output is only needed by level 2's warp, so the two kernels are
+// independent.  Level-0 workgroups come first (they are the longer ones); as each of them retires its CU picks up a
+// face workgroup, instead of the whole chip draining at a kernel boundary first.  `d.front_l0_blocks` = level-0
+// workgroups of this launch; both bodies use the same 512-thread geometry.
+template <int FNS, int FMS, int FPG, int FCQ, int NS, int MS, int PG, int HBA, int CQB>
+__global__ void __launch_bounds__(NS* MS * 64) front16_kernel(StudentDev d) {
+  static_assert(FNS * FMS == NS * MS, "face and level 0 must use the same workgroup size");
+  THA4_DYN_LDS(smem);
+  const int nl0 = d.front_l0_blocks;
+  if ((int)blockIdx.x < nl0) {
+    WaveCtx w = wave_ctx<typename Level016Cfg<NS, MS, PG, HBA, CQB>::G>();
+    w.nblk = nl0;
+    level0_16_body<NS, MS, PG, HBA, CQB>(d, smem, w);
+  } else {
+    WaveCtx w = wave_ctx<typename Face16Cfg<FNS, FMS, FPG, FCQ>::G>();
+    w.blk = blockIdx.x - nl0;
+    w.nblk = gridDim.x - nl0;
+    face16_body<FNS, FMS, FPG, FCQ>(d, smem, w);
+  }
 }
 
 // ---- level 1 ----------------------------------------------------------------------------------------
@@ -689,6 +718,10 @@ using L2G = Level216Cfg<THA4_L216_CFG>::G;
 constexpr int kL0HBA = Level016Cfg<THA4_L016_CFG>::kP1 == kNB0 ? 1 : kNB0 / Level016Cfg<THA4_L016_CFG>::kP1;
 constexpr int kFaceMS = FaceG::MS, kL0MS = L0G::MS, kL1MS = L1G::MS, kL2MS = L2G::MS;
 #define THA4_FACE16_KERNEL v2::face16_kernel<THA4_FACE16_CFG>
+#define THA4_FRONT16_KERNEL v2::front16_kernel<THA4_FACE16_CFG, THA4_L016_CFG>
+#ifndef THA4_FRONT_MERGE
+#define THA4_FRONT_MERGE 1                  // 1: face + level 0 share one launch (front16_kernel); 0: two launches (A/B)
+#endif
 #define THA4_L016_KERNEL v2::level0_16_kernel<THA4_L016_CFG>
 #define THA4_L116_KERNEL v2::level1_16_kernel<THA4_L116_CFG>
 #define THA4_L216_KERNEL v2::level2_16_kernel<THA4_L216_CFG>
@@ -696,6 +729,7 @@ template <class G>
 constexpr int blocks_for(int batch, int side) { return batch * (side * side) / G::PX; }
 // dynamic LDS of each launch.  The streamed kernels park their pose-folded bias vector in ring slot 1 (idle until the first
 // streamed layer prefetches into it); the weights-resident level 2 has no ring and appends it.
+constexpr int kFrontLds = FaceG::LDS > L0G::LDS ? FaceG::LDS : L0G::LDS;
 constexpr int kFaceLds = FaceG::LDS, kL0Lds = L0G::LDS, kL1Lds = L1G::LDS, kL2Lds = L2G::LDS, kL2PLds = L2P::LDS + pb_lds_bytes(kNB2);
 static_assert(pb_lds_bytes(kNB0) <= L0G::SLOT && pb_lds_bytes(kNBF) <= FaceG::SLOT && pb_lds_bytes(kNB1) <= L1G::SLOT && pb_lds_bytes(kNB2) <= L2G::SLOT,
               "the bias vector must fit a ring slot");

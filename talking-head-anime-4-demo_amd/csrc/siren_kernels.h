@@ -38,6 +38,7 @@ struct StudentDev {
   const float *pos128, *pos256, *pos512;             // affine_grid axes
   // workspace (device)
   float* pbias;   // [B][kPbStride]
+  int front_l0_blocks;   // v2::front16_kernel: level-0 workgroups at the head of the merged face + level-0 grid
   float* z1;      // [B][kNB1][4][128*128][4]   (z_offset, siren_layout.h)
   float* z2;      // [B][kNB2][4][256*256][4]
   float* face;    // [B][4][128][128]
@@ -127,6 +128,8 @@ struct Geo {
 
 struct WaveCtx {
   int lane, wave, ns, ms;   // ns: pixel slot, ms: row split
+  int blk, nblk;            // this workgroup's index in its kernel's tile sequence (blockIdx.x / gridDim.x unless several
+                            // kernels share one launch: v2::front16_kernel)
 };
 
 template <class G>
@@ -136,6 +139,8 @@ THA4_DEV WaveCtx wave_ctx() {
   c.wave = uniform_i32(threadIdx.x >> 6);
   c.ns = c.wave % G::NS;
   c.ms = G::MS == 1 ? 0 : c.wave / G::NS;   // compile-time 0 keeps block indices static when rows are not split
+  c.blk = blockIdx.x;
+  c.nblk = gridDim.x;
   return c;
 }
 
@@ -368,7 +373,7 @@ THA4_DEV int slot_pixels(const WaveCtx& w, const float* axis, int (&pix0)[G::PG]
                          float (&px)[G::PG], float (&py)[G::PG]) {
   constexpr int PGS = S * S / 16;
   static_assert(PGS % (G::NS * G::PG) == 0, "a workgroup must not straddle frames");
-  const int pg_first = (xcd_tile(blockIdx.x, gridDim.x) * G::NS + w.ns) * G::PG;
+  const int pg_first = (xcd_tile(w.blk, w.nblk) * G::NS + w.ns) * G::PG;
 #pragma unroll
   for (int pg = 0; pg < G::PG; ++pg) {
     pix0[pg] = ((pg_first + pg) % PGS) * 16;

@@ -234,6 +234,7 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   if (e == hipSuccess) e = allow_lds(THA4_L0_KERNEL, cfg::L0G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L1_KERNEL, cfg::L1G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L2_KERNEL, cfg::L2G::LDS);
+  if (e == hipSuccess) e = allow_lds(THA4_FRONT16_KERNEL, v2::cfg::kFrontLds);
   if (e == hipSuccess) e = allow_lds(THA4_FACE16_KERNEL, v2::cfg::kFaceLds);
   if (e == hipSuccess) e = allow_lds(THA4_L016_KERNEL, v2::cfg::kL0Lds);
   if (e == hipSuccess) e = allow_lds(THA4_L116_KERNEL, v2::cfg::kL1Lds);
@@ -305,11 +306,19 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
     hipLaunchKernelGGL((THA4_L2_KERNEL), dim3(cfg::blocks_for<cfg::L2G>(batch, 512)), dim3(cfg::L2G::THREADS),
                        cfg::L2G::LDS, s, d);
   } else {
-    hipLaunchKernelGGL((THA4_FACE16_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::FaceG>(batch, 128)), dim3(v2::cfg::FaceG::THREADS),
-                       v2::cfg::kFaceLds, s, d);
-    if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
-    hipLaunchKernelGGL((THA4_L016_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L0G>(batch, 128)), dim3(v2::cfg::L0G::THREADS),
-                       v2::cfg::kL0Lds, s, d);
+    if (THA4_FRONT_MERGE) {
+      // face + level 0 in one launch (front16_kernel): timing slot 1 (face) is empty, slot 2 holds the merged kernel
+      if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
+      d.front_l0_blocks = v2::cfg::blocks_for<v2::cfg::L0G>(batch, 128);
+      hipLaunchKernelGGL((THA4_FRONT16_KERNEL), dim3(d.front_l0_blocks + v2::cfg::blocks_for<v2::cfg::FaceG>(batch, 128)),
+                         dim3(v2::cfg::L0G::THREADS), v2::cfg::kFrontLds, s, d);
+    } else {
+      hipLaunchKernelGGL((THA4_FACE16_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::FaceG>(batch, 128)), dim3(v2::cfg::FaceG::THREADS),
+                         v2::cfg::kFaceLds, s, d);
+      if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
+      hipLaunchKernelGGL((THA4_L016_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L0G>(batch, 128)), dim3(v2::cfg::L0G::THREADS),
+                         v2::cfg::kL0Lds, s, d);
+    }
     if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
     hipLaunchKernelGGL((THA4_L116_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L1G>(batch, 256)), dim3(v2::cfg::L1G::THREADS),
                        v2::cfg::kL1Lds, s, d);

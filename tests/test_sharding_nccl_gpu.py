@@ -1,0 +1,73 @@
+"""N>1 path on real GPUs (needs >= 2 devices; skipped on the 1-GPU box): two ranks over RCCL ("nccl" backend) pose a
+sharded stream with the REAL student poser, gather fp32 and RGBA8 frames to rank 0 on the side stream, and rank 0
+checks that every frame's bytes equal its own single-GPU evaluation - a frame does not depend on the GPU that made it
+(SURVEY.md §4(v), §8e)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _worker(rank, world, port, total, chunk, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import tha4_amd  # noqa: F401
+    from tha4_amd import image_io
+    from tha4_amd.poser.modes import mode_14
+    from tha4_amd.sharding import FrameShardedStream
+    from tha4_amd.weights import split_flat_weights
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    w = dict(np.load(os.path.join(GOLDEN, "student_lambda_00_weights.npz")))
+    io = np.load(os.path.join(GOLDEN, "student_lambda_00_io.npz"))
+    poser = mode_14.create_poser_from_state_dicts(dev, *split_flat_weights(w), max_batch=4)
+    image = torch.from_numpy(io["image_f32"]).to(dev)
+    poses = torch.from_numpy(np.resize(io["poses"], (total, 45))).to(dev)
+
+    def frames(lo, hi):
+        blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+        for i in range(lo, hi):
+            poser.pose(image, poses[i], out=blk[i - lo:i - lo + 1])
+        return blk
+
+    ok = True
+    with torch.no_grad():
+        full = FrameShardedStream(frames, total, (4, 512, 512), torch.float32, dev, chunk=chunk, gather=True).run()
+        rgba = FrameShardedStream(lambda lo, hi: image_io.to_display_rgba8(frames(lo, hi)), total, (512, 512, 4), torch.uint8, dev,
+                                  chunk=chunk, gather=True).run()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            mine = frames(0, total)
+            ok = bool(torch.equal(full, mine)) and bool(torch.equal(rgba, image_io.to_display_rgba8(mine)))
+        else:
+            ok = full is None and rgba is None
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the 8-GPU node); the gloo tests cover the logic on CPU")
+@pytest.mark.parametrize("total,chunk", [(10, 4), (5, 8)])
+def test_two_rank_rccl_gather_real_poser(total, chunk):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
