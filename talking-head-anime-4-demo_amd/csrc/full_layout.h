@@ -202,7 +202,9 @@ struct TilePlan {
   int pg = 1, ksplit = 1;
   TileGeom geom;
 };
-inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TMB, int mtiles, int nq, int want_wgs = 256) {
+// `frames`: frames per call the schedule is built for (max_batch): every frame brings its own tiles, so a batched call fills
+// the chip without a K split where a single frame needs one
+inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TMB, int mtiles, int nq, int want_wgs = 256, int frames = 1) {
   TilePlan best;
   if (std::getenv("THA4_WANT_WGS")) want_wgs = std::atoi(std::getenv("THA4_WANT_WGS"));   // tuning aid
   const int kmax = std::getenv("THA4_KSPLIT_MAX") ? std::atoi(std::getenv("THA4_KSPLIT_MAX")) : 16;   // tuning aid
@@ -223,16 +225,17 @@ inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TM
     }
     return false;
   };
+  const long F = frames < 1 ? 1 : frames;
   for (int pg : {4, 2, 1})
-    if (pick(pg) && best.geom.tiles * mtiles >= want_wgs) return best;
-  if (pick(1) && best.geom.tiles * mtiles >= want_wgs / 2) return best;
-  if (pick(2) && best.geom.tiles * mtiles >= want_wgs / 2) return best;
+    if (pick(pg) && best.geom.tiles * mtiles * F >= want_wgs) return best;
+  if (pick(1) && best.geom.tiles * mtiles * F >= want_wgs / 2) return best;
+  if (pick(2) && best.geom.tiles * mtiles * F >= want_wgs / 2) return best;
   // 2) small maps: the largest tile whose K groups can still be spread over the chip
   best.ok = false;
   for (int pg : {2, 1})            // K split is compiled out of the PG = 4 kernel
-    if (pick(pg) && (long)best.geom.tiles * mtiles * std::min(nq, kmax) >= want_wgs) break;
+    if (pick(pg) && (long)best.geom.tiles * mtiles * F * std::min(nq, kmax) >= want_wgs) break;
   if (!best.ok) return best;
-  const int wgs = best.geom.tiles * mtiles;
+  const int wgs = (int)(best.geom.tiles * mtiles * F);
   int ksplit = 1;
   if (wgs < want_wgs / 2 && nq >= min_nq && best.pg < 4) {
     const int want = std::min(std::min(nq, kmax), (want_wgs + wgs - 1) / wgs);
@@ -277,7 +280,7 @@ inline SmallPlan small_geom(const ConvGeom& g, int tile_h, int tile_w, int pg, i
   t.ok = true;
   return t;
 }
-inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int nb, int nq, int max_wgs = 256) {
+inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int nb, int nq, int max_wgs = 256, int frames = 1) {
   SmallPlan best;
   float best_eff = 0.f;
   for (int pg : {4, 2, 1})
@@ -300,7 +303,7 @@ inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int 
   const int cap = std::getenv("THA4_SMALL_MAX_WGS") ? std::atoi(std::getenv("THA4_SMALL_MAX_WGS")) : max_wgs;   // tuning aid
   for (int pg : {1, 2, 4}) {
     const SmallPlan t = pick(pg);
-    if (!t.ok || (long)t.tiles * nb > cap) continue;
+    if (!t.ok || (long)t.tiles * nb * (frames < 1 ? 1 : frames) > cap) continue;
     best = t;
     break;                                             // pg ascending = workgroup count descending: the first fit is the largest
   }

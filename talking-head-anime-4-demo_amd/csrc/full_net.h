@@ -229,12 +229,12 @@ class FullModel {
     const size_t table_bytes = fpend ? (size_t)2 * ctab * sizeof(float) : 0;
     if ((kind != K_SAME1 || std::getenv("THA4_TILE_1X1")) && !std::getenv("THA4_NO_TILE_CONV")) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
-      plan = plan_tile_conv(g0, th, tw, tmb, mtiles, nq);
+      plan = plan_tile_conv(g0, th, tw, tmb, mtiles, nq, 256, max_batch);
       if (plan.ok && table_bytes && !tile_geom(g0, th, tw, plan.pg, tmb, plan.geom.tw_log2, table_bytes).ok) plan.ok = false;
       // a half-filled chip without K split: halve the output tile instead (the window is staged twice as often, but
       // no partial-sum traffic and no second launch)
-      if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles < 200) {
-        const TilePlan p2 = plan_tile_conv(g0, th, tw, 2, mtiles * 2, nq);
+      if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles * max_batch < 200) {
+        const TilePlan p2 = plan_tile_conv(g0, th, tw, 2, mtiles * 2, nq, 256, max_batch);
         if (p2.ok && p2.ksplit == 1 && p2.pg >= plan.pg) { plan = p2; tmb = 2; mtiles *= 2; }
       }
       tiled = plan.ok;
@@ -253,7 +253,13 @@ class FullModel {
       bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
       if (!std::getenv("THA4_SMALL_ALL_KINDS") && (kind == K_S2K4 || in_mode == IN_POOL2)) want = false;
       if (want && !std::getenv("THA4_NO_SMALL_CONV")) {
-        sp = plan_small_conv(g0, th, tw, nb, nq);
+        sp = plan_small_conv(g0, th, tw, nb, nq, 256, max_batch);
+        small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
+      }
+      if (!small && fpend && !tiled && !std::getenv("THA4_NO_SMALL_CONV")) {
+        // a folded normalisation needs one of the two kernels that can evaluate it: take conv_small_kernel even if its grid
+        // runs in several rounds (1x1 projections behind a GroupNorm when the schedule is built for 2 frames)
+        sp = plan_small_conv(g0, th, tw, nb, nq, 1 << 30, max_batch);
         small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
       }
       if (small) { tiled = false; tmb = 1; mtiles = nb; }
@@ -404,7 +410,10 @@ class FullModel {
     int total_tiles = 0;
     for (auto& t : srcs) total_tiles += t.stats_tiles;
     const int fuse_max = std::getenv("THA4_FUSED_NORM_MAX_TILES") ? std::atoi(std::getenv("THA4_FUSED_NORM_MAX_TILES")) : 64;
-    if (total_tiles <= fuse_max && srcs.size() <= 2 && !std::getenv("THA4_NO_SMALL_CONV") && !std::getenv("THA4_NO_TILE_CONV")) {
+    // (a batched call multiplies the consumers' workgroups, each of which would redo the reduction, while one finalize launch
+    // serves all frames: fusing pays for max_batch <= 2 only - measured, profiles/r02_full_b1_reading.md)
+    const int fuse_batch = std::getenv("THA4_FUSED_NORM_MAX_BATCH") ? std::atoi(std::getenv("THA4_FUSED_NORM_MAX_BATCH")) : 2;
+    if (total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !std::getenv("THA4_NO_SMALL_CONV") && !std::getenv("THA4_NO_TILE_CONV")) {
       Pending p;
       p.fused = true;
       for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].stats_off; p.tiles[i] = srcs[i].stats_tiles; }

@@ -252,7 +252,9 @@ def test_mode_12_three_network_poser(poser, weights, full_io, golden_io):
     entries 11..32 of the mode_07 list, computed by the same schedule."""
     from tha4_amd.poser.modes import mode_12
     dev = torch.device("cuda:0")
-    p12 = mode_12.create_poser_from_state_dicts(dev, weights, max_batch=2)
+    # same max_batch as `poser`: the launch plan (K split, fused norms, conv_small) is chosen for the batch the handle is
+    # created for, and bitwise equality between two handles holds for equal plans only
+    p12 = mode_12.create_poser_from_state_dicts(dev, weights, max_batch=4)
     assert p12.get_output_length() == 18 and p12.get_num_parameters() == 45
     image = torch.from_numpy(golden_io["image_f32"]).to(dev)
     poses = torch.from_numpy(full_io["poses"][:2]).to(dev)
