@@ -233,9 +233,11 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   auto activate = [&](const f32x4& r, const QuadCtx& c) -> f32x4 { return apply_act4(r, c.sc, c.sh, c.act); };
   // raw (IN_DIRECT / IN_UP2) or finished (IN_POOL2: the 2x2 mean of the activated samples) values of one item
   auto load_quad = [&](const QuadCtx& c, int o) -> f32x4 {
-    if (!c.base || o < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!c.base) return f32x4{0.f, 0.f, 0.f, 0.f};          // wave-uniform: phantom quad
     if (c.kind == SRC_VECTOR) return *reinterpret_cast<const f32x4*>(c.base + sg * 16);
-    const float* ptr = reinterpret_cast<const float*>(c.base + (unsigned)o);
+    // padding items (o < 0) read pixel 0 instead of branching per lane: their value is discarded by write_window, and ten
+    // divergent branches per K group cost more than ten redundant loads
+    const float* ptr = reinterpret_cast<const float*>(c.base + (unsigned)max(o, 0));
     if (!kPool) return *reinterpret_cast<const f32x4*>(ptr);
     const f32x4 v00 = activate(*reinterpret_cast<const f32x4*>(ptr), c);
     const f32x4 v01 = activate(*reinterpret_cast<const f32x4*>(ptr + 16), c);
@@ -261,13 +263,17 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       const int item = tid + k * kTileThreads;
       if (item >= nitems) continue;
       f32x4 va = rawA[k], vb = rawB[k];
-      if (gofs.v[k] < 0) {                                 // zero padding is applied AFTER normalisation + activation
-        va = f32x4{0.f, 0.f, 0.f, 0.f};
-        vb = va;
-      } else if (!kPool) {
+      if (!kPool) {                                        // (wave-uniform conditions only: no per-lane branch)
         if (cA.base) va = activate(va, cA);
         if (cB.base) vb = activate(vb, cB);
       }
+      const float keep = gofs.v[k] < 0 ? 0.0f : 1.0f;      // zero padding is applied AFTER normalisation + activation
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        va[j] = gofs.v[k] < 0 ? 0.0f : va[j];
+        vb[j] = gofs.v[k] < 0 ? 0.0f : vb[j];
+      }
+      (void)keep;
       f16x8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -37,7 +37,18 @@ def poser(weights):
     return p
 
 
-def test_all_33_outputs_vs_reference_fixture(poser, full_io, golden_io):
+@pytest.fixture(scope="module")
+def poser1(weights):
+    """The batch-1 launch plan (what configs[2] and the GUI use): conv_small_kernel on the small maps, normalisations folded
+    into their consumers.  `poser` (max_batch 4) runs the batched plan: K split over two launches, norm_finalize launches."""
+    p = mode_07.create_poser_from_state_dicts(torch.device("cuda:0"), weights, max_batch=1)
+    p.get_modules()
+    return p
+
+
+@pytest.mark.parametrize("plan", ["batch1", "batch4"])
+def test_all_33_outputs_vs_reference_fixture(plan, poser, poser1, full_io, golden_io):
+    poser = poser1 if plan == "batch1" else poser
     dev = torch.device("cuda:0")
     image = torch.from_numpy(golden_io["image_f32"]).to(dev)
     report = []
@@ -51,7 +62,7 @@ def test_all_33_outputs_vs_reference_fixture(poser, full_io, golden_io):
             report.append((i, fo.OUTPUT_NAMES[k], err))
     bad = [r for r in report if r[2] > TOL]
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/full_parity_report.txt", "w") as fh:
+    with open(f"gpurun_out/full_parity_report_{plan}.txt", "w") as fh:
         fh.write("\n".join(f"pose {i} {n:20s} {e:.3e}" for i, n, e in report) + "\n")
     assert not bad, bad
     out0 = poser.pose(image, torch.from_numpy(full_io["poses"][0]).to(dev))[0].cpu().numpy()
@@ -129,7 +140,8 @@ def test_dense_batch_distinct_images_vs_reference_fixture(poser, golden_io):
         assert torch.equal(sub[j], outs[k])
 
 
-def test_all_33_outputs_full_frame_vs_oracle(poser, weights, full_io, golden_io):
+def test_all_33_outputs_full_frame_vs_oracle(poser1, weights, full_io, golden_io):
+    poser = poser1
     """Every pixel of every output (not a pixel subset) for one pose, against the CPU oracle (pinned to the reference
     by tests/test_full_oracle_golden.py) evaluated on this machine."""
     dev = torch.device("cuda:0")
@@ -175,7 +187,8 @@ def test_adversarial_range_weights(golden_io):
     p.free()
 
 
-def test_decomposer_cache_semantics(poser, full_io, golden_io):
+def test_decomposer_cache_semantics(poser1, full_io, golden_io):
+    poser = poser1
     """Reuse is decided by storage identity + version with a strong reference held (never by a raw address that the
     allocator may recycle), or by an explicit image_version (SURVEY.md §8b); the reference decides by content
     (mode_07.py:56-61).  Every path must give the result of a cold evaluation of the image actually passed."""
@@ -229,7 +242,8 @@ def test_full_device_mismatch_raises_like_the_reference(poser, full_io, golden_i
         poser.get_posing_outputs(torch.from_numpy(golden_io["image_f32"]).to(dev), torch.from_numpy(full_io["poses"][0]).to(dev), indices=(33,))
 
 
-def test_full_stream_switch_is_ordered(poser, full_io, golden_io):
+def test_full_stream_switch_is_ordered(poser1, full_io, golden_io):
+    poser = poser1
     """One workspace per handle: a call on another stream waits (event) for the previous stream's work."""
     dev = torch.device("cuda:0")
     image = torch.from_numpy(golden_io["image_f32"]).to(dev)
