@@ -50,15 +50,28 @@ def main():
                 ks[short] = {"fetch_kib": round(sum(fe[k]) / len(fe[k]), 2), "write_kib": round(sum(wr[k]) / len(wr[k]), 2), "launches": len(fe[k])}
         out["kernels"] = ks
     else:
-        def frame_bytes(fe, wr, frames):
-            return int(round(sum(2.0 * sum(v) for v in fe.values()) * 1024 / frames + sum(sum(v) for v in wr.values()) * 1024 / frames))
-        out["steady_frame_bytes"] = frame_bytes(fe, wr, a.frames)
-        out["steady_frames"] = a.frames
-        out["kernels"] = {k: {"fetch_kib": round(sum(v) / len(v), 2), "write_kib": round(sum(wr[k]) / max(1, len(wr[k])), 2), "launches_per_frame": round(len(v) / a.frames, 2)}
+        def total_bytes(fe, wr):
+            return sum(2.0 * sum(v) for v in fe.values()) * 1024 + sum(sum(v) for v in wr.values()) * 1024
+        # tools/time_full.py runs 3 warm-up frames (1 cold + 2 steady) before the timed ones, so a "--mode steady --frames F"
+        # capture holds F+2 steady + 1 cold frames and a "--mode cold" capture 2 steady + F+1 cold: two equations, two unknowns
+        S = total_bytes(fe, wr)
+        F = a.frames
+        out["captured"] = {"steady_run": f"{F + 2} steady + 1 cold frames", "steady_run_bytes": int(S)}
+        out["kernels"] = {k: {"fetch_kib": round(sum(v) / len(v), 2), "write_kib": round(sum(wr[k]) / max(1, len(wr[k])), 2), "launches_per_frame": round(len(v) / (F + 3), 2)}
                           for k, v in sorted(fe.items(), key=lambda kv: -sum(kv[1]))}
         if a.cold_fetch:
-            out["cold_frame_bytes"] = frame_bytes(per_kernel(a.cold_fetch, "FETCH_SIZE"), per_kernel(a.cold_write, "WRITE_SIZE"), a.cold_frames)
-            out["cold_frames"] = a.cold_frames
+            Cb = total_bytes(per_kernel(a.cold_fetch, "FETCH_SIZE"), per_kernel(a.cold_write, "WRITE_SIZE"))
+            Fc = a.cold_frames
+            out["captured"]["cold_run"] = f"2 steady + {Fc + 1} cold frames"
+            out["captured"]["cold_run_bytes"] = int(Cb)
+            # (F+2) s + c = S ; 2 s + (Fc+1) c = Cb
+            det = (F + 2) * (Fc + 1) - 2.0
+            s_ = (S * (Fc + 1) - Cb) / det
+            c_ = ((F + 2) * Cb - 2.0 * S) / det
+            out["steady_frame_bytes"] = int(round(s_))
+            out["cold_frame_bytes"] = int(round(c_))
+        else:
+            out["steady_frame_bytes"] = int(round(S / (F + 3)))
     with open(a.o, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1)[:1500])
