@@ -293,6 +293,10 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   for (int b = 0; b < TMB; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // LDS offset of tap t inside the window, kept in lane t of one VGPR: the MFMA loop picks it with v_readlane instead of two
+  // scalar loads from the argument block and an s_waitcnt lgkmcnt(0) (which also drains the LDS reads in flight) per tap
+  const int tl = lane & (kMaxTaps - 1);
+  const int my_toff = ((a.tap_dy[tl] - a.win_dy0) * WW + (a.tap_dx[tl] - a.win_dx0)) * 16;
 
 #if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
   long long* stamps = (a.dbg && a.phase != 2 && blockIdx.z == 0) ? a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTileWaves + wave) * 64 : nullptr;
@@ -333,7 +337,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       const char* wsl = ring + slot * slot_bytes + lane * 16;
       for (int tt = 0; tt < a.taps_per_chunk; ++tt) {
         const int t = tc * a.taps_per_chunk + tt;
-        const int toff = ((a.tap_dy[t] - a.win_dy0) * WW + (a.tap_dx[t] - a.win_dx0)) * 16;
+        const int toff = lane_pick(my_toff, t);
         f16x8 bh[PG], bl[PG];
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) {

@@ -209,12 +209,14 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   f32x4 acc[PG];
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) acc[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tapl = lane & (kMaxTaps - 1);                  // tap offsets in lane t of one VGPR (see conv_tile_kernel)
+  const int my_toff = ((a.tap_dy[tapl] - a.win_dy0) * WW + (a.tap_dx[tapl] - a.win_dx0)) * 16;
   auto mac_chunk = [&](int t0, int t1, const WChunk& w) {
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
       const int t = t0 + i;
       if (t >= t1) break;
-      const int toff = ((a.tap_dy[t] - a.win_dy0) * WW + (a.tap_dx[t] - a.win_dx0)) * 16;
+      const int toff = lane_pick(my_toff, t);
 #pragma unroll
       for (int pg = 0; pg < PG; ++pg) {
         const f16x8 bh = *reinterpret_cast<const f16x8*>(win_hi + boff[pg] + toff);

@@ -65,6 +65,9 @@ THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 THA4_DEV float lane_read(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+// value held by lane `src_lane` (wave-uniform index) as a scalar: v_readlane_b32 - a per-tap table kept in one VGPR
+// (lane t holds entry t) replaces a scalar memory load + s_waitcnt lgkmcnt(0) inside the MFMA loops
+THA4_DEV int lane_pick(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 #else
 THA4_DEV void glds16(const void* gsrc_lane, void* lds_base_uniform) { emu::glds16(gsrc_lane, lds_base_uniform); }
 THA4_DEV f32x4 mfma16(float a, float b, f32x4 c) {
@@ -86,6 +89,7 @@ THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {      // fibers run o
   return (int)emu::shfl(v, 0);                                   // tickets are small integers: exact in fp32
 }
 THA4_DEV float lane_read(float v, int src_lane) { return emu::shfl(v, src_lane); }
+THA4_DEV int lane_pick(int v, int src_lane) { return (int)emu::shfl((float)v, src_lane); }       // |v| < 2^24: exact in fp32
 #endif
 
 }  // namespace tha4
