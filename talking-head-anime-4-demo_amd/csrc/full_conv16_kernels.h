@@ -344,16 +344,38 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
           bh[pg] = *reinterpret_cast<const f16x8*>(win_hi + boff[pg] + toff);
           bl[pg] = *reinterpret_cast<const f16x8*>(win_lo + boff[pg] + toff);
         }
+        if (TMB == 4) {
+          // all A fragments of the tap are requested together with the B fragments: one LDS wait per tap instead of one per
+          // output block (the compiler otherwise reuses one register pair and waits lgkmcnt(0) before every block).  Only for
+          // the four-block tiles: with two blocks the extra registers cost the <2,4> kernels their third wave per SIMD
+          f16x8 ah[TMB], al[TMB];
 #pragma unroll
-        for (int b = 0; b < TMB; ++b) {
-          const f16x8 ah = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
-          const f16x8 al = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
+          for (int b = 0; b < TMB; ++b) {
+            ah[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
+            al[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
+          }
+          THA4_SCHED_FENCE();
 #pragma unroll
-          for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah, bh[pg], acc[b][pg]);
+          for (int b = 0; b < TMB; ++b) {
 #pragma unroll
-          for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah, bl[pg], acc[b][pg]);
+            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah[b], bh[pg], acc[b][pg]);
 #pragma unroll
-          for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(al, bh[pg], acc[b][pg]);
+            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah[b], bl[pg], acc[b][pg]);
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(al[b], bh[pg], acc[b][pg]);
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < TMB; ++b) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah, bh[pg], acc[b][pg]);
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah, bl[pg], acc[b][pg]);
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(al, bh[pg], acc[b][pg]);
+          }
         }
       }
       THA4_CSTAMP();                                       // chunk MFMAs issued
