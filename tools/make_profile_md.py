@@ -26,10 +26,12 @@ def read(path):
 
 def student():
     shutil.copy(os.path.join(G, "ps_kernel_stats.csv"), os.path.join(P, f"{tag}_student_b1_kernel_stats.csv"))
-    md = [f"# Round 1 - student path, batch 1 stream (`bench.py --steps 200 --warmup 50 --full-frames 0`), MI355X",
-          "Source: `tools/profile_student.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) and",
-          "`tools/profile_traffic.sh` (FETCH_SIZE and WRITE_SIZE each in its own pass: together they abort rocprofv3 on this image).",
-          "Kernels: generation 2 (fp16 hi/lo split MFMA), weights-resident level 2, XCD-aware tile order.", "",
+    if os.path.exists(os.path.join(G, "student_b1_traffic.json")):
+        shutil.copy(os.path.join(G, "student_b1_traffic.json"), os.path.join(P, f"{tag}_student_b1_traffic.json"))
+    md = [f"# {tag} - student path, batch 1 stream (`bench.py --steps 200 --warmup 50 --profile-frames 5 --full-frames 0 --d2h-frames 0 --exact-frames 0`), MI355X",
+          "Source: `tools/profile_r02.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes; FETCH_SIZE and WRITE_SIZE each in",
+          "its own pass: together they abort rocprofv3 on this image).  Kernels: generation 2 (fp16 hi/lo split MFMA), weights-resident",
+          f"level 2, XCD-aware tile order, face + level 0 in one launch, pose bias folded into the prologues.  Machine-readable traffic: `{tag}_student_b1_traffic.json`.", "",
           f"## rocprofv3 --kernel-trace --stats (full CSV: {tag}_student_b1_kernel_stats.csv)", stats_table(os.path.join(G, "ps_kernel_stats.csv")), "",
           "## PMC passes (per-launch averages summed over the chip; SQ_* cycle counters count quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES)",
           "```", read(os.path.join(G, "ps_pmc_summary.txt")).strip(), "```", "",
@@ -41,10 +43,12 @@ def student():
 
 def full():
     shutil.copy(os.path.join(G, "pf_kernel_stats.csv"), os.path.join(P, f"{tag}_full_b1_kernel_stats.csv"))
-    md = [f"# Round 1 - full THA4 model (mode_07), batch 1, MI355X",
-          "Source: `tools/profile_traffic.sh` / `tools/profile_full.sh` (`rocprofv3 --kernel-trace --stats -- python tools/time_full.py`:",
-          "3 warm-up + 20 steady + 20 cold frames = 43 frames, 21 of them run the eyebrow decomposer), `tools/pmc_full.sh` (PMC, 9 frames),",
-          "`tools/breakdown_full.sh` (per-layer join of the schedule dump with the kernel trace).  Synthetic seeded weights.", "",
+    if os.path.exists(os.path.join(G, "full_b1_traffic.json")):
+        shutil.copy(os.path.join(G, "full_b1_traffic.json"), os.path.join(P, f"{tag}_full_b1_traffic.json"))
+    md = [f"# {tag} - full THA4 model (mode_07), batch 1, MI355X",
+          "Source: `tools/profile_r02.sh` (`rocprofv3 --kernel-trace --stats -- python tools/time_full.py`: 3 warm-up + 20 steady + 20 cold",
+          "frames = 43 frames, 21 of them run the eyebrow decomposer; PMC passes over 9 frames; FETCH_SIZE / WRITE_SIZE passes over steady-only",
+          f"and cold-only runs -> `{tag}_full_b1_traffic.json`; per-layer join of the schedule dump with the kernel trace).  Synthetic seeded weights.", "",
           "Un-profiled wall clock of the same script:", "```", read(os.path.join(G, "pf_time.log")).strip(), "```", "",
           f"## rocprofv3 --kernel-trace --stats (full CSV: {tag}_full_b1_kernel_stats.csv)", stats_table(os.path.join(G, "pf_kernel_stats.csv")), "",
           "## Per-layer breakdown of one cold frame (largest first; TFLOP/s = as-written FLOPs of the layer / its launches)",
