@@ -135,7 +135,8 @@ int tha4_student_device(const tha4_student* h);
 /* Time (ms) of the most recent tha4_student_pose on this handle measured with HIP events recorded
  * on the SAME stream the kernels were launched on; enabled with tha4_student_set_timing(h, 1).
  * Reading it synchronises on the stop event.  kernel: 0 posebias, 1 face, 2 level0, 3 level1,
- * 4 level2(+warp), -1 whole call. */
+ * 4 level2(+warp), -1 whole call.  In the default (fp16-split) generation the pose bias is computed inside the kernels and
+ * face + level 0 share one launch: slots 0 and 1 then measure an empty interval and slot 2 the merged kernel. */
 int tha4_student_set_timing(tha4_student* h, int enable);
 int tha4_student_last_ms(tha4_student* h, int kernel, float* ms_out);
 
