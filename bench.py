@@ -341,7 +341,7 @@ def student_extras(args, work, dev, world, fps, K, W, B):
                 "vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": kernel_traffic_bytes(prof, dom.split(" ")[0]) if B == 1 else None,
                 "traffic_unit": f"bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes in {prof_file}",
-                "traffic_per_frame": (sum(kernel_traffic_bytes(prof, n) or 0 for n in KERNEL_NAMES) if (B == 1 and prof) else None),
+                "traffic_per_frame": (sum(kernel_traffic_bytes(prof, n) or 0 for n in prof.get("kernels", {})) if (B == 1 and prof) else None),
                 "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                 "frame_event_ms": round(whole / nprof, 4),
                 "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
