@@ -32,6 +32,12 @@
 
 namespace tha4 {
 
+#ifndef THA4_TILE_COUNTED_WAIT
+// 1: the chunk barriers leave the weight fetches of the chunks after the next one in flight (counted s_waitcnt vmcnt + raw
+// s_barrier, so that a ring deeper than two slots hides fetch latency).  Measured (round 2, tools/gpu_call19.sh): parity-clean but
+// 1 % SLOWER (146.5 vs 148.3 fps; batch 8 263 vs 268) - the barriers wait for wave skew, not for the fetches - so it stays off.
+#define THA4_TILE_COUNTED_WAIT 0
+#endif
 constexpr int kTileWaves = 8;
 constexpr int kTileThreads = kTileWaves * 64;
 constexpr int kTileMaxItems = 5;     // staging items (pixel, g) per thread and K group: window <= 640 pixels
@@ -200,6 +206,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     go.v[k] = ok ? o * 64 + sg * 16 : -1;                  // BYTE offset from the (wave-uniform) quad base: saddr + voffset loads
   }
 
+  // glds instructions EVERY wave issues per chunk (wave w issues ceil((pieces - w) / 8)): the lower bound the counted barrier uses
+  const int keep_per_chunk = (a.taps_per_chunk * TMB * 2) / kTileWaves;
   auto fetch = [&](int chunk, int slot) {
     const char* src = gw + (size_t)chunk * slot_bytes;
     char* dst = ring + slot * slot_bytes;
@@ -379,7 +387,13 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         }
       }
       THA4_CSTAMP();                                       // chunk MFMAs issued
-      __syncthreads();
+      // every wave must (a) be done reading this slot and (b) have ITS pieces of the NEXT chunk in LDS; the chunks fetched
+      // after that one (ring deeper than two slots) may stay in flight: at least keep_per_chunk glds per younger chunk
+      {
+        const int younger = issued - chunk - 2;            // chunks requested after chunk + 1
+        const int keep = THA4_TILE_COUNTED_WAIT && younger > 0 ? min(8, younger * keep_per_chunk) : 0;
+        THA4_BARRIER_KEEP(keep);
+      }
       THA4_CSTAMP();                                       // chunk barrier passed
       slot = slot + 1 == D ? 0 : slot + 1;
       ++chunk;

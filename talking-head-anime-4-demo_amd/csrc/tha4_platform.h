@@ -32,6 +32,24 @@
 #define THA4_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
+// Workgroup barrier that lets the newest `keep` global_load_lds / global loads of this wave stay in flight (counted
+// s_waitcnt vmcnt): `__syncthreads()` drains every LDS-DMA before its s_barrier, which defeats a weight ring deeper than two
+// slots.  Everything OLDER than the newest `keep` VMEM operations of the wave is complete when the barrier is passed; LDS
+// traffic of the wave is complete (lgkmcnt(0)).  One asm block with a memory clobber: nothing is moved across it.
+#ifdef THA4_EMU
+#define THA4_BARRIER_KEEP(keep) __syncthreads()
+#else
+#define THA4_BARRIER_KEEP_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+#define THA4_BARRIER_KEEP(keep)                                                                                   \
+  do {                                                                                                            \
+    switch (keep) {                                                                                               \
+      THA4_BARRIER_KEEP_CASE(1) THA4_BARRIER_KEEP_CASE(2) THA4_BARRIER_KEEP_CASE(3) THA4_BARRIER_KEEP_CASE(4)     \
+      THA4_BARRIER_KEEP_CASE(5) THA4_BARRIER_KEEP_CASE(6) THA4_BARRIER_KEEP_CASE(7) THA4_BARRIER_KEEP_CASE(8)     \
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;                  \
+    }                                                                                                             \
+  } while (0)
+#endif
+
 namespace tha4 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
