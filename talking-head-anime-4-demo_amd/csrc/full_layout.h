@@ -246,6 +246,31 @@ inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TM
   return best;
 }
 
+// Launch plan of conv_point_kernel<TMB, PG> (full_conv_point_kernels.h): a workgroup = 4 waves x PG pixel groups of 16
+// consecutive pixels x TMB output blocks.  The largest register tile per wave (fewest LDS reads per MFMA) whose grid still
+// gives every CU a workgroup; with a folded normalisation the reduction scratch (2 doubles per padded input channel) must
+// fit one ring slot and fused_norm_table() handles at most 2 channels per thread.
+struct PointPlan {
+  bool ok = false;
+  int tmb = 1, pg = 1, tiles = 0;
+};
+inline PointPlan plan_point_conv(int px, int nb, int cbtot, int frames, bool fused, int want_wgs = 256) {
+  PointPlan best;
+  const long F = frames < 1 ? 1 : frames;
+  long best_wgs = -1;
+  const int cand[6][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 2}, {1, 1}};
+  for (auto& c : cand) {
+    const int tmb = c[0], pg = c[1];
+    if (nb % tmb) continue;
+    if (fused && ((size_t)cbtot * 16 * 16 > (size_t)4 * tmb * 2048 || cbtot * 16 > 512)) continue;
+    const int tiles = (px + 64 * pg - 1) / (64 * pg);
+    const long wgs = (long)tiles * (nb / tmb) * F;
+    if (wgs >= want_wgs) { best.ok = true; best.tmb = tmb; best.pg = pg; best.tiles = tiles; return best; }
+    if (wgs > best_wgs) { best_wgs = wgs; best.ok = true; best.tmb = tmb; best.pg = pg; best.tiles = tiles; }
+  }
+  return best;
+}
+
 // Launch plan of conv_small_kernel<PG> (full_conv_small_kernels.h): a workgroup = 16*PG output positions (TH x 2^twl) x one
 // output block, its 8 waves split the K groups (x tap ranges when there are fewer than 8 groups).
 struct SmallPlan {

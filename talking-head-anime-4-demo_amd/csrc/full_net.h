@@ -21,6 +21,7 @@
 #include "full_image_kernels.h"
 #include "full_conv16_kernels.h"
 #include "full_conv_small_kernels.h"
+#include "full_conv_point_kernels.h"
 #include "full_kernels.h"
 #include "full_layout.h"
 
@@ -167,6 +168,11 @@ class FullModel {
     if (pg == 2) return launch_small<2>(inmode, a, grid, lds, s);
     return launch_small<1>(inmode, a, grid, lds, s);
   }
+  static void dispatch_point(int tmb, int pg, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+#define THA4_PCASE(TM, PGV) if (tmb == TM && pg == PGV) { hipLaunchKernelGGL((conv_point_kernel<TM, PGV>), grid, dim3(kPointThreads), lds, s, a); return; }
+    THA4_PCASE(4, 2) THA4_PCASE(4, 1) THA4_PCASE(2, 2) THA4_PCASE(2, 1) THA4_PCASE(1, 2) THA4_PCASE(1, 1)
+#undef THA4_PCASE
+  }
   static hipError_t allow_all_conv_lds() {
     hipError_t e = hipSuccess;
     auto set = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
@@ -189,6 +195,9 @@ class FullModel {
   set(reinterpret_cast<const void*>(conv_small_kernel<PGV, IN_POOL2>));
     THA4_SALLOW(4) THA4_SALLOW(2) THA4_SALLOW(1)
 #undef THA4_SALLOW
+#define THA4_PALLOW(TM, PGV) set(reinterpret_cast<const void*>(conv_point_kernel<TM, PGV>));
+    THA4_PALLOW(4, 2) THA4_PALLOW(4, 1) THA4_PALLOW(2, 2) THA4_PALLOW(2, 1) THA4_PALLOW(1, 2) THA4_PALLOW(1, 1)
+#undef THA4_PALLOW
     set(reinterpret_cast<const void*>(attention_kernel));
     return e;
   }
@@ -240,16 +249,28 @@ class FullModel {
       tiled = plan.ok;
       if (std::getenv("THA4_NO_TILE_SPLITK") && plan.ksplit > 1) tiled = false;
     }
+    // 1x1 convolutions on maps above 32x32: conv_point_kernel (operands straight from C16 global memory, fp16 hi/lo MFMA,
+    // the K loop free of control flow around memory operations)
+    const int max1x1 = std::getenv("THA4_SMALL_1X1_MAX_PX") ? std::atoi(std::getenv("THA4_SMALL_1X1_MAX_PX")) : 32 * 32;
+    bool point = false;
+    PointPlan pp;
+    if (kind == K_SAME1 && in_mode == IN_DIRECT && tile_px > max1x1 && !tiled && !std::getenv("THA4_NO_POINT_CONV") &&
+        (!residual || res_mode == IN_DIRECT) && point_act_supported(act_in)) {
+      bool tensors = true;
+      for (auto& sx : srcs) tensors = tensors && !sx.vector;
+      pp = plan_point_conv(tile_px, nb, cbtot, max_batch, fpend != nullptr);
+      point = tensors && pp.ok;
+      if (point) { tmb = pp.tmb; mtiles = nb / tmb; }
+    }
     // small maps (the tile plan would split K over two launches) and 1x1 convolutions: conv_small_kernel, K split across
     // the waves of one workgroup, ONE launch
     bool small = false;
     SmallPlan sp;
-    {
+    if (!point) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
       // where it wins (per-layer breakdown in profiles/r02_full_b1_reading.md): 3x3 / 1x1 / transposed-conv classes on maps
       // the tile plan would split over two launches, not the 16-tap stride-2 convolutions (their 108-pixel window per 16
       // outputs makes staging dominate) and not average-pooled inputs (four dependent samples per staged item)
-      const int max1x1 = std::getenv("THA4_SMALL_1X1_MAX_PX") ? std::atoi(std::getenv("THA4_SMALL_1X1_MAX_PX")) : 32 * 32;
       bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
       if (!std::getenv("THA4_SMALL_ALL_KINDS") && (kind == K_S2K4 || in_mode == IN_POOL2)) want = false;
       if (want && !std::getenv("THA4_NO_SMALL_CONV")) {
@@ -266,14 +287,15 @@ class FullModel {
     }
     // fallbacks (1x1 convolutions): small maps (<= 32x32) one pixel group per workgroup with K split over its 4 waves
     // (conv_splitk_kernel), otherwise the exact-fp32 pixel-tiled kernel (conv_mfma_kernel)
-    const bool splitk = !small && !tiled && tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
-    if (fpend && !small && !tiled) { if (error.empty()) error = "internal: a fused normalisation needs the tile / small convolution kernels"; return FTensor(); }
+    const bool splitk = !small && !tiled && !point && tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
+    if (fpend && !small && !tiled && !point) { if (error.empty()) error = "internal: a fused normalisation needs the tile / small convolution kernels"; return FTensor(); }
     int pg = 1;
     if (small) pg = sp.pg;
+    else if (point) pg = pp.pg;
     else if (tiled) pg = plan.pg;
     else if (!splitk && tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
-    if (!small && !tiled && tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
-    const int tiles = small ? sp.tiles : tiled ? plan.geom.tiles : splitk ? tile_px / 16 : tile_px / (64 * pg);
+    if (!small && !tiled && !point && tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
+    const int tiles = small ? sp.tiles : point ? pp.tiles : tiled ? plan.geom.tiles : splitk ? tile_px / 16 : tile_px / (64 * pg);
     const int ksplit = tiled ? plan.ksplit : 1;
     if (tiled && ksplit > 1) {
       partial_floats = std::max(partial_floats, (size_t)ksplit * mtiles * tiles * tmb * 8 * pg * 64 * 4);
@@ -281,7 +303,7 @@ class FullModel {
     const int conv_index = conv_counter++;
     if (std::getenv("THA4_DUMP_SCHEDULE"))
       std::fprintf(stderr, "conv #%d kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d ksplit=%d twl=%d\n", conv_index, (int)kind, ih,
-                   iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles * ksplit, small ? 2 : (int)tiled, ksplit,
+                   iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles * ksplit, small ? 2 : point ? 3 : (int)tiled, ksplit,
                    small ? sp.tw_log2 : tiled ? plan.geom.tw_log2 : 0);
     FTensor out = new_tensor(nb, oh, ow);
     if (want_stats) {
@@ -311,6 +333,12 @@ class FullModel {
         lds = ((table_bytes + 127) & ~(size_t)127) + sg.lds;
         a.w16_inv_scale = inv; a.wg_tw_log2 = sg.tw_log2; a.win_h = sg.win_h; a.win_w = sg.win_w;
         a.win_dy0 = sg.dy0; a.win_dx0 = sg.dx0; a.units_per_q = sp.units_per_q;
+      } else if (point) {
+        float inv = 1.f;
+        const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, false, g, segs, tmb, &inv);
+        w_off = add_param(p16.data(), p16.size());
+        lds = point_lds_bytes(tmb, cbtot);
+        a.w16_inv_scale = inv;
       } else if (tiled) {
         const TileGeom tg = tile_geom(g, th, tw, pg, tmb, plan.geom.tw_log2, table_bytes);
         float inv = 1.f;
@@ -377,6 +405,8 @@ class FullModel {
         c.batch = f.batch;
         if (small) {
           dispatch_small(pg, in_mode, c, dim3(f.batch * tiles * nb, 1, 1), lds, f.stream);
+        } else if (point) {
+          dispatch_point(tmb, pg, c, dim3(f.batch * tiles * mtiles, 1, 1), lds, f.stream);
         } else if (splitk) {
           const dim3 grid(f.batch * tiles, mtiles);
           if (in_mode == IN_DIRECT) hipLaunchKernelGGL((conv_splitk_kernel<4, IN_DIRECT>), grid, dim3(256), 16 * 1024, f.stream, c);

@@ -45,9 +45,19 @@
     switch (keep) {                                                                                               \
       THA4_BARRIER_KEEP_CASE(1) THA4_BARRIER_KEEP_CASE(2) THA4_BARRIER_KEEP_CASE(3) THA4_BARRIER_KEEP_CASE(4)     \
       THA4_BARRIER_KEEP_CASE(5) THA4_BARRIER_KEEP_CASE(6) THA4_BARRIER_KEEP_CASE(7) THA4_BARRIER_KEEP_CASE(8)     \
+      THA4_BARRIER_KEEP_CASE(9) THA4_BARRIER_KEEP_CASE(10) THA4_BARRIER_KEEP_CASE(11) THA4_BARRIER_KEEP_CASE(12)  \
+      THA4_BARRIER_KEEP_CASE(13) THA4_BARRIER_KEEP_CASE(14) THA4_BARRIER_KEEP_CASE(15) THA4_BARRIER_KEEP_CASE(16) \
       default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;                  \
     }                                                                                                             \
   } while (0)
+#endif
+
+// Workgroup barrier for LDS traffic only: the wave's LDS operations are complete, its global loads stay in flight
+// (`__syncthreads()` carries a release fence that drains vmcnt).  Global stores before it are NOT ordered by it.
+#ifdef THA4_EMU
+#define THA4_BARRIER_LDS() __syncthreads()
+#else
+#define THA4_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
 namespace tha4 {

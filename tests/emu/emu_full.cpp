@@ -10,6 +10,7 @@
 #endif
 #include "full_conv16_kernels.h"
 #include "full_conv_small_kernels.h"
+#include "full_conv_point_kernels.h"
 #include "full_image_kernels.h"
 #include "full_layout.h"
 
@@ -141,9 +142,11 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
   Mirror M;
   const bool splitk = pg == 0;
-  const bool small = pg >= 20;              // conv_small_kernel<pg - 20> (tmb must be 1; `ksplit` carries units_per_q, 0 = planner's)
-  const bool tiled = pg >= 10 && !small;    // conv_tile_kernel<tmb, pg - 10>
-  const int tpg = pg - 10, spg = pg - 20;
+  const bool point = pg >= 30;              // conv_point_kernel<tmb, pg - 30> (1x1, IN_DIRECT)
+  const bool small = pg >= 20 && !point;    // conv_small_kernel<pg - 20> (tmb must be 1; `ksplit` carries units_per_q, 0 = planner's)
+  const bool tiled = pg >= 10 && !small && !point;    // conv_tile_kernel<tmb, pg - 10>
+  const int tpg = pg - 10, spg = pg - 20, ppg = pg - 30;
+  if (point && (kind != 0 || k != 1 || in_mode != IN_DIRECT || vec1)) return -6;
   const FusedSpec fused = g_fused;
   g_fused.set = false;
   const size_t table_bytes = fused.set ? (size_t)2 * (cb0 + (c1 > 0 && !vec1 ? cb1 : 0)) * 16 * sizeof(float) : 0;
@@ -158,8 +161,8 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     tg0 = tile_geom(kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0)), th, tw, tpg, tmb, tw_log2, table_bytes);
     if (!tg0.ok) return -4;
   }
-  const int tiles_per_class = small ? sp0.tiles : splitk ? th * tw / 16 : (tiled ? tg0.tiles : (th * tw / 16) / (4 * pg));
-  if (!small && !splitk && !tiled && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
+  const int tiles_per_class = point ? (th * tw + 64 * ppg - 1) / (64 * ppg) : small ? sp0.tiles : splitk ? th * tw / 16 : (tiled ? tg0.tiles : (th * tw / 16) / (4 * pg));
+  if (!small && !splitk && !tiled && !point && tiles_per_class * 4 * pg * 16 != th * tw) return -2;
   const int stats_tiles = tiles_per_class * nclass;
   std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
   float *dX0 = M.up(X0), *dX1 = c1 > 0 ? M.up(X1) : nullptr, *dR = residual ? M.up(R) : nullptr, *dB = M.up(B), *dO = M.up(O), *dST = M.up(ST);
@@ -223,6 +226,17 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb, &inv);
       a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
       a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots;
+    }
+    if (point) {
+      float inv = 1.f;
+      P16 = pack_conv_weight16(weight, cout, cin, 1, 1, false, g, segs, tmb, &inv);
+      a.w16 = M.up(P16); a.w16_inv_scale = inv;
+      const size_t plds = point_lds_bytes(tmb, cb0 + cb1);
+      const dim3 pgrid(n * tiles_per_class * mtiles, 1, 1);
+#define RUNP(TM, PGV) if (tmb == TM && ppg == PGV) THA4_RUN((conv_point_kernel<TM, PGV>), pgrid, kPointThreads, plds, a);
+      RUNP(4, 2) RUNP(4, 1) RUNP(2, 2) RUNP(2, 1) RUNP(1, 2) RUNP(1, 1)
+#undef RUNP
+      continue;
     }
     const size_t lds = small ? ((table_bytes + 127) & ~(size_t)127) + sg.lds : tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
     const int phases = tiled && ksplit > 1 ? 2 : 1;

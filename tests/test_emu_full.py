@@ -134,6 +134,13 @@ CASES = [
     (0, 3, 1, 22, 2, "silu", 64, 0, False, 32, 32, 32, True, False, False, True, (4, 0)),    # avg-pool 2x2 on load
     (0, 3, 1, 24, 0, "relu", 32, 0, False, 20, 20, 16, True, False, True, False, (3, 0)),    # ragged 20x20 in 8x8 tiles, per-channel output activations
     (0, 1, 1, 21, 0, "none", 64, 0, False, 16, 16, 128, True, False, False, True, (4, 0)),   # 8 output blocks: XCD-aware (block -> XCD) workgroup order
+    # conv_point_kernel (pg = 30 + PG): 1x1 convolutions on larger maps, operands straight from global memory
+    (0, 1, 4, 32, 0, "none", 64, 32, False, 16, 32, 64, True, True, False, True, (4, 1)),    # U-Net skip: concat, residual, 3 K groups (< one chunk), 8 pixel tiles -> XCD order
+    (0, 1, 2, 32, 0, "relu", 272, 0, False, 24, 24, 32, True, False, True, True, (4, 1)),    # 17 quads (phantom quad), 9 K groups = 3 chunks with a tail, ragged last tile, mixed output activations
+    (0, 1, 1, 31, 0, "silu", 48, 16, False, 16, 16, 16, True, False, False, True, (4, 1)),   # SiLU input, first source with an odd quad count: a K group straddles the sources
+    (0, 1, 4, 31, 0, "relu", 128, 0, False, 16, 16, 64, False, False, False, False, (4, 1)), # no scale/shift (identity table), exactly one chunk
+    (0, 1, 2, 31, 0, "none", 160, 96, False, 8, 24, 96, True, True, False, True, (4, 1)),    # 3 output tiles, 8 K groups = 2 full chunks
+    (0, 1, 1, 32, 0, "relu", 32, 0, False, 20, 20, 48, True, False, False, True, (4, 1)),    # one K group, ragged 400-pixel map
 ]
 
 
@@ -413,6 +420,8 @@ FUSED_CASES = [
     (24, 1, "none", 128, 0, 16, 16, 48, 32, False, 8, (4, 0)),    # 1x1 qkv projection after GroupNorm
     (12, 3, "silu", 64, 32, 32, 32, 32, 32, True, 4, (4, 1)),     # conv_tile_kernel<2,2> with the table in its prologue
     (11, 3, "relu", 48, 0, 16, 16, 32, 0, False, 2, (4, 2)),      # conv_tile_kernel K split (phase 1 builds the table, phase 2 skips it)
+    (32, 1, "silu", 96, 64, 16, 32, 32, 32, True, 4, (4, 0)),     # conv_point_kernel<2,2>: GroupNorm(32) over a concatenation + FiLM in its prologue
+    (31, 1, "relu", 64, 0, 16, 16, 32, 0, False, 2, (4, 0)),      # conv_point_kernel<2,1>: InstanceNorm
 ]
 
 
@@ -438,9 +447,9 @@ def test_conv_with_fused_norm(lib, case):
     hn = torch_act(_norm_ref(xin, cin, groups, gamma, beta, f0, f1), act_in)
     ref = F.conv2d(hn, torch.from_numpy(weight).double(), torch.from_numpy(bias).double(), padding=k // 2).numpy()
     lib.emu_set_fused_norm(P(st0), tiles, P(st1), tiles * 2 if c1 else 0, cin, groups, C.c_float(1.0 / (h * w)), P(gamma), P(beta), P(f0), P(f1))
-    tmb = 1 if pg >= 20 else 2
+    tmb = 1 if 20 <= pg < 30 else 2
     out, stats = run_conv(lib, 0, k, tmb, pg, 0, act_in, x0, x1, False, None, None, weight, bias, None, None, 1, twl,
-                          extra if pg < 20 else 0)
+                          extra if pg < 20 else (1 if pg >= 30 else 0))
     assert np.abs(out - ref).max() < 5e-5, np.abs(out - ref).max()
     assert np.abs(stats[..., 0] - ref.sum(axis=(2, 3))).max() < 2e-3
 
