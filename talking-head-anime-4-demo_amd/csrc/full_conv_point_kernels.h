@@ -31,18 +31,6 @@ inline size_t point_lds_bytes(int TMB, int cbtot) {
   return (((size_t)2 * cbtot * 16 * sizeof(float) + 127) & ~(size_t)127) + 2 * point_slot_bytes(TMB) + (size_t)kPointWaves * TMB * 16 * 2 * sizeof(float);
 }
 
-// act(x * sc + sh) for the input activations this kernel accepts (host-checked): none, ReLU, SiLU
-THA4_DEV f32x4 point_act4(const f32x4& x, const f32x4& sc, const f32x4& sh, int act) {
-  f32x4 o;
-  const float lo = act == ACT_RELU ? 0.0f : -__builtin_inff();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(x[j], sc[j], sh[j]), lo);
-  if (act == ACT_SILU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = o[j] * fast_sigmoid(o[j]);
-  }
-  return o;
-}
 inline bool point_act_supported(int act) { return act == ACT_NONE || act == ACT_RELU || act == ACT_SILU; }
 
 template <int TMB, int PG>
@@ -144,8 +132,8 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
     Frag f;
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
-      const f32x4 xa = point_act4(cur.va[pg], sca, sha, acta);
-      const f32x4 xb = point_act4(cur.vb[pg], scb, shb, actb);
+      const f32x4 xa = apply_act4(cur.va[pg], sca, sha, acta);
+      const f32x4 xb = apply_act4(cur.vb[pg], scb, shb, actb);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float ua = valid ? xa[j] : 0.0f, ub = valid ? xb[j] : 0.0f;

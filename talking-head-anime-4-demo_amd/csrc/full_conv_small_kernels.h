@@ -36,6 +36,13 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = uniform_i32(tid >> 6);
   const int p = lane & 15, g = lane >> 4, g4 = g * 4;
+#if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
+  long long* stamps = a.dbg ? a.dbg + ((size_t)blockIdx.x * kSmallWaves + wave) * 64 : nullptr;
+  int nstamp = 0;
+#define THA4_SSTAMP() do { if (stamps && lane == 0 && nstamp < 64) stamps[nstamp] = clock64(); ++nstamp; } while (0)
+#else
+#define THA4_SSTAMP()
+#endif
 
   // ---- tile decomposition (16*PG output positions, TH x 2^twl) ------------------------------------
   const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (PG * 16) >> twl;
@@ -167,8 +174,14 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   auto write_window = [&]() {
     bind_table(cA);
     bind_table(cB);
+#ifdef THA4_PHASE_WINDOW
+    THA4_SSTAMP();
+#endif
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
+#ifdef THA4_PHASE_WINDOW
+      if (k > 0) THA4_SSTAMP();
+#endif
       const int item = lane + k * 64;
       if (item >= nitems) continue;
       f32x4 va = rawA[k], vb = rawB[k];
@@ -228,6 +241,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     }
   };
 
+  THA4_SSTAMP();                                           // 0: entry (index set-up done)
   // ---- first unit's loads go out before the normalisation table is built -------------------------
   // three register-resident weight chunks (3 taps each: a whole 3x3 K group) are in flight per wave; longer tap ranges
   // (4x4 stride 2: 16 taps) roll through the three slots
@@ -269,10 +283,20 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
       if (wave == 0 && a.residual && inside[pg]) resv[pg] = load_residual(pg);
     }
   }
+  THA4_SSTAMP();                                           // 1: first unit's loads issued
+#if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
+  if (a.dbg) {                                             // tuning aid: when do the window (requested first) and the weights land?
+    asm volatile("s_waitcnt vmcnt(19)" ::: "memory");      // 18 weight loads + the stamp's store are younger than the window loads
+    THA4_SSTAMP();                                         // 2: window landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    THA4_SSTAMP();                                         // 3: weights landed
+  }
+#endif
   if (a.fnorm.enabled) {
     fused_norm_table(a, n, tid, kSmallThreads, tab_sc, tab_sh, reinterpret_cast<double*>(wins));
     __syncthreads();                                       // table complete; scratch (aliasing the windows) no longer read
   }
+  THA4_SSTAMP();                                           // 2: normalisation table built
   bool staged = false;
   for (; u < nunits; u += kSmallWaves) {
     const int Q = u / upq;
@@ -283,6 +307,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
       staged = true;
       THA4_WAVE_SYNC();
     }
+    THA4_SSTAMP();                                         // 3 + 2i: unit i's window written (its loads have arrived)
     for (int t = t0; t < t1; t += 3 * TC) {                // slots are refilled as soon as their MFMAs are issued
       mac_chunk(t, t1, w0);
       if (t + 3 * TC < t1) load_weights(Q, t + 3 * TC, t1, w0);
@@ -295,6 +320,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
         if (t + 5 * TC < t1) load_weights(Q, t + 5 * TC, t1, w2);
       }
     }
+    THA4_SSTAMP();                                         // 4 + 2i: unit i's MFMAs issued
     // the next unit's window + weights are requested before this wave idles: one memory round trip per unit
     const int un = u + kSmallWaves;
     if (un < nunits) {
@@ -306,11 +332,13 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   }
 
   // ---- combine the eight K slices in wave order, epilogue on wave 0 -----------------------------------
+  THA4_SSTAMP();                                           // K loop left
   __syncthreads();                                         // every wave is done with its window: the region is reused
   f32x4* red = reinterpret_cast<f32x4*>(wins);             // [wave][pg][64]
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) red[(wave * PG + pg) * 64 + lane] = acc[pg];
   __syncthreads();
+  THA4_SSTAMP();                                           // partial sums exchanged
   if (wave != 0) return;
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
@@ -349,6 +377,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
       }
     }
   }
+  THA4_SSTAMP();                                           // wave 0: epilogue issued
 }
 
 }  // namespace tha4

@@ -102,26 +102,39 @@ THA4_DEV float fast_sigmoid(float v) {
 #endif
 }
 
+// tanh on the same two transcendentals: sign(v) (1 - e) / (1 + e), e = 2^(-2 |v| log2 e).  Absolute error ~1e-7 (the
+// cancellation in 1 - e near 0 costs relative, not absolute, accuracy; outputs are O(1) colour changes).  libm's tanhf
+// is ~150 instructions and was inlined at every activation site - four per 16-byte item, in the staging loops of every
+// convolution kernel even though no layer has a tanh INPUT activation: the small-map kernels spent more cycles fetching
+// that code than executing anything (profiles/r02_full_b1_reading.md).
+THA4_DEV float fast_tanh(float v) {
+#ifdef THA4_EMU
+  return tanhf(v);
+#else
+  const float e = __builtin_amdgcn_exp2f(fabsf(v) * -2.8853900817779268f);
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return copysignf(t, v);
+#endif
+}
+
 THA4_DEV float apply_act(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.0f);
   if (act == ACT_SILU) return v * fast_sigmoid(v);
   if (act == ACT_SIGMOID) return fast_sigmoid(v);
-  if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_TANH) return fast_tanh(v);
   return v;
 }
 
-// act(x * sc + sh) on four values with ONE (uniform) dispatch on the activation
+// act(x * sc + sh) on four values with ONE (uniform) dispatch on the activation; ReLU / none share a branch-free path
 THA4_DEV f32x4 apply_act4(const f32x4& x, const f32x4& sc, const f32x4& sh, int act) {
   f32x4 o;
+  const float lo = act == ACT_RELU ? 0.0f : -__builtin_inff();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = fmaf(x[j], sc[j], sh[j]);
-  if (act == ACT_RELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.0f);
-  } else if (act == ACT_SILU) {
+  for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(x[j], sc[j], sh[j]), lo);
+  if (act == ACT_SILU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = o[j] * fast_sigmoid(o[j]);
-  } else if (act != ACT_NONE) {
+  } else if (act == ACT_SIGMOID || act == ACT_TANH) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act);
   }

@@ -326,7 +326,9 @@ inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int 
     return b;
   };
   const int cap = std::getenv("THA4_SMALL_MAX_WGS") ? std::atoi(std::getenv("THA4_SMALL_MAX_WGS")) : max_wgs;   // tuning aid
-  for (int pg : {1, 2, 4}) {
+  const bool big_first = std::getenv("THA4_SMALL_BIG_FIRST") != nullptr;                                        // tuning aid
+  for (int i = 0; i < 3; ++i) {
+    const int pg = big_first ? (4 >> i) : (1 << i);
     const SmallPlan t = pick(pg);
     if (!t.ok || (long)t.tiles * nb * (frames < 1 ? 1 : frames) > cap) continue;
     best = t;

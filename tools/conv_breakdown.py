@@ -18,7 +18,7 @@ for kv in sched:
 rows = [r for r in csv.DictReader(open(sys.argv[2]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 convs = [r for r in rows if "conv_mfma_kernel" in r["Kernel_Name"] or "conv_splitk_kernel" in r["Kernel_Name"] or "conv_tile_kernel" in r["Kernel_Name"]
-         or "conv_small_kernel" in r["Kernel_Name"]]
+         or "conv_small_kernel" in r["Kernel_Name"] or "conv_point_kernel" in r["Kernel_Name"]]
 n = len(launches)
 last = convs[-n:]
 print(f"{len(sched)} convs, {n} launches per cold frame, {len(convs)} conv launches in trace")
@@ -30,7 +30,7 @@ for kv, r in zip(launches, last):
     th, tw = map(int, kv["tile"].split("x"))
     cin = int(kv["cin"].split("(")[0])
     gflop = 2.0 * th * tw * cin * int(kv["cout"]) * taps / 1e9
-    key = (kv["kind"], kv["tile"], kv["mode"], cin, kv["cout"], kv["splitk"] + ("S" if kv.get("tiled") == "2" else ""), kv["tmb"], kv["pg"], kv["wgs"], kv.get("ksplit", "1"))
+    key = (kv["kind"], kv["tile"], kv["mode"], cin, kv["cout"], kv["splitk"] + ("S" if kv.get("tiled") == "2" else "P" if kv.get("tiled") == "3" else ""), kv["tmb"], kv["pg"], kv["wgs"], kv.get("ksplit", "1"))
     agg[key][0] += 1
     agg[key][1] += us
     agg[key][2] += gflop / (2 if int(kv.get("ksplit", "1")) > 1 else 1)

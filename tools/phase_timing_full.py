@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "talking-head-anime-4-demo_amd", "csrc")
 lib = os.path.join(ROOT, "build_variants", "libtha4_phase.so")
 if "build" in sys.argv:
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTHA4_PHASE_TIMING", "-I", CSRC, "-I",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTHA4_PHASE_TIMING", *(["-DTHA4_PHASE_WINDOW"] if "--window" in sys.argv else []), "-I", CSRC, "-I",
                     os.path.join(ROOT, "include"), os.path.join(CSRC, "tha4_capi.hip"), "-o", lib], check=True)
     sys.exit(0)
 
@@ -46,7 +46,9 @@ sched = [l for l in tmp.read().decode().splitlines() if l.startswith("conv #")]
 del os.environ["THA4_DUMP_SCHEDULE"]
 
 targets = ["tile=64x64 cin=256(cb 16) cout=256", "tile=16x16 cin=512(cb 32) cout=512", "tile=256x256 cin=128(cb 8) cout=128",
-           "tile=128x128 cin=128(cb 8) cout=128", "tile=32x32 cin=256(cb 16) cout=256"]
+           "tile=128x128 cin=128(cb 8) cout=128", "tile=32x32 cin=256(cb 16) cout=256", "tile=16x16 cin=256(cb 16) cout=256"]
+if "--small" in sys.argv:
+    targets = [t for t in targets if "16x16" in t or "32x32" in t]
 L = p._lib
 L.tha4_full_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 for tgt in targets:
@@ -68,7 +70,14 @@ for tgt in targets:
     n = int((t[0, 0] > 0).sum())
     first = t[:, :, 0].copy()
     d = np.diff(t[:, :, :n], axis=-1)
-    print(f"== {line[:150]}")
+    print(f"== {line[:170]}")
     print(f"   stamps per wave: {n}; wave span entry -> last stamp: {(t[:, :, n - 1] - t[:, :, 0]).mean():.0f} cycles")
     print("   mean cycles between consecutive stamps: " + " ".join(f"{x:.0f}" for x in d.mean(axis=(0, 1))))
+    if "tiled=2" in line:       # conv_small_kernel: waves have different stamp counts (wave 0 runs the epilogue): per-wave rows of workgroup 0 and the spread of entry times
+        for wv in (0, 1, 7):
+            nn = int((t[0, wv] > 0).sum())
+            print(f"   wg 0 wave {wv}: " + " ".join(f"{x:.0f}" for x in np.diff(t[0, wv, :nn])))
+        ent = t[:, 0, 0]
+        last = np.array([t[w, 0, int((t[w, 0] > 0).sum()) - 1] for w in range(wgs)])
+        print(f"   workgroup entry spread: {ent.max() - ent.min():.0f} cycles; first entry -> last epilogue: {last.max() - ent.min():.0f} cycles (s_memtime ticks at 100 MHz)")
 os.environ.pop("THA4_DBG_CONV", None)
