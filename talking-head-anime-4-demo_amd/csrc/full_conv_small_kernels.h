@@ -118,25 +118,34 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   }
 
   struct QuadCtx { const char* base; f32x4 sc, sh; int act; int kind; bool fused; int tab; };
+  // the two source descriptors as plain scalars (constant indices): indexing a.src[] with a run-time index costs a chain of
+  // dependent scalar loads from the argument block at the top of every K group
+  const float *s0_data = a.src[0].data, *s0_scale = a.src[0].scale, *s0_shift = a.src[0].shift;
+  const float *s1_data = a.src[1].data, *s1_scale = a.src[1].scale, *s1_shift = a.src[1].shift;
+  const int s0_cb = a.src[0].cb, s0_kind = a.src[0].kind, s0_act = a.src[0].act;
+  const int s1_cb = a.src[1].cb, s1_kind = a.src[1].kind, s1_act = a.src[1].act;
   auto quad_ctx = [&](int q) -> QuadCtx {
     QuadCtx c;
     c.base = nullptr; c.act = ACT_NONE; c.kind = SRC_TENSOR; c.fused = false; c.tab = 0;
     c.sc = f32x4{1.f, 1.f, 1.f, 1.f};
     c.sh = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q >= cbtot) return c;                              // phantom quad of an odd channel-block count
-    int s = 0, ql = q;
-    if (a.nsrc > 1 && q >= a.src[0].cb) { s = 1; ql = q - a.src[0].cb; }
-    const ConvSrc& S = a.src[s];
-    c.act = S.act; c.kind = S.kind;
-    if (a.fnorm.enabled && S.kind == SRC_TENSOR) {
+    const bool second = a.nsrc > 1 && q >= s0_cb;
+    const int ql = second ? q - s0_cb : q;
+    const float* const S_data = second ? s1_data : s0_data;
+    const float* const S_scale = second ? s1_scale : s0_scale;
+    const float* const S_shift = second ? s1_shift : s0_shift;
+    const int S_cb = second ? s1_cb : s0_cb, S_kind = second ? s1_kind : s0_kind, S_act = second ? s1_act : s0_act;
+    c.act = S_act; c.kind = S_kind;
+    if (a.fnorm.enabled && S_kind == SRC_TENSOR) {
       c.fused = true;
       c.tab = q * 16 + sg * 4;                             // table index = padded channel of the concatenation
-    } else if (S.scale) {
-      c.sc = *reinterpret_cast<const f32x4*>(S.scale + ((size_t)n * S.cb + ql) * 16 + sg * 4);
-      c.sh = *reinterpret_cast<const f32x4*>(S.shift + ((size_t)n * S.cb + ql) * 16 + sg * 4);
+    } else if (S_scale) {
+      c.sc = *reinterpret_cast<const f32x4*>(S_scale + ((size_t)n * S_cb + ql) * 16 + sg * 4);
+      c.sh = *reinterpret_cast<const f32x4*>(S_shift + ((size_t)n * S_cb + ql) * 16 + sg * 4);
     }
-    c.base = reinterpret_cast<const char*>(S.kind == SRC_VECTOR ? S.data + ((size_t)n * S.cb + ql) * 16
-                                                                : S.data + ((size_t)n * S.cb + ql) * (size_t)in_px * 16);
+    c.base = reinterpret_cast<const char*>(S_kind == SRC_VECTOR ? S_data + ((size_t)n * S_cb + ql) * 16
+                                                                : S_data + ((size_t)n * S_cb + ql) * (size_t)in_px * 16);
     return c;
   };
   auto bind_table = [&](QuadCtx& c) {                      // after the table barrier
