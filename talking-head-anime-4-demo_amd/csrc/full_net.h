@@ -242,7 +242,7 @@ class FullModel {
       if (plan.ok && table_bytes && !tile_geom(g0, th, tw, plan.pg, tmb, plan.geom.tw_log2, table_bytes).ok) plan.ok = false;
       // a half-filled chip without K split: halve the output tile instead (the window is staged twice as often, but
       // no partial-sum traffic and no second launch)
-      if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles * max_batch < 200) {
+      if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles * max_batch < 200 && !std::getenv("THA4_NO_TMB_HALVE")) {
         const TilePlan p2 = plan_tile_conv(g0, th, tw, 2, mtiles * 2, nq, 256, max_batch);
         if (p2.ok && p2.ksplit == 1 && p2.pg >= plan.pg) { plan = p2; tmb = 2; mtiles *= 2; }
       }
