@@ -427,7 +427,7 @@ def full_extras(args, work, dev, world, fps, B):
     per_frame = None
     if prof and B == 1:
         per_frame = prof.get("cold_frame_bytes" if cold else "steady_frame_bytes")
-    roofline = {"bound": "mfma", "kernel": "whole frame (static schedule of conv_tile / conv_small / attention / image kernels)",
+    roofline = {"bound": "mfma", "kernel": "whole frame (static schedule of conv_tile / conv_small / conv_point / attention / image kernels)",
                 "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
                 "frac_of_split_ceiling": round(ach * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
                 "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
