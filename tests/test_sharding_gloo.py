@@ -1,7 +1,7 @@
 """N>1 path on CPU: world_size-2 gloo processes running the frame-sharded stream with a stub
 frame function (the sharding/gather logic is backend-agnostic; the GPU box runs it over RCCL)."""
 import os
-import socket
+import tempfile
 
 import pytest
 import torch
@@ -29,10 +29,10 @@ def _frame(i):
     return torch.rand(2, 4, 4, generator=g)
 
 
-def _worker(rank, world, port, total, chunk, gather, q, rgba8=False):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, rendezvous, total, chunk, gather, q, rgba8=False):
+    # file rendezvous: a TCP port picked by the parent can be taken by another process between its probe and the store's bind
+    os.environ["GLOO_SOCKET_IFNAME"] = os.environ.get("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
     calls = []
 
     def frame_fn(lo, hi):
@@ -53,27 +53,27 @@ def _to_u8(blk):
     return (blk.permute(0, 2, 3, 1) * 255.0).to(torch.uint8).contiguous()
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _run_two_ranks(total, chunk, gather, rgba8=False):
+    """Spawn the two ranks and collect {rank: (rank, local range, frame_fn calls, result)}."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_worker, args=(r, 2, os.path.join(d, "rendezvous"), total, chunk, gather, q, rgba8)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(2):
+            r = q.get(timeout=120)
+            res[r[0]] = r
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    return res
 
 
 @pytest.mark.parametrize("total,chunk", [(11, 4), (8, 8), (1, 4), (5, 1), (16, 4), (3, 8)])
 def test_two_rank_gather_reassembles_stream(total, chunk):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, chunk, True, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = {}
-    for _ in range(2):
-        r = q.get(timeout=120)
-        res[r[0]] = r
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_two_ranks(total, chunk, True)
     full = res[0][3]
     assert res[1][3] is None
     assert full.shape == (total, 2, 4, 4)
@@ -88,19 +88,7 @@ def test_two_rank_gather_reassembles_stream(total, chunk):
 
 
 def test_two_rank_no_gather_keeps_local_blocks():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 7, 3, False, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = {}
-    for _ in range(2):
-        r = q.get(timeout=120)
-        res[r[0]] = r
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_two_ranks(7, 3, False)
     for r in (0, 1):
         lo, hi = res[r][1]
         blk = res[r][3]
@@ -128,20 +116,8 @@ def test_preallocated_result_is_validated():
 
 def test_two_rank_rgba8_gather():
     """Display epilogue BEFORE the exchange: uint8 HWC frames gathered, same row placement."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
     total, chunk = 13, 4
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, chunk, True, q, True)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = {}
-    for _ in range(2):
-        r = q.get(timeout=120)
-        res[r[0]] = r
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_two_ranks(total, chunk, True, rgba8=True)
     full = res[0][3]
     assert full.dtype == torch.uint8 and full.shape == (total, 4, 4, 2)
     for i in range(total):
