@@ -219,6 +219,9 @@ def main():
     ap.add_argument("--d2h-frames", type=int, default=500, help="student N=1 B=1: steps for the RGBA8 + D2H inclusive measurement (0 = skip)")
     ap.add_argument("--exact-frames", type=int, default=500, help="student N=1 B=1: steps for the exact-fp32 generation A/B (0 = skip)")
     ap.add_argument("--full-frames", type=int, default=30, help="student N=1 B=1: frames of the appended full-model measurement (0 = skip)")
+    ap.add_argument("--settle-seconds", type=float, default=0.3,
+                    help="untimed frames posed for this long BEFORE the W warm-up steps, so that a short run (--steps 20 --warmup 5) "
+                         "is timed at the GPU's steady clocks like the stream it samples (0 = none)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,6 +252,11 @@ def main():
             torch.cuda.synchronize(dev)
 
     with torch.no_grad():
+        if args.settle_seconds > 0:                       # same frames as the warm-up steps, not counted anywhere
+            t_end = time.perf_counter() + args.settle_seconds
+            while time.perf_counter() < t_end:
+                timed_steps(work, 0, max(1, min(W, 8)))
+                torch.cuda.synchronize(dev)
         timed_steps(work, 0, W)
         if gather:
             from tha4_amd import image_io
@@ -288,7 +296,7 @@ def main():
             "metric": ("frames/sec (whole job) on 512x512 RGBA + 45-dim pose, " + ("distilled student" if student else "full THA4 model")),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE, "per_gpu_fps": round(fps / world, 2)}
+            "dtype": DTYPE, "per_gpu_fps": round(fps / world, 2), "settle_seconds": args.settle_seconds}
         par = {"frames_per_gpu": K * B, "batch": B, "parallelism": f"frame-parallel x{world}",
                "gather": ("rgba8" if args.rgba8_gather else "fp32") if gather else False}
         if student:
