@@ -270,6 +270,15 @@ def main():
                     work.step(W + (f - base) // B, out=blk[f - lo:f - lo + B])
                 return image_io.to_display_rgba8(blk) if args.rgba8_gather else blk
 
+            # untimed rehearsal of the exchange - one full gather round and one ragged tail per rank - so that RCCL's
+            # point-to-point connections (set up lazily on first use) exist before the clock starts
+            def rehearsal_fn(lo, hi):
+                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+                for f in range(0, hi - lo, B):
+                    work.step(0, out=blk[f:f + B])
+                return image_io.to_display_rgba8(blk) if args.rgba8_gather else blk
+
+            FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
             stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
             gathered = stream.allocate_result()       # rank 0: all frames - allocated outside the timed region
             barrier()
