@@ -211,7 +211,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed pose() calls per rank (default 200 student / 5 full)")
     ap.add_argument("--characters", default=None, help="student: lambda_00 | lambda_01 | alternate (by rank; default for --batch > 1)")
     ap.add_argument("--cold", action="store_true", help="full model, batch 1: the image changes every frame (no decomposer cache)")
-    ap.add_argument("--gather-chunk", type=int, default=32, help="frames per gather round (N>1; rounded to a multiple of --batch)")
+    ap.add_argument("--gather-chunk", type=int, default=None,
+                    help="frames per gather round (N>1; rounded to a multiple of --batch; default: a fifth of the rank's frames, "
+                         "at most 32 - a short run still overlaps its exchange with compute)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gather of finished frames")
     ap.add_argument("--rgba8-gather", action="store_true", help="N>1: display epilogue (sRGB, uint8 HWC) before the gather: 4x fewer bytes")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget in seconds of CPU work (0 disables; N=1 only)")
@@ -260,7 +262,8 @@ def main():
         timed_steps(work, 0, W)
         if gather:
             from tha4_amd import image_io
-            chunk = max(B, args.gather_chunk // B * B)
+            want_chunk = args.gather_chunk if args.gather_chunk is not None else min(32, max(1, K * B // 5))
+            chunk = max(B, want_chunk // B * B)
             shape, dtype = ((512, 512, 4), torch.uint8) if args.rgba8_gather else ((4, 512, 512), torch.float32)
 
             def frame_fn(lo, hi):          # global frame ids of this rank start at rank*K*B; whole steps only
