@@ -201,6 +201,76 @@ def timed_steps(work, lo, hi):
     return out
 
 
+def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False):
+    """Settle, W warm-up steps, then EXACTLY K timed steps between barriers (N > 1: with the gather of the finished frames to
+    rank 0 inside the timed region, after an untimed rehearsal of the exchange).  Returns this rank's elapsed seconds (and, for
+    the tests, what rank 0 gathered).  Device-agnostic: tests/test_bench_stream_gloo.py runs it on CPU tensors over gloo."""
+    cuda = dev.type == "cuda"
+    gather = world > 1 and not args.no_gather
+    frames = None
+
+    def barrier():
+        if cuda:
+            torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            if cuda:
+                torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        if args.settle_seconds > 0:                       # same frames as the warm-up steps, not counted anywhere
+            t_end = time.perf_counter() + args.settle_seconds
+            while time.perf_counter() < t_end:
+                timed_steps(work, 0, max(1, min(W, 8)))
+                if cuda:
+                    torch.cuda.synchronize(dev)
+        timed_steps(work, 0, W)
+        if gather:
+            want_chunk = args.gather_chunk if args.gather_chunk is not None else min(32, max(1, K * B // 5))
+            chunk = max(B, want_chunk // B * B)
+            shape, dtype = ((512, 512, 4), torch.uint8) if args.rgba8_gather else ((4, 512, 512), torch.float32)
+
+            def finish(blk):
+                if not args.rgba8_gather:
+                    return blk
+                from tha4_amd import image_io
+                return image_io.to_display_rgba8(blk)
+
+            def frame_fn(lo, hi):          # global frame ids of this rank start at rank*K*B; whole steps only
+                base = rank * K * B
+                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+                for f in range(lo, hi, B):                                   # straight into the gather block
+                    work.step(W + (f - base) // B, out=blk[f - lo:f - lo + B])
+                return finish(blk)
+
+            # untimed rehearsal of the exchange - one full gather round and one ragged tail per rank - so that RCCL's
+            # point-to-point connections (set up lazily on first use) exist before the clock starts
+            def rehearsal_fn(lo, hi):
+                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+                for f in range(0, hi - lo, B):
+                    work.step(0, out=blk[f:f + B])
+                return finish(blk)
+
+            FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
+            stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
+            gathered = stream.allocate_result()       # rank 0: all frames - allocated outside the timed region
+            barrier()
+            t0 = time.perf_counter()
+            gathered = stream.run(gathered)
+            barrier()
+            t1 = time.perf_counter()
+            if return_frames:
+                frames = gathered
+            del gathered
+        else:
+            barrier()
+            t0 = time.perf_counter()
+            timed_steps(work, W, W + K)
+            barrier()
+            t1 = time.perf_counter()
+    return (t1 - t0, frames) if return_frames else t1 - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", choices=["student", "full"], default="student",
@@ -247,56 +317,7 @@ def main():
     work = StudentWork(dev, rank, B, K + W, characters) if student else FullWork(dev, rank, B, K + W, steady=not args.cold)
     gather = world > 1 and not args.no_gather
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    with torch.no_grad():
-        if args.settle_seconds > 0:                       # same frames as the warm-up steps, not counted anywhere
-            t_end = time.perf_counter() + args.settle_seconds
-            while time.perf_counter() < t_end:
-                timed_steps(work, 0, max(1, min(W, 8)))
-                torch.cuda.synchronize(dev)
-        timed_steps(work, 0, W)
-        if gather:
-            from tha4_amd import image_io
-            want_chunk = args.gather_chunk if args.gather_chunk is not None else min(32, max(1, K * B // 5))
-            chunk = max(B, want_chunk // B * B)
-            shape, dtype = ((512, 512, 4), torch.uint8) if args.rgba8_gather else ((4, 512, 512), torch.float32)
-
-            def frame_fn(lo, hi):          # global frame ids of this rank start at rank*K*B; whole steps only
-                base = rank * K * B
-                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
-                for f in range(lo, hi, B):                                   # straight into the gather block
-                    work.step(W + (f - base) // B, out=blk[f - lo:f - lo + B])
-                return image_io.to_display_rgba8(blk) if args.rgba8_gather else blk
-
-            # untimed rehearsal of the exchange - one full gather round and one ragged tail per rank - so that RCCL's
-            # point-to-point connections (set up lazily on first use) exist before the clock starts
-            def rehearsal_fn(lo, hi):
-                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
-                for f in range(0, hi - lo, B):
-                    work.step(0, out=blk[f:f + B])
-                return image_io.to_display_rgba8(blk) if args.rgba8_gather else blk
-
-            FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
-            stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
-            gathered = stream.allocate_result()       # rank 0: all frames - allocated outside the timed region
-            barrier()
-            t0 = time.perf_counter()
-            gathered = stream.run(gathered)
-            barrier()
-            t1 = time.perf_counter()
-            del gathered
-        else:
-            barrier()
-            t0 = time.perf_counter()
-            timed_steps(work, W, W + K)
-            barrier()
-            t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = measure(work, args, dev, rank, world, K, W, B, dist)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,0 +1,73 @@
+"""bench.py's measured section (`bench.measure`) at N = 2 on CPU tensors over gloo: settle + warm-up + untimed rehearsal of the
+exchange + the timed sharded stream.  Checks what the driver's multi-GPU run relies on: every timed step is executed exactly
+once by the rank that owns it, rank 0 receives frame f at row f whichever rank made it (full rounds and the ragged tail), and
+the warm-up / rehearsal frames never reach the result."""
+import argparse
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _StubWork:
+    """stands in for StudentWork / FullWork: step i of rank r writes the constant 1000 r + i into its B frames"""
+
+    def __init__(self, rank, B):
+        self.rank, self.B, self.calls = rank, B, []
+
+    def step(self, i, out=None):
+        self.calls.append(i)
+        if out is None:
+            out = torch.empty(self.B, 4, 512, 512)
+        out.fill_(1000.0 * self.rank + i)
+        return out
+
+
+def _worker(rank, world, rendezvous, K, W, B, chunk, q):
+    os.environ["GLOO_SOCKET_IFNAME"] = os.environ.get("GLOO_SOCKET_IFNAME", "lo")
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
+    work = _StubWork(rank, B)
+    args = argparse.Namespace(no_gather=False, rgba8_gather=False, gather_chunk=chunk, settle_seconds=0.01)
+    elapsed, frames = bench.measure(work, args, torch.device("cpu"), rank, world, K, W, B, dist, return_frames=True)
+    rows = None if frames is None else frames[:, 0, 0, 0].clone()
+    uniform = None if frames is None else bool((frames == frames[:, :1, :1, :1]).all())
+    q.put((rank, elapsed, work.calls, rows, uniform))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,W,B,chunk", [(7, 2, 1, None), (5, 1, 2, 4), (20, 5, 1, None)])
+def test_measure_two_ranks(K, W, B, chunk):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_worker, args=(r, 2, os.path.join(d, "rendezvous"), K, W, B, chunk, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(2):
+            r = q.get(timeout=240)
+            res[r[0]] = r
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    for r in (0, 1):
+        _, elapsed, calls, rows, uniform = res[r]
+        assert elapsed > 0
+        timed = [i for i in calls if i >= W]
+        assert timed == list(range(W, W + K))                    # every timed step once, in order, on its own rank
+        assert all(i < W for i in calls[:len(calls) - K])          # everything before: settle / warm-up / rehearsal steps
+    rows, uniform = res[0][3], res[0][4]
+    assert res[1][3] is None and uniform
+    assert rows.shape[0] == 2 * K * B
+    for f in range(2 * K * B):
+        r, j = divmod(f, K * B)
+        assert rows[f].item() == 1000.0 * r + W + j // B           # frame f at row f, made by rank r at its step W + j // B
