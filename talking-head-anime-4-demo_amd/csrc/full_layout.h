@@ -181,10 +181,17 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   const int npx = t.win_h * t.win_w;
   if (npx * 4 > 5 * 512) return t;                     // kTileMaxItems staging items per thread
   t.taps_per_chunk = 1;
-  for (int d = 1; d <= g.ntaps; ++d)
-    if (g.ntaps % d == 0 && d <= 4 && d * TMB * 2048 <= 32 * 1024) t.taps_per_chunk = d;
+  // One chunk barrier per streamed weight chunk: whole K groups (9 taps of a 3x3, 8 of the 16 of a 4x4) per chunk where two
+  // ring slots of that size fit beside the window, else up to 4 taps / 32 KiB (measured: 155.9 -> 158.4 fps, batch 8 294.7 -> 297.3)
+  const int taps_max = std::getenv("THA4_TILE_TAPS_MAX") ? std::atoi(std::getenv("THA4_TILE_TAPS_MAX")) : 9;            // tuning aid
+  const int slot_max = std::getenv("THA4_TILE_SLOT_MAX_KB") ? std::atoi(std::getenv("THA4_TILE_SLOT_MAX_KB")) * 1024 : 72 * 1024;
   const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
-  const size_t slot = (size_t)t.taps_per_chunk * TMB * 2048, red = 8 * (size_t)TMB * 16 * 2 * sizeof(float);
+  const size_t red = 8 * (size_t)TMB * 16 * 2 * sizeof(float);
+  for (int d = 1; d <= g.ntaps; ++d)                     // the largest chunk that still leaves room for two ring slots
+    if (g.ntaps % d == 0 && d <= taps_max && (size_t)d * TMB * 2048 <= (size_t)slot_max &&
+        ((d <= 4 && (size_t)d * TMB * 2048 <= 32 * 1024) || 8 * plane + 2 * (size_t)d * TMB * 2048 + red + extra_lds <= 160 * 1024))
+      t.taps_per_chunk = d;
+  const size_t slot = (size_t)t.taps_per_chunk * TMB * 2048;
   // deeper while it costs no occupancy: never push a workgroup that fits twice on a CU (<= 80 KiB) over that line
   t.ring_slots = 2;
   const size_t base = 8 * plane + 2 * slot + red + extra_lds;     // extra_lds: scale/shift table of a fused normalisation
