@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   const int slot_bytes = a.taps_per_chunk * TMB * 2048;
   char* win_hi = smem;
   char* win_lo = smem + 4 * PLANE;
-  char* ring = smem + 8 * PLANE;
+  const int WB = a.win_buffers == 2 ? 8 * PLANE : 0;      // byte distance of the second window buffer (0: single-buffered)
+  char* ring = smem + 8 * PLANE + WB;
   const int D = a.ring_slots;                                            // ring depth (2..4)
   float* red = reinterpret_cast<float*>(ring + D * slot_bytes);          // [8 waves][TMB*16][2]
   // normalisation folded into this kernel (FusedNorm): per-channel scale | shift table behind `red`
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       rawB[k] = load_quad(cB, gofs.v[k]);
     }
   };
-  auto write_window = [&](const Offsets gofs) {
+  auto write_window = [&](const Offsets gofs, int wofs) {   // wofs: byte offset of the window buffer written
 #pragma unroll
     for (int k = 0; k < kTileMaxItems; ++k) {
       const int item = tid + k * kTileThreads;
@@ -300,8 +301,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         lo[4 + j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[4 + j], vb[j]);
       }
       const int off = sg * PLANE + (item >> 2) * 16;
-      *reinterpret_cast<f16x8*>(win_hi + off) = hi;
-      *reinterpret_cast<f16x8*>(win_lo + off) = lo;
+      *reinterpret_cast<f16x8*>(win_hi + wofs + off) = hi;
+      *reinterpret_cast<f16x8*>(win_lo + wofs + off) = lo;
     }
   };
 
@@ -339,13 +340,14 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     }
     load_window(q_begin, go);
     THA4_CSTAMP();                                         // 1: first window loads issued
-    write_window(go);
+    write_window(go, 0);
     THA4_CSTAMP();                                         // 2: first window written
   }
   __syncthreads();
   THA4_CSTAMP();                                           // 3: prologue barrier passed
   for (int Q = q_begin; Q < q_end; ++Q) {
     if (Q + 1 < q_end) load_window(Q + 1, go);
+    const int rd = ((Q - q_begin) & 1) ? WB : 0;          // window buffer of this K group
     for (int tc = 0; tc < ntc; ++tc) {
       if (issued < nchunks) {                              // refill the slot freed by the previous barrier
         fetch(issued++, islot);
@@ -358,8 +360,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         f16x8 bh[PG], bl[PG];
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) {
-          bh[pg] = *reinterpret_cast<const f16x8*>(win_hi + boff[pg] + toff);
-          bl[pg] = *reinterpret_cast<const f16x8*>(win_lo + boff[pg] + toff);
+          bh[pg] = *reinterpret_cast<const f16x8*>(win_hi + rd + boff[pg] + toff);
+          bl[pg] = *reinterpret_cast<const f16x8*>(win_lo + rd + boff[pg] + toff);
         }
         if (TMB == 4) {
           // all A fragments of the tap are requested together with the B fragments: one LDS wait per tap instead of one per
@@ -396,6 +398,9 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         }
       }
       THA4_CSTAMP();                                       // chunk MFMAs issued
+      // double-buffered window: K group Q+1 is written into the other buffer BEFORE the last chunk barrier of Q, which then
+      // also publishes it - one barrier per K group less, and the write overlaps the other waves' last MFMAs
+      if (WB && tc == ntc - 1 && Q + 1 < q_end) write_window(go, WB - rd);
       // every wave must (a) be done reading this slot and (b) have ITS pieces of the NEXT chunk in LDS; the chunks fetched
       // after that one (ring deeper than two slots) may stay in flight: at least keep_per_chunk glds per younger chunk
       {
@@ -407,8 +412,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       slot = slot + 1 == D ? 0 : slot + 1;
       ++chunk;
     }
-    if (Q + 1 < q_end) {
-      write_window(go);                                    // every wave has finished reading window Q (barrier above)
+    if (!WB && Q + 1 < q_end) {
+      write_window(go, 0);                                 // every wave has finished reading window Q (barrier above)
       THA4_CSTAMP();                                       // next window written
       __syncthreads();
       THA4_CSTAMP();                                       // window barrier passed

@@ -81,6 +81,7 @@ struct ConvArgs {
   int win_dy0, win_dx0;  // window origin relative to (tile origin * in_stride)
   int taps_per_chunk;    // taps per streamed weight chunk (divides ntaps)
   int ring_slots;        // depth of the LDS weight ring (2..4)
+  int win_buffers;       // 1: one LDS window, rewritten behind its own barrier; 2: double-buffered (the write of K group Q+1 precedes Q's last chunk barrier)
   float* partial;        // split-K workspace [ksplit][batch][mtile][tile][TMB][8*PG][64] f32x4, or null
   int ksplit;            // K splits (phase 1 grid z)
   int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue

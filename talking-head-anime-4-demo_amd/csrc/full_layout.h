@@ -159,6 +159,7 @@ struct TileGeom {
   int win_h = 0, win_w = 0, dy0 = 0, dx0 = 0;
   int taps_per_chunk = 1;
   int ring_slots = 2;            // LDS weight ring depth: as deep (<= 4) as the LDS left by the window allows
+  int win_buffers = 1;           // 2: the window is double-buffered (one barrier per K group less)
   size_t lds = 0;
 };
 inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB, int tw_log2, size_t extra_lds = 0) {
@@ -194,10 +195,13 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   const size_t slot = (size_t)t.taps_per_chunk * TMB * 2048;
   // deeper while it costs no occupancy: never push a workgroup that fits twice on a CU (<= 80 KiB) over that line
   t.ring_slots = 2;
-  const size_t base = 8 * plane + 2 * slot + red + extra_lds;     // extra_lds: scale/shift table of a fused normalisation
+  // second window buffer where it fits beside two ring slots (PG <= 2 tiles)
+  t.win_buffers = (!std::getenv("THA4_NO_DOUBLE_WINDOW") && 16 * plane + 2 * slot + red + extra_lds <= 160 * 1024) ? 2 : 1;
+  const size_t win = 8 * plane * t.win_buffers;
+  const size_t base = win + 2 * slot + red + extra_lds;           // extra_lds: scale/shift table of a fused normalisation
   const size_t cap = base <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
-  while (t.ring_slots < 4 && 8 * plane + (t.ring_slots + 1) * slot + red + extra_lds <= cap) ++t.ring_slots;
-  t.lds = 8 * plane + t.ring_slots * slot + red + extra_lds;
+  while (t.ring_slots < 4 && win + (t.ring_slots + 1) * slot + red + extra_lds <= cap) ++t.ring_slots;
+  t.lds = win + t.ring_slots * slot + red + extra_lds;
   t.ok = t.lds <= 160 * 1024;
   return t;
 }

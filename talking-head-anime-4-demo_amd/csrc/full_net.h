@@ -347,6 +347,7 @@ class FullModel {
         lds = tg.lds;
         a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
         a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots;
+        a.win_buffers = tg.win_buffers;
         if (!tg.ok) { if (error.empty()) error = "conv tile geometry differs between parity classes"; return FTensor(); }
       } else {
         w_off = add_param(pack_conv_weight(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb));

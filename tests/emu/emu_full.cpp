@@ -225,7 +225,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       float inv = 1.f;
       P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb, &inv);
       a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
-      a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots;
+      a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots; a.win_buffers = tg.win_buffers;
     }
     if (point) {
       float inv = 1.f;
