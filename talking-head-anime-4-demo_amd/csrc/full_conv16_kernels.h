@@ -398,12 +398,10 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         }
       }
       THA4_CSTAMP();                                       // chunk MFMAs issued
-      // double-buffered window: K group Q+1 is written into the other buffer BEFORE the last chunk barrier of Q, which then
-      // also publishes it - one barrier per K group less, and the write overlaps the other waves' last MFMAs
-      if (WB && tc == ntc - 1 && Q + 1 < q_end) write_window(go, WB - rd);
       // every wave must (a) be done reading this slot and (b) have ITS pieces of the NEXT chunk in LDS; the chunks fetched
-      // after that one (ring deeper than two slots) may stay in flight: at least keep_per_chunk glds per younger chunk
-      {
+      // after that one (ring deeper than two slots) may stay in flight: at least keep_per_chunk glds per younger chunk.
+      // Double-buffered window: the LAST chunk barrier of the K group is deferred behind the window write below
+      if (!(WB && tc == ntc - 1)) {
         const int younger = issued - chunk - 2;            // chunks requested after chunk + 1
         const int keep = THA4_TILE_COUNTED_WAIT && younger > 0 ? min(8, younger * keep_per_chunk) : 0;
         THA4_BARRIER_KEEP(keep);
@@ -412,12 +410,14 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       slot = slot + 1 == D ? 0 : slot + 1;
       ++chunk;
     }
-    if (!WB && Q + 1 < q_end) {
-      write_window(go, 0);                                 // every wave has finished reading window Q (barrier above)
-      THA4_CSTAMP();                                       // next window written
-      __syncthreads();
-      THA4_CSTAMP();                                       // window barrier passed
-    }
+    // single window: every wave has finished reading window Q (last chunk barrier), K group Q+1 overwrites it behind its own
+    // barrier.  Double-buffered: Q+1 goes into the OTHER buffer (nobody reads it during K group Q) before the deferred last
+    // chunk barrier, which then also publishes it - one barrier per K group less, and the write overlaps the other waves'
+    // last MFMAs.  (ONE call site of write_window: a second one inside the chunk loop cost 90 VGPRs and 17 % fps.)
+    if (Q + 1 < q_end) write_window(go, WB ? WB - rd : 0);
+    THA4_CSTAMP();                                         // next window written
+    if (WB || Q + 1 < q_end) __syncthreads();
+    THA4_CSTAMP();                                         // window barrier passed
   }
 
   // ---- split-K: phase 1 publishes the partial fragments, phase 2 adds them in split order ----------------
