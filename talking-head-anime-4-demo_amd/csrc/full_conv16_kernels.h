@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   const int q_per = (NQ + ksplit - 1) / ksplit;
   int q_begin = ks * q_per;
   const int q_end = min(NQ, q_begin + q_per);              // this workgroup's K groups
-  const int ntc = a.ntaps / a.taps_per_chunk;            // weight chunks per K group
+  const int ntc = (a.ntaps + a.taps_per_chunk - 1) / a.taps_per_chunk;   // weight chunks per K group (the last one may be shorter: 9 = 5 + 4)
   const int slot_bytes = a.taps_per_chunk * TMB * 2048;
   char* win_hi = smem;
   char* win_lo = smem + 4 * PLANE;
@@ -208,11 +208,13 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   }
 
   // glds instructions EVERY wave issues per chunk (wave w issues ceil((pieces - w) / 8)): the lower bound the counted barrier uses
-  const int keep_per_chunk = (a.taps_per_chunk * TMB * 2) / kTileWaves;
-  auto fetch = [&](int chunk, int slot) {
-    const char* src = gw + (size_t)chunk * slot_bytes;
+  const int keep_per_chunk = ((a.ntaps - (ntc - 1) * a.taps_per_chunk) * TMB * 2) / kTileWaves;     // (of the shortest chunk)
+  auto fetch = [&](int chunk, int slot) {                  // chunk = K group * ntc + chunk of the group
+    const int cq = chunk / ntc, ct = chunk - cq * ntc;
+    const int t0 = ct * a.taps_per_chunk, nt = min(a.taps_per_chunk, a.ntaps - t0);
+    const char* src = gw + ((size_t)cq * a.ntaps + t0) * TMB * 2048;
     char* dst = ring + slot * slot_bytes;
-    const int pieces = a.taps_per_chunk * TMB * 2;
+    const int pieces = nt * TMB * 2;
     for (int pc = wave; pc < pieces; pc += kTileWaves) glds16(src + pc * 1024 + lane * 16, dst + pc * 1024);
   };
 
@@ -354,7 +356,8 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         islot = islot + 1 == D ? 0 : islot + 1;
       }
       const char* wsl = ring + slot * slot_bytes + lane * 16;
-      for (int tt = 0; tt < a.taps_per_chunk; ++tt) {
+      const int taps_here = min(a.taps_per_chunk, a.ntaps - tc * a.taps_per_chunk);
+      for (int tt = 0; tt < taps_here; ++tt) {
         const int t = tc * a.taps_per_chunk + tt;
         const int toff = lane_pick(my_toff, t);
         f16x8 bh[PG], bl[PG];

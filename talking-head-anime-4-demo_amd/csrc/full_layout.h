@@ -188,10 +188,18 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   const int slot_max = std::getenv("THA4_TILE_SLOT_MAX_KB") ? std::atoi(std::getenv("THA4_TILE_SLOT_MAX_KB")) * 1024 : 72 * 1024;
   const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
   const size_t red = 8 * (size_t)TMB * 16 * 2 * sizeof(float);
-  for (int d = 1; d <= g.ntaps; ++d)                     // the largest chunk that still leaves room for two ring slots
-    if (g.ntaps % d == 0 && d <= taps_max && (size_t)d * TMB * 2048 <= (size_t)slot_max &&
-        ((d <= 4 && (size_t)d * TMB * 2048 <= 32 * 1024) || 8 * plane + 2 * (size_t)d * TMB * 2048 + red + extra_lds <= 160 * 1024))
+  // the largest chunk that still leaves room for two ring slots; chunks need not divide the taps (9 = 5 + 4: two barriers
+  // instead of three for the four-block tiles), but a chunk size is only taken if it lowers the chunk count
+  const bool uneven = std::getenv("THA4_TILE_EVEN_CHUNKS") == nullptr;     // tuning aid (measured: 157.15 -> 157.75 fps with 5 + 4)
+  int best_chunks = g.ntaps + 1;
+  for (int d = 1; d <= g.ntaps; ++d) {
+    const int chunks = (g.ntaps + d - 1) / d;
+    if ((uneven || g.ntaps % d == 0) && d <= taps_max && (size_t)d * TMB * 2048 <= (size_t)slot_max && chunks < best_chunks &&
+        ((d <= 4 && (size_t)d * TMB * 2048 <= 32 * 1024) || 8 * plane + 2 * (size_t)d * TMB * 2048 + red + extra_lds <= 160 * 1024)) {
       t.taps_per_chunk = d;
+      best_chunks = chunks;
+    }
+  }
   const size_t slot = (size_t)t.taps_per_chunk * TMB * 2048;
   // deeper while it costs no occupancy: never push a workgroup that fits twice on a CU (<= 80 KiB) over that line
   t.ring_slots = 2;

@@ -284,7 +284,7 @@ def test_tile_conv_launch_plans(lib):
         assert tiles == -(-th // tile_h) * -(-tw // (1 << twl))
         assert win_h * win_w * 4 <= 5 * 512 and lds <= 160 * 1024 and 2 <= slots <= 4
         ntaps = {0: k * k, 1: 16, 2: 4}[kind]
-        assert ntaps % tpc == 0 and tpc <= 9 and (tpc <= 4 or tpc * tmb * 2048 <= 72 * 1024)   # whole K groups per chunk where the ring fits
+        assert 1 <= tpc <= min(9, ntaps) and (tpc <= 4 or tpc * tmb * 2048 <= 72 * 1024)   # whole K groups per chunk where the ring fits, else 5 + 4
         assert 1 <= ksplit <= min(nq, 16)
         per = -(-nq // ksplit)
         assert (ksplit - 1) * per < nq                     # every split owns at least one K group
