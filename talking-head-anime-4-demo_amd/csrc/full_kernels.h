@@ -646,21 +646,34 @@ struct NormArgs {
   long long film0_stride, film1_stride;
   float* scale[2];         // outputs per source, [n][cb*16]
   float* shift[2];
+  int cpb;                 // padded channels per workgroup (a multiple of the group size; blockIdx.y selects the range)
 };
 
 constexpr int kNormThreads = 1024;
+// channels per workgroup: whole GroupNorm groups, at least 32 channels, about an eighth of the tensor - a large map has
+// 256-512 tiles per channel, and the more tile slices a workgroup's 1024 threads form the fewer dependent load rounds each
+// thread pays (one workgroup per frame: 8-16 rounds; 4-8 workgroups: 2)
+inline int norm_channels_per_block(int ctot, int channels, int groups) {
+  const int gs = groups > 0 ? channels / groups : 1;
+  const int want = ctot / 8 > 32 ? ctot / 8 : 32;
+  int cpb = (want + gs - 1) / gs * gs;
+  return cpb < ctot ? cpb : ctot;
+}
 __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a) {
   THA4_DYN_LDS(smem);
   const int n = blockIdx.x;
   const int c0 = a.cb[0] * 16;
-  const int ctot = c0 + (a.nsrc > 1 ? a.cb[1] * 16 : 0);
+  const int ctot_all = c0 + (a.nsrc > 1 ? a.cb[1] * 16 : 0);
+  const int cbeg = blockIdx.y * a.cpb;                       // this workgroup's channels [cbeg, cbeg + ctot)
+  const int ctot = min(a.cpb, ctot_all - cbeg);
   // thread (slice, c): channel c = t % ctot sums tiles slice, slice+S, ... in fp64; consecutive threads read
   // consecutive channels of one tile row (coalesced).  Slices are then combined in a fixed order: deterministic.
   const int S = max(1, kNormThreads / ctot);                 // tile slices (ctot <= 1024)
   double* part = reinterpret_cast<double*>(smem);            // [S][ctot][2]
   double* csum = part + (size_t)S * ctot * 2;                // [ctot]
   double* csq = csum + ctot;
-  for (int c = threadIdx.x % ctot, sl = threadIdx.x / ctot; sl < S && c < ctot; sl += kNormThreads) {   // one pass (S*ctot <= threads)
+  for (int cl0 = threadIdx.x % ctot, sl = threadIdx.x / ctot; sl < S && cl0 < ctot; sl += kNormThreads) {   // one pass (S*ctot <= threads)
+    const int c = cbeg + cl0;
     const int s = c < c0 ? 0 : 1;
     const int cl = c - (s ? c0 : 0);
     const int cw = a.cb[s] * 16;
@@ -683,33 +696,34 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
       su[0] += (double)v[0];
       sq[0] += (double)v[1];
     }
-    part[((size_t)sl * ctot + c) * 2] = (su[0] + su[1]) + (su[2] + su[3]);
-    part[((size_t)sl * ctot + c) * 2 + 1] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+    part[((size_t)sl * ctot + cl0) * 2] = (su[0] + su[1]) + (su[2] + su[3]);
+    part[((size_t)sl * ctot + cl0) * 2 + 1] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < ctot; c += kNormThreads) {
+  for (int cl0 = threadIdx.x; cl0 < ctot; cl0 += kNormThreads) {
     double su = 0.0, sq = 0.0;
-    for (int sl = 0; sl < S; ++sl) { su += part[((size_t)sl * ctot + c) * 2]; sq += part[((size_t)sl * ctot + c) * 2 + 1]; }
-    csum[c] = su;
-    csq[c] = sq;
+    for (int sl = 0; sl < S; ++sl) { su += part[((size_t)sl * ctot + cl0) * 2]; sq += part[((size_t)sl * ctot + cl0) * 2 + 1]; }
+    csum[cl0] = su;
+    csq[cl0] = sq;
   }
   __syncthreads();
   // logical channel index of padded channel c: source 0 holds channels [0, C0real), source 1 the rest.
   // Both sources are exact multiples of 16 whenever two are concatenated (unet.py skip widths).
-  for (int c = threadIdx.x; c < ctot; c += kNormThreads) {
+  for (int cl0 = threadIdx.x; cl0 < ctot; cl0 += kNormThreads) {
+    const int c = cbeg + cl0;
     const int s = c < c0 ? 0 : 1;
     const int cl = c - (s ? c0 : 0);
     float sc = 0.f, sh = 0.f;
     if (c < a.channels) {
       double mean, var;
       if (a.groups == 0) {
-        mean = csum[c] * a.inv_count;
-        var = csq[c] * a.inv_count - mean * mean;
+        mean = csum[cl0] * a.inv_count;
+        var = csq[cl0] * a.inv_count - mean * mean;
       } else {
         const int gs = a.channels / a.groups;
-        const int gi = c / gs;
+        const int gi = c / gs;                               // (the workgroup's range holds whole groups: cpb is a multiple of gs)
         double su = 0.0, sq = 0.0;
-        for (int k = gi * gs; k < (gi + 1) * gs; ++k) { su += csum[k]; sq += csq[k]; }
+        for (int k = gi * gs; k < (gi + 1) * gs; ++k) { su += csum[k - cbeg]; sq += csq[k - cbeg]; }
         mean = su * a.inv_count / gs;
         var = sq * a.inv_count / gs - mean * mean;
       }

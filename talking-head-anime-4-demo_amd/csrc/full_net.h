@@ -474,8 +474,11 @@ class FullModel {
       a.gamma = P(g_off); a.beta = P(b_off);
       a.film0 = film0_off == kNone ? nullptr : P(film0_off); a.film0_stride = 0;
       a.film1 = film1_off == kNone ? nullptr : Wk(film1_off); a.film1_stride = film1_stride;
-      const int ctot = cbt * 16, S = std::max(1, kNormThreads / ctot);
-      hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch), dim3(kNormThreads), ((size_t)S * ctot * 2 + 2 * ctot) * sizeof(double), f.stream, a);
+      const int ctot = cbt * 16;
+      a.cpb = std::getenv("THA4_NORM_ONE_WG") ? ctot : norm_channels_per_block(ctot, channels, groups);
+      const int S = std::max(1, kNormThreads / a.cpb);
+      hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch, (ctot + a.cpb - 1) / a.cpb), dim3(kNormThreads),
+                         ((size_t)S * a.cpb * 2 + 2 * a.cpb) * sizeof(double), f.stream, a);
     });
     return out;
   }

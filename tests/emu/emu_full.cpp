@@ -330,9 +330,11 @@ int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float
   a.film0 = M.up(film0, (size_t)n * 2 * channels); a.film1 = M.up(film1, (size_t)n * 2 * channels);
   a.film0_stride = 2 * channels; a.film1_stride = 2 * channels;
   a.scale[0] = M.up(o0); a.shift[0] = M.up(h0); a.scale[1] = M.up(o1); a.shift[1] = M.up(h1);
-  const int ctot = (cb0 + (nsrc > 1 ? cb1 : 0)) * 16, S = std::max(1, kNormThreads / ctot);
-  const size_t lds = ((size_t)S * ctot * 2 + 2 * ctot) * sizeof(double);
-  THA4_RUN(norm_finalize_kernel, dim3(n), kNormThreads, lds, a);
+  const int ctot = (cb0 + (nsrc > 1 ? cb1 : 0)) * 16;
+  a.cpb = norm_channels_per_block(ctot, channels, groups);
+  const int S = std::max(1, kNormThreads / a.cpb);
+  const size_t lds = ((size_t)S * a.cpb * 2 + 2 * a.cpb) * sizeof(double);
+  THA4_RUN(norm_finalize_kernel, dim3(n, (ctot + a.cpb - 1) / a.cpb), kNormThreads, lds, a);
   if (M.sync() != 0) return -9;
   M.down(o0); M.down(h0); M.down(o1); M.down(h1);
   std::memcpy(scale0, o0.data(), o0.size() * sizeof(float));
