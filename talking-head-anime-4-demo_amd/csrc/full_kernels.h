@@ -103,6 +103,15 @@ THA4_DEV float fast_sigmoid(float v) {
 #endif
 }
 
+// e^v on v_exp_f32 (2^x): ~2 ulp relative; the softmax weights of attention_kernel (libm's expf is ~20 instructions)
+THA4_DEV float fast_exp(float v) {
+#ifdef THA4_EMU
+  return expf(v);
+#else
+  return __builtin_amdgcn_exp2f(v * 1.4426950408889634f);
+#endif
+}
+
 // tanh on the same two transcendentals: sign(v) (1 - e) / (1 + e), e = 2^(-2 |v| log2 e).  Absolute error ~1e-7 (the
 // cancellation in 1 - e near 0 costs relative, not absolute, accuracy; outputs are O(1) colour changes).  libm's tanhf
 // is ~150 instructions and was inlined at every activation site - four per 16-byte item, in the staging loops of every
@@ -788,12 +797,16 @@ struct AttnArgs {
 };
 
 constexpr int kAttnHeadDim = 32;     // 256 channels / 8 heads (mode_07.py:222-224,253-255)
-constexpr int kAttnQueries = 32;     // query tokens per workgroup
-constexpr int kAttnSlices = 8;       // key slices per query (8 consecutive lanes share a query)
-constexpr int kAttnRow = kAttnHeadDim / 4 + 1;   // f32x4 per K/V row in LDS (+1: slices 8 rows apart would share banks)
-constexpr int kAttnMaxKeys = 32;     // keys per slice held in registers: tokens <= 256
+#ifndef THA4_ATTN_SLICES
+#define THA4_ATTN_SLICES 16
+#endif
+constexpr int kAttnSlices = THA4_ATTN_SLICES;    // key slices per query (consecutive lanes share a query): 16 -> 128 workgroups of 16
+                                                  // queries for the 16x16 maps instead of 64 of 32 (13.8 -> ~10 us per launch)
+constexpr int kAttnQueries = 256 / kAttnSlices;  // query tokens per workgroup
+constexpr int kAttnRow = kAttnHeadDim / 4 + 1;   // f32x4 per K/V row in LDS (+1: consecutive rows, read by consecutive slices, on distinct banks)
+constexpr int kAttnMaxKeys = 256 / kAttnSlices;  // keys per slice held in registers: tokens <= 256
 
-// grid (heads, frames, tokens / 32), 256 threads: thread (query ql = t>>3, slice sl = t&7) scores keys sl, sl+8, ...
+// grid (heads, frames, tokens / kAttnQueries), 256 threads: thread (query ql = t / S, slice sl = t % S; S = kAttnSlices) scores keys sl, sl+S, ...
 // against its query, takes the slice maximum, accumulates exp-weighted values, and the 8 slices of a query are merged
 // with lane shuffles (max first, then one rescale per slice) - a fixed order.
 __global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
@@ -803,7 +816,7 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
   f32x4* ks = reinterpret_cast<f32x4*>(smem);   // [L][kAttnRow]
   f32x4* vs = ks + L * kAttnRow;                // [L][kAttnRow]
   const int n = blockIdx.y, h = blockIdx.x, t = threadIdx.x;
-  const int ql = t >> 3, sl = t & 7;
+  const int ql = t / kAttnSlices, sl = t % kAttnSlices;
   const int tq = blockIdx.z * kAttnQueries + ql;
   const int cbq = a.channels / 16;
   const float scale = 1.0f / sqrtf(sqrtf((float)CH));
@@ -844,7 +857,7 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
     m = fmaxf(m, d);
   }
 #pragma unroll
-  for (int x = 1; x < kAttnSlices; x <<= 1) m = fmaxf(m, lane_read(m, (t & 63) ^ x));    // row maximum over the 8 slices
+  for (int x = 1; x < kAttnSlices; x <<= 1) m = fmaxf(m, lane_read(m, (t & 63) ^ x));    // row maximum over the slices
   f32x4 o[Q4];
 #pragma unroll
   for (int i = 0; i < Q4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -852,7 +865,7 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
 #pragma unroll
   for (int it = 0; it < kAttnMaxKeys; ++it) {
     if (it < nk) {
-      const float e = expf(sc[it] - m);
+      const float e = fast_exp(sc[it] - m);
       den += e;
       const f32x4* vr = vs + (size_t)(sl + it * kAttnSlices) * kAttnRow;
 #pragma unroll
