@@ -14,8 +14,9 @@
  * `tha4_*_pose` never allocates, never synchronises and enqueues all work on the given stream
  * (callers bracket it with stream events exactly like full_manual_poser.py:388-398 does).
  * A handle owns ONE workspace: consecutive calls on the same stream are ordered by the stream; when the stream
- * differs from the previous call's, the new stream is made to wait (event, no host sync) for the work enqueued on
- * the previous one.  A handle must not be used from two host threads at once (the reference is single-threaded,
+ * differs from the previous call's, an event (created with the handle) is recorded on the PREVIOUS stream and the new
+ * stream waits for it (no host sync).  A stream given to a pose call must therefore stay valid until the handle's next
+ * pose call has returned.  A handle must not be used from two host threads at once (the reference is single-threaded,
  * SURVEY.md §8b); use one handle per thread.
  */
 #ifndef THA4_HIP_H
@@ -27,14 +28,15 @@
 extern "C" {
 #endif
 
-#define THA4_ABI_VERSION 2
+#define THA4_ABI_VERSION 3
 
 typedef enum tha4_status {
   THA4_OK = 0,
   THA4_ERR_INVALID_ARGUMENT = -1,  /* null pointer, bad batch, wrong architecture dims            */
   THA4_ERR_HIP = -2,               /* a HIP runtime call failed (message in tha4_last_error())    */
   THA4_ERR_NO_DEVICE = -3,         /* no gfx950 device / device index out of range                */
-  THA4_ERR_BATCH_TOO_LARGE = -4    /* batch > max_batch given at create                           */
+  THA4_ERR_BATCH_TOO_LARGE = -4,   /* batch > max_batch given at create                           */
+  THA4_ERR_NUMERIC_RANGE = -5      /* full model: an earlier pose call left the operand range (see tha4_full_numeric_status) */
 } tha4_status;
 
 /* One Conv2d(kernel_size=1) layer as stored in the reference state_dict
@@ -71,6 +73,16 @@ typedef struct tha4_position_axes {
   const float* axis512; /* [512] */
 } tha4_position_axes;
 
+/* Display epilogue fused into the kernel that composes the posed frame: what every real-time caller
+ * runs on the device right after pose() (src/tha4/app/character_model_ifacialmocap_puppeteer.py:325-349,377-381;
+ * src/tha4/image_util.py:56-58): clip((x+1)/2,0,1) -> linear->sRGB on RGB -> optional blend over an opaque background
+ * colour -> CHW->HWC -> *255 -> truncate to uint8.  The values are converted while still in registers: the fp32 frame
+ * is neither re-read nor (when the fp32 output pointer is NULL) written. */
+typedef struct tha4_display {
+  uint8_t* rgba8_dev;          /* device, uint8 [B,512,512,4]; NULL = no display output                         */
+  const float* background_rgb; /* HOST, 3 floats in [0,1] (sRGB-encoded, as the reference blends) or NULL = keep alpha */
+} tha4_display;
+
 /* Optional extra outputs of SirenMorpher03.forward / TwoStepPoserComputationProtocol
  * (src/tha4/nn/siren/morpher/siren_morpher_03.py:133-139, src/tha4/poser/modes/mode_14.py:85-88).
  * Device pointers, each may be NULL.  Output index in the reference list is given in brackets. */
@@ -80,6 +92,7 @@ typedef struct tha4_student_aux {
   float* warped_dev;       /* [3] [B,4,512,512] grid_sample of the input     */
   float* grid_change_dev;  /* [4] [B,2,512,512] normalised offsets (x, y)    */
   float* face_dev;         /* [5] [B,4,128,128] face morpher output          */
+  tha4_display display;    /* fused display epilogue of output 0 (ABI v3)    */
 } tha4_student_aux;
 
 typedef struct tha4_student tha4_student; /* opaque */
@@ -112,7 +125,8 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
  *   image_batch_stride floats between consecutive frames' images; 0 = one image shared by the batch
  *                      (the reference needs B identical copies for that; 4*512*512 = dense batch)
  *   pose_dev           fp32 [B,45]
- *   out_blended_dev    fp32 [B,4,512,512]  output index 0 (the posed frame); must not alias image_dev
+ *   out_blended_dev    fp32 [B,4,512,512]  output index 0 (the posed frame); must not alias image_dev; may be NULL
+ *                      when aux->display.rgba8_dev is given (the caller only wants the displayable frame)
  *   aux                optional outputs 1..5, may be NULL
  *   stream             hipStream_t to enqueue on (NULL = the null stream) */
 int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_batch_stride,
@@ -186,6 +200,20 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
  *                   max|delta| device->host sync, mode_07.py:56-61; here the caller states it). */
 int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev, int batch,
                    float* const* outputs_dev, int reuse_decomposer, void* stream);
+
+/* Numeric-range guard of the full model (no reference counterpart: the reference computes in plain fp32).  The convolutions
+ * stage their normalised + activated operands as unscaled fp16 hi + lo halves (22 significant bits, |v| <= 65504); beyond
+ * that range - or with NaN / inf in weights or inputs - the affected outputs are not finite.  The kernels detect this where
+ * every such fault ends up (the scale/shift of the next normalisation, a network's head block) and set a sticky flag in
+ * host-visible memory.  tha4_full_pose returns THA4_ERR_NUMERIC_RANGE once, WITHOUT enqueueing work, when it finds the flag
+ * set by an earlier call (it never synchronises, so the call that faulted itself returns THA4_OK); this function is the
+ * synchronous check: synchronize != 0 waits for the handle's device first.  Both report-and-clear. */
+int tha4_full_numeric_status(tha4_full* h, int synchronize);
+
+/* tha4_full_pose with the display epilogue of output 0 (the upscaler's merged frame) fused into the kernel that composes
+ * it; `display` may be NULL (= tha4_full_pose).  With display->rgba8_dev set, outputs_dev may be all-NULL. */
+int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev, int batch,
+                      float* const* outputs_dev, int reuse_decomposer, const tha4_display* display, void* stream);
 
 void tha4_full_destroy(tha4_full* h);
 int tha4_full_max_batch(const tha4_full* h);

@@ -64,4 +64,5 @@ def parse_resource_remarks(stderr: str) -> str:
     if cur:
         out.append(cur)
     return "".join(f"{c['name']} vgprs={c.get('VGPRs', '?')} vgpr_spill={c.get('VGPRs Spill', '?')} "
-                   f"scratch={c.get('ScratchSize [bytes/lane]', '?')} occupancy={c.get('Occupancy [waves/SIMD]', '?')}\n" for c in out)
+                   f"scratch={c.get('ScratchSize [bytes/lane]', '?')} occupancy={c.get('Occupancy [waves/SIMD]', '?')} "
+                   f"sgpr_spill={c.get('SGPRs Spill', '?')}\n" for c in out)

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtha4_hip.so")
 
-THA4_ABI_VERSION = 2
+THA4_ABI_VERSION = 3
 STUDENT_EXACT_FP32 = 1
 
 c_float_p = C.POINTER(C.c_float)
@@ -36,9 +36,28 @@ class Tha4PositionAxes(C.Structure):
     _fields_ = [("axis128", c_float_p), ("axis256", c_float_p), ("axis512", c_float_p)]
 
 
+class Tha4Display(C.Structure):
+    """tha4_display: the display epilogue fused into the kernel that composes the posed frame."""
+    _fields_ = [("rgba8_dev", C.c_void_p), ("background_rgb", c_float_p)]
+
+
 class Tha4StudentAux(C.Structure):
     _fields_ = [("alpha_dev", C.c_void_p), ("color_change_dev", C.c_void_p), ("warped_dev", C.c_void_p),
-                ("grid_change_dev", C.c_void_p), ("face_dev", C.c_void_p)]
+                ("grid_change_dev", C.c_void_p), ("face_dev", C.c_void_p), ("display", Tha4Display)]
+
+
+ERR_NUMERIC_RANGE = -5
+
+
+def make_display(rgba8_ptr: int, background_rgb):
+    """(Tha4Display, keepalive) for a device uint8 [B,512,512,4] buffer and an optional 3-float background colour."""
+    d = Tha4Display()
+    d.rgba8_dev = rgba8_ptr
+    keep = None
+    if background_rgb is not None:
+        keep = (C.c_float * 3)(*[float(x) for x in background_rgb])
+        d.background_rgb = C.cast(keep, c_float_p)
+    return d, keep
 
 
 class Tha4NamedTensor(C.Structure):
@@ -179,6 +198,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.tha4_full_pose.restype = C.c_int
     lib.tha4_full_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
                                    C.c_void_p]
+    lib.tha4_full_pose_ex.restype = C.c_int
+    lib.tha4_full_pose_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                      C.POINTER(Tha4Display), C.c_void_p]
+    lib.tha4_full_numeric_status.restype = C.c_int
+    lib.tha4_full_numeric_status.argtypes = [C.c_void_p, C.c_int]
     lib.tha4_full_destroy.restype = None
     lib.tha4_full_destroy.argtypes = [C.c_void_p]
     lib.tha4_full_max_batch.restype = C.c_int
@@ -198,7 +222,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_create_ex", "tha4_student_pose", "tha4_student_set_weights", "tha4_student_destroy",
     "tha4_student_max_batch", "tha4_student_device", "tha4_student_set_timing", "tha4_student_last_ms",
-    "tha4_full_create", "tha4_full_create_ex", "tha4_full_num_networks", "tha4_full_pose", "tha4_full_destroy", "tha4_full_max_batch",
+    "tha4_full_create", "tha4_full_create_ex", "tha4_full_num_networks", "tha4_full_pose", "tha4_full_pose_ex", "tha4_full_numeric_status",
+    "tha4_full_destroy", "tha4_full_max_batch",
     "tha4_display_rgba8", "tha4_ingest_rgba8",
 ]
 

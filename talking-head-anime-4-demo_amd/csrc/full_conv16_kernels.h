@@ -120,6 +120,7 @@ THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, 
       if (f.film1) { k *= (1.0 + (double)s1v[i]); b = b * (1.0 + (double)s1v[i]) + (double)b1v[i]; }
       sc = (float)k;
       sh = (float)b;
+      report_fault_unless_finite(f.fault, sc, sh);
     }
     tab_sc[c] = sc;
     tab_sh[c] = sh;

@@ -10,6 +10,7 @@
 //   nn/face_morpher/face_morpher_08.py:158-193, nn/morpher/morpher_00.py:42-66, nn/upscaler/upscaler_02.py:59-96
 #pragma once
 #include "tha4_platform.h"
+#include "image_io_kernels.h"
 
 namespace tha4 {
 
@@ -57,7 +58,21 @@ struct ImgArgs {
   const float* in2;
   int batch;
   int sel;                  // combiner: eyebrow_morphed_image_index (0 or 2, mode_07.py:275)
+  int* fault;               // sticky numeric-fault flag of the handle (full_kernels.h report_fault_unless_finite), or null
+  unsigned char* rgba8;     // unet_tail_kernel: fused display epilogue of out[0] (tha4_hip.h tha4_display), [B][S*S][4], or null
+  int rgba8_has_bg;
+  float rgba8_bg[3];
 };
+
+// the head block of a network (16 floats per pixel, padded channels are exact zeros) must be finite: a staged operand beyond
+// the fp16 range, or a NaN from the weights, that no normalisation saw on its way here ends up in it
+THA4_DEV void check_head_finite(const float* h, int* fault) {
+  if (!fault) return;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += fabsf(h[i]);
+  if (!(s < __builtin_inff())) *fault = 1;
+}
 
 // pose slices padded to C16 vectors: eyebrow pose[0:12] -> [B][16], face pose[12:39] -> [B][32]   (mode_07.py:80,91)
 __global__ void __launch_bounds__(64) pose_pad_kernel(const float* pose, float* eyebrow16, float* face32, int batch) {
@@ -92,6 +107,7 @@ __global__ void __launch_bounds__(256) decomposer_tail_kernel(ImgArgs a) {
   const int y = idx / S, x = idx % S;
   const float* img = a.image + (size_t)n * a.image_stride;
   const float* h = a.head + ((size_t)n * P + idx) * 16;
+  check_head_finite(h, a.fault);
   const float bga = h[0], eba = h[5];
   float* co = a.c16_out + ((size_t)n * P + idx) * 16;
 #pragma unroll
@@ -121,6 +137,7 @@ __global__ void __launch_bounds__(256) combiner_tail_kernel(ImgArgs a) {
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
   const float* h = a.head + ((size_t)n * P + idx) * 16;
+  check_head_finite(h, a.fault);
   const float* eb = a.in0 + (size_t)n * 4 * P;
   const float* bg = a.in1 + (size_t)n * 4 * P;
   const float gxc = h[0], gyc = h[1], al = h[2], ca = h[7];
@@ -176,6 +193,7 @@ __global__ void __launch_bounds__(256) face_tail_kernel(ImgArgs a) {
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
   const float* h = a.head + ((size_t)n * P + idx) * 16;
+  check_head_finite(h, a.fault);
   const float* fin = a.in0 + (size_t)n * 4 * P;
   const float gxc = h[0], gyc = h[1], ia = h[6], ea = h[11];
   const float gx = axis_pos(x, S) + gxc, gy = axis_pos(y, S) + gyc;
@@ -243,18 +261,30 @@ __global__ void __launch_bounds__(256) unet_tail_kernel(ImgArgs a) {
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
   const float* h = a.head + ((size_t)n * P + idx) * 16;
+  check_head_finite(h, a.fault);
   const float* src = a.in0 + (size_t)n * 4 * P;
   const float gxc = h[4], gyc = h[5];
   const float al = 1.0f / (1.0f + expf(-h[6]));
   const float gx = axis_pos(x, S) + gxc, gy = axis_pos(y, S) + gyc;
+  float merged[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float w = sample_border(src, S, S, c, gx, gy);
     const float d = h[c];
     const size_t off = ((size_t)n * 4 + c) * P + idx;
-    a.out[0][off] = d * al + w * (1.0f - al);
+    merged[c] = d * al + w * (1.0f - al);
+    a.out[0][off] = merged[c];
     a.out[2][off] = w;
     a.out[4][off] = d;
+  }
+  if (a.rgba8) {            // display epilogue on the values in registers: one packed 4-byte store per pixel
+    const float a01 = fminf(fmaxf((merged[3] + 1.0f) * 0.5f, 0.0f), 1.0f);
+    uchar4 o;
+    o.x = display_channel(merged[0], 0, a01, a.rgba8_has_bg != 0, a.rgba8_bg[0]);
+    o.y = display_channel(merged[1], 1, a01, a.rgba8_has_bg != 0, a.rgba8_bg[1]);
+    o.z = display_channel(merged[2], 2, a01, a.rgba8_has_bg != 0, a.rgba8_bg[2]);
+    o.w = display_channel(merged[3], 3, a01, a.rgba8_has_bg != 0, 0.0f);
+    reinterpret_cast<uchar4*>(a.rgba8)[(size_t)n * P + idx] = o;
   }
   a.out[1][(size_t)n * P + idx] = al;
   a.out[3][((size_t)n * 2 + 0) * P + idx] = gxc;

@@ -33,6 +33,16 @@ struct ConvSrc {
   int act;              // activation applied after scale/shift (before zero padding / pooling)
 };
 
+// Numeric-fault detection (tha4_hip.h THA4_ERR_NUMERIC_RANGE).  The convolutions stage their operands as UNSCALED fp16 hi + lo
+// halves: a normalised + activated value of |v| >= 65520 becomes hi = inf, lo = -inf and every accumulator it touches NaN.
+// Such a fault (or a NaN / inf coming from the weights) always reaches the moments of the next normalisation or a network's
+// head block, so THOSE are checked - per channel in the normalisation arithmetic, per pixel in the image tails - and the hot
+// loops carry no range check.  The flag lives in pinned host memory mapped into the device: set once, read by the host at
+// the next tha4_full_pose / tha4_full_numeric_status.
+THA4_DEV void report_fault_unless_finite(int* fault, float a, float b) {
+  if (fault && !(fabsf(a) < __builtin_inff() && fabsf(b) < __builtin_inff())) *fault = 1;
+}
+
 // Normalisation folded into the consumer (full_conv_small_kernels.h fused_norm_table): instead of reading per-(n, c)
 // scale/shift vectors produced by norm_finalize_kernel, the convolution reduces the producer's per-tile moments itself.
 struct FusedNorm {
@@ -48,6 +58,7 @@ struct FusedNorm {
   const float* film1;      // [n][film1_stride] per-frame (scale | shift) or null
   long long film1_stride;
   int enabled;
+  int* fault;              // sticky numeric-fault flag of the handle (a non-finite scale/shift sets it), or null
 };
 
 struct ConvArgs {
@@ -138,9 +149,14 @@ THA4_DEV float apply_act(float v, int act) {
 // act(x * sc + sh) on four values with ONE (uniform) dispatch on the activation; ReLU / none share a branch-free path
 THA4_DEV f32x4 apply_act4(const f32x4& x, const f32x4& sc, const f32x4& sh, int act) {
   f32x4 o;
-  const float lo = act == ACT_RELU ? 0.0f : -__builtin_inff();
+  // ReLU clamps; every other activation passes the value through untouched so that a NaN produced upstream stays a NaN
+  // (fmaxf(x, -inf) would turn it into -inf).  `act` is wave-uniform: the select is on a scalar condition
+  const bool relu = act == ACT_RELU;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(x[j], sc[j], sh[j]), lo);
+  for (int j = 0; j < 4; ++j) {
+    const float t = fmaf(x[j], sc[j], sh[j]);
+    o[j] = relu ? fmaxf(t, 0.0f) : t;
+  }
   if (act == ACT_SILU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = o[j] * fast_sigmoid(o[j]);
@@ -547,6 +563,8 @@ __global__ void __launch_bounds__(256) conv_splitk_kernel(ConvArgs a) {
 struct FusedInstanceNorm {   // InstanceNorm2d(affine) scale/shift computed by the consumer from the producer's per-tile moments
   const float* stats;        // [n][tiles][cb*16][2] or null (not fused)
   int tiles;
+  int channels;              // real channels: gamma / beta hold this many floats, padded channels get scale = shift = 0
+  int* fault;                // sticky numeric-fault flag of the handle, or null
   float inv_count, eps;
   const float* gamma;
   const float* beta;
@@ -563,6 +581,7 @@ struct AffineAddArgs {
 // scale/shift of channel c of frame n from per-tile moments (same fp64 arithmetic as norm_finalize_kernel, groups == 0)
 THA4_DEV void instance_norm_from_moments(const FusedInstanceNorm& f, int n, int cw, int c, float& sc, float& sh) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
+  if (c >= f.channels) { sc = 0.f; sh = 0.f; return; }     // padded channel of the last block (as norm_finalize_kernel / fused_norm_table)
   const float* ps = f.stats + ((size_t)n * f.tiles * cw + c) * 2;
   const float gam = f.gamma[c], bet = f.beta[c];           // requested together with the moments: one memory round trip
   double su = 0.0, sq = 0.0;
@@ -583,6 +602,7 @@ THA4_DEV void instance_norm_from_moments(const FusedInstanceNorm& f, int n, int 
   const double kk = (double)gam * rstd;
   sc = (float)kk;
   sh = (float)((double)bet - mean * kk);
+  report_fault_unless_finite(f.fault, sc, sh);
 }
 
 __global__ void __launch_bounds__(256) affine_add_kernel(AffineAddArgs k) {
@@ -656,6 +676,7 @@ struct NormArgs {
   float* scale[2];         // outputs per source, [n][cb*16]
   float* shift[2];
   int cpb;                 // padded channels per workgroup (a multiple of the group size; blockIdx.y selects the range)
+  int* fault;              // sticky numeric-fault flag of the handle, or null
 };
 
 constexpr int kNormThreads = 1024;
@@ -749,6 +770,7 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
       }
       sc = (float)k;
       sh = (float)b;
+      report_fault_unless_finite(a.fault, sc, sh);
     }
     a.scale[s][(size_t)n * a.cb[s] * 16 + cl] = sc;
     a.shift[s][(size_t)n * a.cb[s] * 16 + cl] = sh;

@@ -73,6 +73,7 @@ class FullModel {
   size_t partial_floats = 0, partial_off = 0;
   int conv_counter = 0;      // build-order index of every convolution (schedule dump / tuning aids)
   size_t dbg_off = 0;        // tuning aid (THA4_PHASE_TIMING): stamp buffer
+  int* fault = nullptr;      // sticky numeric-fault flag (pinned host memory mapped into the device; set by the C ABI at create)
   void finalize_scratch() {
     partial_off = alloc_work(partial_floats);
 #ifdef THA4_PHASE_TIMING
@@ -100,6 +101,7 @@ class FullModel {
   struct Frame {            // per-call bindings
     const float* image; long long image_stride; const float* pose; int batch; hipStream_t stream;
     float* out[33];         // NCHW outputs in the reference order (never null: unrequested ones point into scratch)
+    unsigned char* rgba8; int rgba8_has_bg; float rgba8_bg[3];    // fused display epilogue of out[0] (tha4_display) or null
   };
   using Op = std::function<void(const Frame&)>;
   std::vector<Op> ops_decomposer, ops_rest;
@@ -390,6 +392,7 @@ class FullModel {
           fn.film0 = fp.film0_off == kNone ? nullptr : P(fp.film0_off);
           fn.film1 = fp.film1_off == kNone ? nullptr : Wk(fp.film1_off);
           fn.film1_stride = fp.film1_stride;
+          fn.fault = fault;
         }
         c.w = P(w_off);
         c.w16 = P<char>(w_off);
@@ -474,6 +477,7 @@ class FullModel {
       a.gamma = P(g_off); a.beta = P(b_off);
       a.film0 = film0_off == kNone ? nullptr : P(film0_off); a.film0_stride = 0;
       a.film1 = film1_off == kNone ? nullptr : Wk(film1_off); a.film1_stride = film1_stride;
+      a.fault = fault;
       const int ctot = cbt * 16;
       a.cpb = std::getenv("THA4_NORM_ONE_WG") ? ctot : norm_channels_per_block(ctot, channels, groups);
       const int S = std::max(1, kNormThreads / a.cpb);
@@ -494,8 +498,8 @@ class FullModel {
       auto mat = [&](const Pending& p) { return p.has() && !p.fused; };
       auto fin = [&](const Pending& p, FusedInstanceNorm& fi) {       // InstanceNorm only (resnet_block.py:52-67)
         if (!p.fused) return;
-        fi.stats = Wk(p.stats_off[0]); fi.tiles = p.tiles[0]; fi.inv_count = p.inv_count; fi.eps = 1e-5f;
-        fi.gamma = P(p.gamma_off); fi.beta = P(p.beta_off);
+        fi.stats = Wk(p.stats_off[0]); fi.tiles = p.tiles[0]; fi.channels = p.channels; fi.inv_count = p.inv_count; fi.eps = 1e-5f;
+        fi.gamma = P(p.gamma_off); fi.beta = P(p.beta_off); fi.fault = fault;
       };
       k.a = Wk(A.off); k.sa = mat(pa) ? Wk(pa.scale_off) : nullptr; k.ha = mat(pa) ? Wk(pa.shift_off) : nullptr; k.act_a = act_a;
       k.b = Wk(B.off); k.sb = mat(pb) ? Wk(pb.scale_off) : nullptr; k.hb = mat(pb) ? Wk(pb.shift_off) : nullptr;
@@ -745,7 +749,7 @@ class FullModel {
   void image_op(std::vector<Op>& ops, K kernel, int pixels, std::function<void(const Frame&, ImgArgs&)> bind) {
     ops.push_back([=](const Frame& f) {
       ImgArgs a{};
-      a.image = f.image; a.image_stride = f.image_stride; a.pose = f.pose; a.batch = f.batch; a.sel = sel_index;
+      a.image = f.image; a.image_stride = f.image_stride; a.pose = f.pose; a.batch = f.batch; a.sel = sel_index; a.fault = fault;
       bind(f, a);
       hipLaunchKernelGGL(kernel, dim3((pixels + 255) / 256, f.batch), dim3(256), 0, f.stream, a);
     });
@@ -867,6 +871,8 @@ class FullModel {
       image_op(ops, unet_tail_kernel<512>, 512 * 512, [=](const Frame& f, ImgArgs& a) {
         a.head = Wk(hd.off); a.in0 = f.out[5];
         for (int i = 0; i < 5; ++i) a.out[i] = f.out[i];
+        a.rgba8 = f.rgba8; a.rgba8_has_bg = f.rgba8_has_bg;
+        for (int k = 0; k < 3; ++k) a.rgba8_bg[k] = f.rgba8_bg[k];
       });
     }
     head_storage.clear();

@@ -503,7 +503,8 @@ THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bia
     wv += body_source(img, face, g, y1, x1) * wse;
     const float blended = (1.0f - al) * wv + al * col;
     const size_t pix = (size_t)pix0[pg] + p;
-    d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
+    if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
+    if (d.out_rgba8) store_display(d, n, pix, g, p, blended);
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
     if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = wv;
     if (d.out_alpha && g == 0) d.out_alpha[(size_t)n * NPIX + pix] = al;

@@ -27,6 +27,7 @@
 #pragma once
 #include "tha4_platform.h"
 #include "siren_layout.h"
+#include "image_io_kernels.h"
 
 namespace tha4 {
 
@@ -51,12 +52,27 @@ struct StudentDev {
   float* out_color;          // [B][4][512][512] or null
   float* out_warped;         // [B][4][512][512] or null
   float* out_grid;           // [B][2][512][512] or null
+  unsigned char* out_rgba8;  // [B][512][512][4] display epilogue of the posed frame (tha4_hip.h tha4_display) or null; with it
+                             // out_blended may be null
+  int rgba8_has_bg;          // blend over the opaque background colour rgba8_bg (sRGB-encoded, [0,1]); alpha becomes 1
+  float rgba8_bg[3];
   int batch;
   // generation 2 (siren16_kernels.h): 1/S of every streamed layer in execution order; the first-layer tables (wx, wy),
   // the pose-folded biases and the z hand-off carry the sine's 30x (pb_scale = 30; generation 1: 1)
   const float *s_face, *s_l0, *s_l1, *s_l2;
   float pb_scale;
 };
+
+// Display epilogue of the posed frame, fused into the warp/blend tail (tha4_hip.h tha4_display): lane
+// group g holds channel g of pixel p, so the four bytes of a pixel are written by lanes p, p+16, p+32, p+48 - the 64 lanes of
+// a wave cover 64 CONTIGUOUS bytes of the HWC frame (one store instruction per 16 pixels, like every other output).
+// Must be called by all 64 lanes (the alpha of a pixel is read from lane p + 48).
+THA4_DEV void store_display(const StudentDev& d, int n, size_t pix, int g, int p, float blended) {
+  float a01 = 0.0f;
+  if (d.rgba8_has_bg) a01 = fminf(fmaxf((lane_read(blended, p + 48) + 1.0f) * 0.5f, 0.0f), 1.0f);     // wave-uniform branch
+  const float bg = g == 0 ? d.rgba8_bg[0] : (g == 1 ? d.rgba8_bg[1] : d.rgba8_bg[2]);
+  d.out_rgba8[((size_t)n * (kImg * kImg) + pix) * 4 + g] = display_channel(blended, g, a01, d.rgba8_has_bg != 0, bg);
+}
 
 // ---------------------------------------------------------------------------------------------
 // sin(30 z) exactly as the reference rounds it: u = fl(30 z) (siren.py:39), then sin(u) to ~1.4e-7
@@ -97,6 +113,17 @@ THA4_DEV float sin_omega(float z) {
 THA4_DEV float sin_u(float u) {
 #ifdef THA4_ABLATE_SIN   // timing ablation only (tools/sweep.py): results are wrong
   return u;
+#endif
+#if defined(THA4_HW_SIN) && !defined(THA4_EMU)
+  // A/B variant (tools/sin_cliff.py, profiles/r03_sin_cliff.md; never shipped): k = rint(u / 2 pi) by the magic add, 2-term
+  // Cody-Waite by 2 pi, v_sin_f32 (argument in revolutions) on the reduced argument.  7 issue slots instead of 12.
+  {
+    const float th = fmaf(u, 0x1.45f306p-3f, 12582912.0f);
+    const float kh = th - 12582912.0f;
+    float rh = fmaf(-kh, 6.28125f, u);
+    rh = fmaf(-kh, 0x1.fb5444p-10f, rh);
+    return __builtin_amdgcn_sinf(rh * 0x1.45f306p-3f);
+  }
 #endif
   const float t = fmaf(u, 0x1.45f306p-2f, 12582912.0f);
   const float k = t - 12582912.0f;
@@ -592,7 +619,8 @@ __global__ void __launch_bounds__(NS* MS * 64) level2_kernel(StudentDev d) {
     wv += body_source(img, face, g, y1, x1) * wse;
     const float blended = (1.0f - al) * wv + al * col;            // siren_morpher_03.py:131
     const size_t pix = (size_t)pix0[pg] + p;
-    d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
+    if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
+    if (d.out_rgba8) store_display(d, n, pix, g, p, blended);
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
     if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = wv;
     if (d.out_alpha && g == 0) d.out_alpha[(size_t)n * NPIX + pix] = al;

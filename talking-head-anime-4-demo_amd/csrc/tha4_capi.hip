@@ -45,19 +45,26 @@ struct DeviceGuard {
 
 constexpr int kNumKernels = 5;
 
+const char* const kNumericFaultMessage =
+    "numeric fault in an earlier tha4_full_pose on this handle: a normalisation scale/shift or a network's head block was not "
+    "finite - a normalised + activated convolution operand left the fp16 hi/lo range (|v| >= 65520 is staged as inf) or the "
+    "weights / inputs contain NaN or inf; the outputs of that call are invalid";
+
 // One workspace per handle: two pose calls on DIFFERENT streams would race on it.  Calls on the same stream are ordered
-// by the stream; when the stream changes, an event recorded on the previous stream (at that moment: it covers the
-// previous call and anything enqueued there since) is waited for by the new one.  Nothing is recorded on the common
-// single-stream path.
+// by the stream; when the stream changes, the event `done` (created with the handle: pose never allocates) is recorded on
+// the previous stream - at that moment, so it covers the previous call and anything enqueued there since - and waited for
+// by the new one.  Nothing is recorded on the common single-stream path (an event per frame would put a signal packet
+// between the frames of a 160-us stream).  Contract (tha4_hip.h): a stream given to a pose call must stay valid until
+// the handle's NEXT pose call has returned.
 struct StreamOrder {
   hipStream_t last = nullptr;
   bool used = false;
   hipEvent_t done = nullptr;
+  hipError_t create() { return hipEventCreateWithFlags(&done, hipEventDisableTiming); }
   hipError_t enter(hipStream_t s) {
     hipError_t e = hipSuccess;
-    if (used && s != last) {
-      if (!done) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventRecord(done, last);
+    if (used && s != last && done) {
+      e = hipEventRecord(done, last);
       if (e == hipSuccess) e = hipStreamWaitEvent(s, done, 0);
     }
     last = s;
@@ -216,6 +223,7 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   h->max_batch = max_batch;
   h->exact_fp32 = exact;
   auto cleanup = [&]() {
+    h->order.destroy();
     if (h->blob) (void)hipFree(h->blob);
     if (h->workspace) (void)hipFree(h->workspace);
     delete h;
@@ -230,6 +238,7 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   const size_t s_z1 = align_up(B * kNB1 * 128 * 128 * 16 * sizeof(float), 256);
   const size_t s_z2 = align_up(B * kNB2 * 256 * 256 * 16 * sizeof(float), 256);
   if (e == hipSuccess) e = hipMalloc((void**)&h->workspace, s_pb + s_face + s_z1 + s_z2);
+  if (e == hipSuccess) e = h->order.create();
   if (e == hipSuccess) e = allow_lds(THA4_FACE_KERNEL, cfg::FaceG::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L0_KERNEL, cfg::L0G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L1_KERNEL, cfg::L1G::LDS);
@@ -265,8 +274,10 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
 
 int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev,
                       int batch, float* out_blended_dev, const tha4_student_aux* aux, void* stream) {
-  if (!h || !image_dev || !pose_dev || !out_blended_dev)
-    return fail(THA4_ERR_INVALID_ARGUMENT, "handle/image/pose/out must not be NULL");
+  if (!h || !image_dev || !pose_dev) return fail(THA4_ERR_INVALID_ARGUMENT, "handle/image/pose must not be NULL");
+  unsigned char* rgba8 = aux ? aux->display.rgba8_dev : nullptr;
+  if (!out_blended_dev && !rgba8)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "out_blended_dev must not be NULL unless aux->display.rgba8_dev is given");
   if (batch < 1) return fail(THA4_ERR_INVALID_ARGUMENT, "batch must be >= 1");
   if (batch > h->max_batch) return fail(THA4_ERR_BATCH_TOO_LARGE, "batch exceeds max_batch given at create");
   if (image_batch_stride != 0 && image_batch_stride < 4LL * kImg * kImg)
@@ -285,6 +296,9 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
   d.out_color = aux ? aux->color_change_dev : nullptr;
   d.out_warped = aux ? aux->warped_dev : nullptr;
   d.out_grid = aux ? aux->grid_change_dev : nullptr;
+  d.out_rgba8 = rgba8;
+  d.rgba8_has_bg = rgba8 && aux->display.background_rgb ? 1 : 0;
+  for (int k = 0; k < 3; ++k) d.rgba8_bg[k] = d.rgba8_has_bg ? aux->display.background_rgb[k] : 0.0f;
   if (aux && aux->face_dev) d.face = aux->face_dev;   // face kernel writes output 5 directly; level2 reads it there
   d.batch = batch;
 
@@ -399,6 +413,7 @@ struct tha4_full {
   bool decomposer_valid = false;
   int last_batch = 0;
   StreamOrder order;
+  int* fault = nullptr;        // pinned host memory, device-visible: the kernels' sticky numeric-fault flag
 };
 
 int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
@@ -447,8 +462,13 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
   if (e == hipSuccess) e = hipMalloc((void**)&m.dev_work, m.work_floats * sizeof(float));
   if (e == hipSuccess) e = hipMemset(m.dev_work, 0, m.work_floats * sizeof(float));
   if (e == hipSuccess) e = FullModel::allow_all_conv_lds();
+  if (e == hipSuccess) e = h->order.create();
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->fault, 64, hipHostMallocMapped);
+  if (e == hipSuccess) { *h->fault = 0; m.fault = h->fault; }
   std::vector<char>().swap(m.host_params);
   if (e != hipSuccess) {
+    h->order.destroy();
+    if (h->fault) (void)hipHostFree(h->fault);
     if (m.dev_params) (void)hipFree(m.dev_params);
     if (m.dev_work) (void)hipFree(m.dev_work);
     delete h;
@@ -460,11 +480,21 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
 
 int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev, int batch,
                    float* const* outputs_dev, int reuse_decomposer, void* stream) {
-  if (!h || !image_dev || !pose_dev || !outputs_dev)
+  return tha4_full_pose_ex(h, image_dev, image_batch_stride, pose_dev, batch, outputs_dev, reuse_decomposer, nullptr, stream);
+}
+
+int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_stride, const float* pose_dev, int batch,
+                      float* const* outputs_dev, int reuse_decomposer, const tha4_display* display, void* stream) {
+  unsigned char* rgba8 = display ? display->rgba8_dev : nullptr;
+  if (!h || !image_dev || !pose_dev || (!outputs_dev && !rgba8))
     return fail(THA4_ERR_INVALID_ARGUMENT, "handle/image/pose/outputs must not be NULL");
+  if (rgba8 && h->model.num_networks != 5)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "the display epilogue belongs to output 0, which a 3-network (mode_12) handle does not produce");
+  float* const no_outputs[33] = {};
+  if (!outputs_dev) outputs_dev = no_outputs;
   {
     const int first = h->model.num_networks == 5 ? 0 : 11;     // a mode_12 handle produces outputs 11..32 only
-    bool any = false;
+    bool any = rgba8 != nullptr;
     for (int i = first; i < 33; ++i) any = any || outputs_dev[i] != nullptr;
     if (!any) return fail(THA4_ERR_INVALID_ARGUMENT, "no output requested");
     for (int i = 0; i < first; ++i)
@@ -474,11 +504,20 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
   if (batch > h->model.max_batch) return fail(THA4_ERR_BATCH_TOO_LARGE, "batch exceeds max_batch given at create");
   if (image_batch_stride != 0 && image_batch_stride < 4LL * 512 * 512)
     return fail(THA4_ERR_INVALID_ARGUMENT, "image_batch_stride must be 0 (shared) or >= 4*512*512");
+  // sticky numeric-fault flag of EARLIER calls (no synchronisation: whatever has become visible by now; tha4_full_numeric_status
+  // is the synchronous check).  Reported once, then cleared so that the caller can go on with sane inputs
+  if (*reinterpret_cast<volatile int*>(h->fault)) {
+    *reinterpret_cast<volatile int*>(h->fault) = 0;
+    return fail(THA4_ERR_NUMERIC_RANGE, kNumericFaultMessage);
+  }
   DeviceGuard guard(h->device);
   FullModel& m = h->model;
   FullModel::Frame f{};
   f.image = image_dev; f.image_stride = image_batch_stride; f.pose = pose_dev; f.batch = batch;
   f.stream = static_cast<hipStream_t>(stream);
+  f.rgba8 = rgba8;
+  f.rgba8_has_bg = rgba8 && display->background_rgb ? 1 : 0;
+  for (int k = 0; k < 3; ++k) f.rgba8_bg[k] = f.rgba8_has_bg ? display->background_rgb[k] : 0.0f;
   HIP_TRY(h->order.enter(f.stream));
   bool want_dec[6];
   for (int i = 0; i < 33; ++i) f.out[i] = outputs_dev[i] ? outputs_dev[i] : m.Wk(m.scratch_out[i]);
@@ -488,6 +527,19 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
   h->decomposer_valid = true;
   h->last_batch = batch;
   HIP_TRY(hipGetLastError());
+  return THA4_OK;
+}
+
+int tha4_full_numeric_status(tha4_full* h, int synchronize) {
+  if (!h) return fail(THA4_ERR_INVALID_ARGUMENT, "handle must not be NULL");
+  if (synchronize) {
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if (*reinterpret_cast<volatile int*>(h->fault)) {
+    *reinterpret_cast<volatile int*>(h->fault) = 0;
+    return fail(THA4_ERR_NUMERIC_RANGE, kNumericFaultMessage);
+  }
   return THA4_OK;
 }
 
@@ -504,6 +556,7 @@ void tha4_full_destroy(tha4_full* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   h->order.destroy();
+  if (h->fault) (void)hipHostFree(h->fault);
   if (h->model.dev_params) (void)hipFree(h->model.dev_params);
   if (h->model.dev_work) (void)hipFree(h->model.dev_work);
   delete h;

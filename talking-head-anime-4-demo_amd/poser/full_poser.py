@@ -91,6 +91,20 @@ class HipFullPoser(Poser):
         wanted = list(range(self.list_length)) if indices is None else [int(i) for i in indices]
         return self._run(image, pose, wanted, image_changed, image_version)
 
+    def pose_display_rgba8(self, image: Tensor, pose: Tensor, background_rgb=None, image_changed: bool = False,
+                           image_version: Optional[int] = None) -> Tensor:
+        """``pose()`` (output 0) followed by the puppeteers' display post-processing
+        (character_model_ifacialmocap_puppeteer.py:325-349,377-381), fused into the upscaler's tail kernel
+        (tha4_full_pose_ex / tha4_display): returns ``uint8 [B,512,512,4]``."""
+        return self._run(image, pose, [], image_changed, image_version, display=(True, background_rgb))
+
+    def check_numeric_range(self):
+        """Synchronous form of the numeric-range guard (tha4_full_numeric_status): waits for the device and raises
+        ``Tha4Error`` if a pose call since the last check left the fp16 hi/lo operand range (|normalised + activated value|
+        >= 65520) or met NaN / inf.  ``pose()`` itself never synchronises: it raises for an EARLIER call's fault."""
+        if self._handle is not None:
+            _capi.check(self._lib, self._lib.tha4_full_numeric_status(self._handle, 1), "tha4_full_numeric_status")
+
     def free(self):
         self._destroy_handle()
         self._state_dicts = None
@@ -122,9 +136,25 @@ class HipFullPoser(Poser):
         except Exception:
             pass
 
+    #: what happens when a batch larger than ``max_batch`` arrives on a live handle.  The launch plan (K split, conv_small,
+    #: folded normalisations) is chosen for the batch the handle is built for and a frame's bytes are only guaranteed
+    #: within one plan, so growing is never silent: "warn" (default) re-creates the handle with a RuntimeWarning - the
+    #: reference accepts any batch, a drop-in must too -, "error" raises Tha4Error instead (callers that rely on bitwise
+    #: reproducibility, e.g. the sharded stream), "allow" re-creates quietly.
+    regrow_policy = "warn"
+
     def _ensure_handle(self, batch: int):
         if self._handle is not None and batch <= self._max_batch:
             return
+        if self._handle is not None:
+            msg = (f"HipFullPoser: batch {batch} exceeds the max_batch {self._max_batch} this handle was planned for; "
+                   f"re-creating it for {batch} frames changes the launch plan - results stay within the parity gate but "
+                   f"are no longer bitwise equal to frames posed before (pass max_batch= to create_poser to avoid this)")
+            if self.regrow_policy == "error":
+                raise _capi.Tha4Error(msg)
+            if self.regrow_policy == "warn":
+                import warnings
+                warnings.warn(msg, RuntimeWarning, stacklevel=4)
         dev = self._device_index()
         if self._lib is None:
             self._lib = _capi.load_library()
@@ -141,7 +171,7 @@ class HipFullPoser(Poser):
         self._handle = handle
 
     def _run(self, image: Tensor, pose: Tensor, wanted: List[int], image_changed: bool,
-             image_version: Optional[int] = None) -> List[Tensor]:
+             image_version: Optional[int] = None, display=None):
         given = image                                       # the caller's tensor object (cache identity)
         if image.dim() == 3:
             image = image.unsqueeze(0)
@@ -160,7 +190,7 @@ class HipFullPoser(Poser):
                 raise AssertionError(f"{name} must be float32, got {t.dtype}")
             if t.device.type != "cuda" or t.device.index != dev:
                 raise AssertionError(f"{name} is on {t.device}, poser is on {self.device}")
-        if not wanted or any(i < 0 or i >= self.list_length for i in wanted):
+        if (not wanted and display is None) or any(i < 0 or i >= self.list_length for i in wanted):
             raise AssertionError(f"output indices must be in [0, {self.list_length}), got {wanted}")
         copied = not image.is_contiguous()
         image, pose = image.contiguous(), pose.contiguous()
@@ -186,11 +216,19 @@ class HipFullPoser(Poser):
             outs[i] = t
             ptrs[ci] = t.data_ptr()
         stride = 0 if (image.shape[0] == 1 and b > 1) else 4 * 512 * 512
+        rgba, disp_ref, disp_keep = None, None, None
+        if display is not None:
+            rgba = torch.empty((b, 512, 512, 4), dtype=torch.uint8, device=target)
+            disp, disp_keep = _capi.make_display(rgba.data_ptr(), display[1])
+            disp_ref = C.byref(disp)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            st = self._lib.tha4_full_pose(self._handle, image.data_ptr(), stride, pose.data_ptr(), b, ptrs, int(reuse),
-                                          C.c_void_p(stream))
-        _capi.check(self._lib, st, "tha4_full_pose")
+            st = self._lib.tha4_full_pose_ex(self._handle, image.data_ptr(), stride, pose.data_ptr(), b, ptrs, int(reuse),
+                                             disp_ref, C.c_void_p(stream))
+        _capi.check(self._lib, st, "tha4_full_pose_ex")
+        del disp_keep
         self._cache_key = key
         self._cache_image = keep if key is not None else None
+        if display is not None:
+            return rgba
         return [outs[i] for i in wanted]

@@ -117,13 +117,15 @@ class HipStudentPoser(Poser):
         max_batch, position axes stay).  Before the first call it just replaces what the lazy loaders will deliver."""
         conv = lambda sd: {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
         face, body = conv(face_state_dict), conv(body_state_dict)
-        self.state_dict_loaders = {"face_morpher": lambda: face, "body_morpher": lambda: body}
-        self._state_dicts = {"face_morpher": face, "body_morpher": body}
         if self._handle is not None:
+            # the native call validates and packs first: a rejected pair ("not a mode_14 student") leaves the live handle AND
+            # the Python-side state (loaders, get_modules(), a later re-create) on the old character
             weights, keep = _capi.build_student_weights(face, body)
             st = self._lib.tha4_student_set_weights(self._handle, C.byref(weights))
             _capi.check(self._lib, st, "tha4_student_set_weights")
             del keep
+        self.state_dict_loaders = {"face_morpher": lambda: face, "body_morpher": lambda: body}
+        self._state_dicts = {"face_morpher": face, "body_morpher": body}
         return self
 
     def load_character(self, module_file_names: Dict[str, str]):
@@ -227,6 +229,34 @@ class HipStudentPoser(Poser):
                                          blended.data_ptr(), aux_ref, C.c_void_p(stream))
         _capi.check(self._lib, st, "tha4_student_pose")
         return outs
+
+    def pose_display_rgba8(self, image: Tensor, pose: Tensor, background_rgb=None, out: Optional[Tensor] = None,
+                           want_frame: bool = False):
+        """``pose()`` followed by the display post-processing every puppeteer runs on the device
+        (character_model_ifacialmocap_puppeteer.py:325-349,377-381: clip((x+1)/2) -> linear->sRGB -> optional background
+        blend -> HWC -> *255 -> ``.byte()``), FUSED into the kernel that composes the frame (tha4_display): returns the
+        ``uint8 [B,512,512,4]`` frame; the fp32 frame is neither written nor re-read unless ``want_frame`` asks for it
+        too (then ``(rgba8, frame)`` is returned)."""
+        image, pose, b = self._check_inputs(image, pose)
+        self._ensure_handle(b)
+        dev = self._device_index()
+        if out is not None:
+            if (tuple(out.shape) != (b, IMAGE_SIZE, IMAGE_SIZE, 4) or out.dtype != torch.uint8 or out.device != image.device
+                    or not out.is_contiguous()):
+                raise AssertionError(f"out must be a contiguous uint8 [{b},{IMAGE_SIZE},{IMAGE_SIZE},4] tensor on {image.device}")
+            rgba = out
+        else:
+            rgba = torch.empty((b, IMAGE_SIZE, IMAGE_SIZE, 4), dtype=torch.uint8, device=image.device)
+        frame = torch.empty((b, 4, IMAGE_SIZE, IMAGE_SIZE), dtype=torch.float32, device=image.device) if want_frame else None
+        aux = _capi.Tha4StudentAux()
+        aux.display, keep = _capi.make_display(rgba.data_ptr(), background_rgb)
+        stride = 0 if (image.shape[0] == 1 and b > 1) else 4 * IMAGE_SIZE * IMAGE_SIZE
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        st = self._lib.tha4_student_pose(self._handle, image.data_ptr(), stride, pose.data_ptr(), b,
+                                         frame.data_ptr() if want_frame else None, C.byref(aux), C.c_void_p(stream))
+        _capi.check(self._lib, st, "tha4_student_pose")
+        del keep
+        return (rgba, frame) if want_frame else rgba
 
     # ---- measurement hooks (bench.py) ----------------------------------------------------------
     def set_timing(self, enable: bool):

@@ -30,6 +30,7 @@
 #define __restrict__
 
 struct emu_uint3 { unsigned x = 0, y = 0, z = 0; };
+struct uchar4 { unsigned char x, y, z, w; };      // HIP's vector type, as far as the image kernels use it
 struct dim3 {
   unsigned x, y, z;
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}

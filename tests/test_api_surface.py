@@ -135,13 +135,18 @@ def test_full_weight_struct_and_create_validation(built):
 
 def test_no_kernel_spills(built):
     """hipcc's per-kernel resource report (written by the build): no kernel may spill VGPRs - a spilling build of the
-    weights-resident level-2 kernel once produced wrong, run-to-run varying pixels on the device.  (A few convolution
-    instantiations keep a dead 20-byte stack object - no scratch instruction in their ISA - hence the small allowance.)"""
+    weights-resident level-2 kernel once produced wrong, run-to-run varying pixels on the device.  The convolution kernels
+    that spill a few SGPRs (7-20, into lanes of one VGPR by v_writelane, all outside the K loops: their by-value ConvArgs
+    keeps ~100 scalars live) get a 20-36-byte frame reserved by the backend for that VGPR; no scratch instruction exists in
+    their ISA (profiles/r03_hygiene.md).  Anything else with a stack frame fails."""
     import re
     from tha4_amd import _build
     lines = open(_build.RESOURCES).read().splitlines()
     assert sum("conv_tile_kernel" in l for l in lines) == 27 and sum("tha42v2" in l for l in lines) >= 5
-    bad = [l for l in lines if "vgpr_spill=0" not in l or int(re.search(r"scratch=(\d+)", l).group(1)) > 32]
+
+    def num(l, key):
+        return int(re.search(key + r"=(\d+)", l).group(1))
+    bad = [l for l in lines if num(l, "vgpr_spill") != 0 or (num(l, "scratch") > 0 and not (num(l, "sgpr_spill") > 0 and num(l, "scratch") <= 40))]
     assert not bad, bad
     student = [l for l in lines if "tha42v2" in l or "posebias" in l]
     assert all("scratch=0" in l for l in student), student

@@ -140,6 +140,86 @@ def test_dense_batch_distinct_images_vs_reference_fixture(poser, golden_io):
         assert torch.equal(sub[j], outs[k])
 
 
+SUB7 = slice(3, None, 7)
+
+
+def test_batch8_plan_vs_reference_fixture(weights):
+    """The launch plan `bench.py --model full --batch 8` runs (BASELINE configs[4]: 8 frames per GPU; a `max_batch = 8`
+    handle uses no K split, no conv_small, no folded normalisations where 8 frames fill the chip - DESIGN.md §4b) against
+    the UNMODIFIED reference's `get_posing_outputs(image[8], pose[8])` with 8 distinct images
+    (tests/golden/make_golden_full_batch8.py; the distiller call, siren_morpher_protocols_03.py:102-108)."""
+    from oracle.student_oracle import synthetic_image
+    io = _npz("full_batch8_io.npz")
+    dev = torch.device("cuda:0")
+    p = mode_07.create_poser_from_state_dicts(dev, weights, max_batch=8)
+    images = torch.from_numpy(np.stack([synthetic_image(seed=int(s)) for s in io["image_seeds"]])).to(dev)
+    poses = torch.from_numpy(io["poses"]).to(dev)
+    outs = p.get_posing_outputs(images, poses)
+    assert p._max_batch == 8 and len(outs) == 33
+    fr = int(io["frame"])
+    report = []
+    for k in (0, 1, 2, 3, 5):
+        got = outs[k].cpu().numpy()
+        assert got.shape[0] == 8 and np.isfinite(got).all()
+        for i in range(8):
+            err = float(np.abs(got[i][:, SUB7, SUB7] - io[f"ref32_sub7_out{k}"][i]).max())
+            report.append((f"batch8 frame {i} {fo.OUTPUT_NAMES[k]}", err, _tol(fo.OUTPUT_NAMES[k])))
+    for k in range(33):
+        got = outs[k][fr].cpu().numpy()[:, SUB7, SUB7]
+        noise = float(np.abs(io[f"ref32_frame_sub7_out{k}"] - io[f"ref64_frame_sub7_out{k}"]).max())
+        report.append((f"frame {fr} {fo.OUTPUT_NAMES[k]} vs ref32", float(np.abs(got - io[f"ref32_frame_sub7_out{k}"]).max()), _tol(fo.OUTPUT_NAMES[k])))
+        report.append((f"frame {fr} {fo.OUTPUT_NAMES[k]} vs ref64", float(np.abs(got - io[f"ref64_frame_sub7_out{k}"]).max()), _tol(fo.OUTPUT_NAMES[k], noise)))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/full_batch8_parity_report.txt", "w") as fh:
+        fh.write("max_batch = 8 handle, 8 distinct images vs the unmodified reference (stride-7 pixel subset)\n")
+        fh.write("\n".join(f"{n:40s} {e:.3e} (tol {t:.1e})" for n, e, t in report) + "\n")
+    bad = [r for r in report if r[1] > r[2]]
+    assert not bad, bad
+    # within this plan a frame's bytes do not depend on the batch it was posed in
+    single = p.get_posing_outputs(images[3], poses[3], image_changed=True)
+    for k in (0, 3, 5, 11, 19, 27):
+        assert torch.equal(single[k][0], outs[k][3]), k
+    p.free()
+
+
+def test_every_launch_plan_vs_reference_fixture(weights, full_io, golden_io):
+    """`plan_tile_conv` / `plan_small_conv` / `plan_point_conv` / the folded normalisations choose by `max_batch`
+    (DESIGN.md §4b): one frame through handles built for 1, 2, 3, 4, 5, 8 and 16 frames, all 33 outputs of each against
+    the reference fixture.  Bit-exactness holds within a plan only; the report lists how far the plans are apart."""
+    dev = torch.device("cuda:0")
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    pose = torch.from_numpy(full_io["poses"][0]).to(dev)
+    lines, bad, base = [], [], None
+    for mb in (1, 2, 3, 4, 5, 8, 16):
+        p = mode_07.create_poser_from_state_dicts(dev, weights, max_batch=mb)
+        outs = p.get_posing_outputs(image, pose, image_changed=True)
+        worst, worst_name, spread = 0.0, "", 0.0
+        for k in range(33):
+            got = outs[k][0].cpu().numpy()
+            assert np.isfinite(got).all(), (mb, fo.OUTPUT_NAMES[k])
+            err = float(np.abs(got[:, SUB, SUB] - full_io[f"ref32_sub_out{k}"][0]).max())
+            if err > worst:
+                worst, worst_name = err, fo.OUTPUT_NAMES[k]
+            if err > _tol(fo.OUTPUT_NAMES[k]):
+                bad.append((mb, fo.OUTPUT_NAMES[k], err))
+            if base is not None:
+                spread = max(spread, float((outs[k] - base[k]).abs().max()))
+        if base is None:
+            base = [o.clone() for o in outs]
+        # the full batch the handle was built for (shared image): finite, and frame 0 keeps its bytes
+        if mb > 1:
+            many = p.get_posing_outputs(image, pose.unsqueeze(0).repeat(mb, 1), image_changed=True, indices=(0,))[0]
+            assert many.shape[0] == mb and torch.equal(many[0], outs[0][0]) and torch.equal(many[mb - 1], outs[0][0])
+        lines.append(f"max_batch {mb:2d}: worst output vs reference {worst:.3e} ({worst_name}); max |delta| to the max_batch-1 plan {spread:.3e}")
+        p.free()
+        del p
+        torch.cuda.empty_cache()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/full_plan_sweep_report.txt", "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    assert not bad, bad
+
+
 def test_all_33_outputs_full_frame_vs_oracle(poser1, weights, full_io, golden_io):
     poser = poser1
     """Every pixel of every output (not a pixel subset) for one pose, against the CPU oracle (pinned to the reference
@@ -283,3 +363,62 @@ def test_mode_12_three_network_poser(poser, weights, full_io, golden_io):
         assert err <= TOL, (j, err)
     assert torch.equal(p12.pose(image, poses[0]), outs[0][0:1])          # default output = face morpher output 0
     p12.free()
+
+
+def test_full_fused_display_rgba8(poser1, full_io, golden_io):
+    """tha4_full_pose_ex / tha4_display: the display epilogue fused into the upscaler's tail gives the bytes of the standalone
+    kernel on the fp32 frame (character_model_ifacialmocap_puppeteer.py:325-349,377-381)."""
+    from tha4_amd import image_io
+    dev = torch.device("cuda:0")
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    pose = torch.from_numpy(full_io["poses"][1]).to(dev)
+    frame = poser1.pose(image, pose, image_changed=True)
+    for bg in (None, (0.0, 1.0, 0.0)):
+        fused = poser1.pose_display_rgba8(image, pose, background_rgb=bg)
+        assert fused.shape == (1, 512, 512, 4) and fused.dtype == torch.uint8
+        assert torch.equal(fused, image_io.to_display_rgba8(frame, bg))
+    assert torch.equal(poser1.pose(image, pose), frame)                     # the fp32 path is untouched by the option
+
+
+def test_numeric_range_guard_and_regrow_policy(weights, golden_io, full_io):
+    """(1) Operands are staged as unscaled fp16 hi/lo halves: a normalised + activated value of |v| >= 65520 is outside the
+    path's range (DESIGN.md §4b "Numerics").  It must not pass silently: the kernels raise a sticky flag where every such
+    fault ends up, `check_numeric_range()` (synchronous) and the NEXT pose call report it once.  (2) A batch beyond max_batch
+    re-plans the handle: never silently (`regrow_policy`)."""
+    import copy
+    import warnings
+    from tha4_amd import _capi
+    dev = torch.device("cuda:0")
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    pose = torch.from_numpy(full_io["poses"][0]).to(dev)
+    bad = copy.deepcopy(weights)
+    # InstanceNorm gain of the face morpher's first block x 2e5: its ReLU output, O(1) for the standard set, becomes O(1e5+)
+    bad["face_morpher"]["downsample_blocks.0.1.weight"] = bad["face_morpher"]["downsample_blocks.0.1.weight"] * 2e5
+    p = mode_07.create_poser_from_state_dicts(dev, bad, max_batch=1)
+    p.pose(image, pose)                                              # never synchronises: the faulting call itself returns
+    with pytest.raises(_capi.Tha4Error, match="numeric fault"):
+        p.check_numeric_range()
+    p.check_numeric_range()                                          # report-and-clear
+    p.pose(image, pose)
+    torch.cuda.synchronize()
+    with pytest.raises(_capi.Tha4Error, match="numeric fault"):      # the next call reports the earlier call's fault
+        p.pose(image, pose)
+    p.free()
+    # the same gain at 1e3 (staged values of O(1e3..1e4)) is inside the range: no flag, finite outputs
+    ok = copy.deepcopy(weights)
+    ok["face_morpher"]["downsample_blocks.0.1.weight"] = ok["face_morpher"]["downsample_blocks.0.1.weight"] * 1e3
+    p = mode_07.create_poser_from_state_dicts(dev, ok, max_batch=1)
+    out = p.pose(image, pose)
+    p.check_numeric_range()
+    assert torch.isfinite(out).all()
+    # (2) growth beyond max_batch
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        two = p.pose(image, pose.unsqueeze(0).repeat(2, 1))
+    assert two.shape[0] == 2 and p._max_batch == 2
+    assert any(issubclass(r.category, RuntimeWarning) and "launch plan" in str(r.message) for r in rec)
+    p.regrow_policy = "error"
+    with pytest.raises(_capi.Tha4Error, match="max_batch"):
+        p.pose(image, pose.unsqueeze(0).repeat(3, 1))
+    assert p._max_batch == 2
+    p.free()

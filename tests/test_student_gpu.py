@@ -379,3 +379,72 @@ def test_warp_border_clamp_per_op(dev, gx, gy, golden_io):
     blended = 0.75 * ref + 0.25 * colour[:, None, None]
     assert np.abs(outs[0] - blended).max() < 2e-4
     p.free()
+
+
+# ---- display epilogue fused into the warp/blend tail -------------------------------------------------
+def test_fused_display_rgba8(poser, dev, golden_io):
+    """`pose_display_rgba8` (tha4_display: sRGB / background / HWC / uint8 on the values still in registers) gives the bytes of
+    `to_display_rgba8(pose())` - the standalone kernel on the fp32 frame - and is within 1 LSB of the unmodified reference's
+    post-processing of ITS frame (tests/golden/display_io.npz holds that for pose 0)."""
+    from tha4_amd import image_io
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    poses = torch.from_numpy(golden_io["poses"][:3]).to(dev)
+    frames = poser.pose(image, poses)
+    for bg in (None, (0.0, 1.0, 0.0), (0.25, 0.5, 0.75)):
+        fused = poser.pose_display_rgba8(image, poses, background_rgb=bg)
+        assert fused.shape == (3, 512, 512, 4) and fused.dtype == torch.uint8
+        assert torch.equal(fused, image_io.to_display_rgba8(frames, bg)), bg
+    both, frame = poser.pose_display_rgba8(image, poses[0], want_frame=True)
+    assert torch.equal(frame, frames[0:1]) and torch.equal(both, poser.pose_display_rgba8(image, poses[0]))
+    out = torch.zeros((1, 512, 512, 4), dtype=torch.uint8, device=dev)
+    assert poser.pose_display_rgba8(image, poses[1], out=out).data_ptr() == out.data_ptr()
+    assert torch.equal(out, poser.pose_display_rgba8(image, poses[1]))
+    # against the reference's bytes for ITS posed frame: our frame is within 3.6e-4 of it, i.e. < 0.1 LSB before the sRGB curve
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "display_io.npz"))
+    got = poser.pose_display_rgba8(image, poses[0])[0].cpu().numpy().astype(np.int32)
+    ref = z["posed_none"].astype(np.int32)
+    d = np.abs(got - ref)
+    # the sRGB curve is steep near black (12.92 x 255 x 0.5 LSB per unit): a 3.6e-4 frame difference is up to 0.6 LSB there
+    assert d.max() <= 2 and (d > 1).mean() < 1e-4 and (d > 0).mean() < 0.05, (d.max(), (d > 0).mean())
+
+
+# ---- SURVEY.md §8d config 2: parity on the first 64 frames of the stream -------------------------------------------------------
+@pytest.mark.parametrize("character", ["lambda_00", "lambda_01"])
+def test_64_pose_sweep(character, dev, char_weights, char_io):
+    """The first 64 poses of the config-2 stream (seed 1234): every posed frame, FULL size, against the oracle evaluated on this
+    box (the oracle is bit-identical to the reference, tests/test_oracle_golden.py), and the pinned ones against stride-8 pixel
+    subsets of the UNMODIFIED reference's frames (tests/golden/make_golden_sweep.py).  Writes the error distribution."""
+    import os
+    from tha4_amd.weights import split_flat_weights
+    w = char_weights[character]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"student_{character}_sweep.npz"))
+    poses, pinned = z["poses"], z["ref32_sub8_out0"]
+    assert np.array_equal(poses[:8], char_io[character]["poses"])
+    face_sd, body_sd = split_flat_weights(w)
+    p = mode_14.create_poser_from_state_dicts(dev, face_sd, body_sd, max_batch=8)
+    image_np = char_io[character]["image_f32"]
+    image = torch.from_numpy(image_np).to(dev)
+    errs, errs_pinned = [], []
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    for i0 in range(0, 64, 8):
+        got = p.pose(image, torch.from_numpy(poses[i0:i0 + 8]).to(dev)).cpu().numpy()
+        ref = so.student_forward_torch(w, image_np, poses[i0:i0 + 8], "float32")[0].numpy()
+        for k in range(8):
+            errs.append(float(np.abs(got[k] - ref[k]).max()))
+            if i0 + k < pinned.shape[0]:
+                errs_pinned.append(float(np.abs(got[k][:, 3::8, 3::8] - pinned[i0 + k]).max()))
+    errs, errs_pinned = np.array(errs), np.array(errs_pinned)
+    edges = [0, 1e-4, 2e-4, 3e-4, 4e-4, 5e-4, 7e-4, 1e-3, 1.0]
+    hist = np.histogram(errs, bins=edges)[0]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/student_{character}_sweep64.txt", "w") as fh:
+        fh.write(f"{character}: max|hip - reference fp32| of the posed frame over the first 64 poses of the config-2 stream (gate 1e-3)\n")
+        fh.write(f"full frame vs oracle on this box: max {errs.max():.3e}  median {np.median(errs):.3e}  mean {errs.mean():.3e}\n")
+        fh.write(f"pinned stride-8 subsets vs the unmodified reference ({len(errs_pinned)} poses): max {errs_pinned.max():.3e}  median {np.median(errs_pinned):.3e}\n")
+        for lo, hi, c in zip(edges[:-1], edges[1:], hist):
+            fh.write(f"  [{lo:.0e}, {hi:.0e})  {int(c):3d}  {'#' * int(c)}\n")
+        fh.write("per pose: " + " ".join(f"{e:.2e}" for e in errs) + "\n")
+    print(f"PARITY sweep {character}: max {errs.max():.3e} median {np.median(errs):.3e}; pinned max {errs_pinned.max():.3e}")
+    assert errs.max() <= 1e-3 and errs_pinned.max() <= 1e-3
+    p.free()
