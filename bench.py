@@ -166,6 +166,10 @@ class StudentWork:
     def step(self, i, out=None):
         return self.poser.pose(self.image, self.poses[i] if self.B > 1 else self.poses[i, 0], out=out)
 
+    def step_rgba8(self, i, out=None):
+        """pose + display epilogue fused in the composing kernel (tha4_display): uint8 [B,512,512,4], no fp32 frame written"""
+        return self.poser.pose_display_rgba8(self.image, self.poses[i] if self.B > 1 else self.poses[i, 0], out=out)
+
 
 class FullWork:
     kind = "full"
@@ -194,6 +198,16 @@ class FullWork:
             return out
         return r
 
+    def step_rgba8(self, i, out=None):
+        if self.B == 1:
+            r = self.poser.pose_display_rgba8(self.images[0], self.poses[i, 0], image_changed=not self.steady)
+        else:
+            r = self.poser.pose_display_rgba8(self.images[i % 2], self.poses[i])
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
 
 def timed_steps(work, lo, hi):
     for i in range(lo, hi):
@@ -217,43 +231,57 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False):
             if cuda:
                 torch.cuda.synchronize(dev)
 
+    settle_steps = 0
     with torch.no_grad():
         if args.settle_seconds > 0:                       # same frames as the warm-up steps, not counted anywhere
             t_end = time.perf_counter() + args.settle_seconds
             while time.perf_counter() < t_end:
                 timed_steps(work, 0, max(1, min(W, 8)))
+                settle_steps += max(1, min(W, 8))
                 if cuda:
                     torch.cuda.synchronize(dev)
+        work.settle_steps = settle_steps
         timed_steps(work, 0, W)
         if gather:
             want_chunk = args.gather_chunk if args.gather_chunk is not None else min(32, max(1, K * B // 5))
             chunk = max(B, want_chunk // B * B)
             shape, dtype = ((512, 512, 4), torch.uint8) if args.rgba8_gather else ((4, 512, 512), torch.float32)
 
-            def finish(blk):
-                if not args.rgba8_gather:
-                    return blk
-                from tha4_amd import image_io
-                return image_io.to_display_rgba8(blk)
+            # frames leave the rank as fp32 [4,512,512] or - display epilogue FUSED into the composing kernel (tha4_display) -
+            # as uint8 [512,512,4]: a quarter of the bytes, and no fp32 frame is ever written
+            step = work.step_rgba8 if args.rgba8_gather else work.step
 
             def frame_fn(lo, hi):          # global frame ids of this rank start at rank*K*B; whole steps only
                 base = rank * K * B
-                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+                blk = torch.empty((hi - lo,) + shape, dtype=dtype, device=dev)
                 for f in range(lo, hi, B):                                   # straight into the gather block
-                    work.step(W + (f - base) // B, out=blk[f - lo:f - lo + B])
-                return finish(blk)
+                    step(W + (f - base) // B, out=blk[f - lo:f - lo + B])
+                return blk
 
             # untimed rehearsal of the exchange - one full gather round and one ragged tail per rank - so that RCCL's
             # point-to-point connections (set up lazily on first use) exist before the clock starts
             def rehearsal_fn(lo, hi):
-                blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+                blk = torch.empty((hi - lo,) + shape, dtype=dtype, device=dev)
                 for f in range(0, hi - lo, B):
-                    work.step(0, out=blk[f:f + B])
-                return finish(blk)
+                    step(0, out=blk[f:f + B])
+                return blk
 
             FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
-            stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
-            gathered = stream.allocate_result()       # rank 0: all frames - allocated outside the timed region
+            if return_frames:              # tests: archive the whole (short) stream on rank 0
+                stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
+                gathered = stream.allocate_result()       # allocated outside the timed region
+            else:
+                # the root is a STREAM: a ring of 3 gather rounds (world x chunk frames each; 8 x 32 x 4 MiB x 3 = 3 GiB) whose
+                # consumer sees every frame once - the bench's consumer only counts them (a real one encodes / composites)
+                work.delivered = 0
+
+                def consume(lo, hi, frames_view):
+                    work.delivered += hi - lo
+
+                stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True,
+                                            on_chunk=consume, ring_slots=3)
+                work.ring_bytes = stream.ring_bytes()
+                gathered = None
             barrier()
             t0 = time.perf_counter()
             gathered = stream.run(gathered)
@@ -261,6 +289,8 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False):
             t1 = time.perf_counter()
             if return_frames:
                 frames = gathered
+            elif rank == 0 and work.delivered != K * B * world:
+                raise RuntimeError(f"gather delivered {work.delivered} of {K * B * world} frames")
             del gathered
         else:
             barrier()
@@ -277,7 +307,7 @@ def main():
                     help="student = configs[1]/[3] (default: the headline metric); full = configs[2]/[4]")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1, help="frames per Poser.pose() call (1 = configs[1]/[2]; 32 = configs[3]; 8 = configs[4] per GPU)")
-    ap.add_argument("--steps", type=int, default=None, help="timed pose() calls per rank (default 2000 student / 100 full)")
+    ap.add_argument("--steps", type=int, default=None, help="timed pose() calls per rank (default: student 2000 at batch 1, 64 at batch > 1; full 100 / 20)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed pose() calls per rank (default 200 student / 5 full)")
     ap.add_argument("--characters", default=None, help="student: lambda_00 | lambda_01 | alternate (by rank; default for --batch > 1)")
     ap.add_argument("--cold", action="store_true", help="full model, batch 1: the image changes every frame (no decomposer cache)")
@@ -291,6 +321,9 @@ def main():
     ap.add_argument("--d2h-frames", type=int, default=500, help="student N=1 B=1: steps for the RGBA8 + D2H inclusive measurement (0 = skip)")
     ap.add_argument("--exact-frames", type=int, default=500, help="student N=1 B=1: steps for the exact-fp32 generation A/B (0 = skip)")
     ap.add_argument("--full-frames", type=int, default=30, help="student N=1 B=1: frames of the appended full-model measurement (0 = skip)")
+    ap.add_argument("--batched-steps", type=int, default=24,
+                    help="student N=1 B=1: steps of the appended batched measurements - configs[3] (batch 32) and configs[4] (full model, batch 8), "
+                         "one GPU's share of each (0 = skip)")
     ap.add_argument("--settle-seconds", type=float, default=0.3,
                     help="untimed frames posed for this long BEFORE the W warm-up steps, so that a short run (--steps 20 --warmup 5) "
                          "is timed at the GPU's steady clocks like the stream it samples (0 = none)")
@@ -311,8 +344,10 @@ def main():
 
     student = args.model == "student"
     B = max(1, args.batch)
-    K = args.steps if args.steps is not None else (2000 if student else 100)
-    W = args.warmup if args.warmup is not None else (200 if student else 5)
+    # defaults: configs[1] 2000-frame stream; configs[3] 64 batches of 32; configs[2] 100 frames;
+    # configs[4] 20 batches of 8 per GPU
+    K = args.steps if args.steps is not None else ((2000 if B == 1 else 64) if student else (100 if B == 1 else 20))
+    W = args.warmup if args.warmup is not None else ((200 if B == 1 else 8) if student else (5 if B == 1 else 3))
     characters = args.characters or ("lambda_00" if B == 1 else "alternate")
     work = StudentWork(dev, rank, B, K + W, characters) if student else FullWork(dev, rank, B, K + W, steady=not args.cold)
     gather = world > 1 and not args.no_gather
@@ -329,9 +364,12 @@ def main():
             "metric": ("frames/sec (whole job) on 512x512 RGBA + 45-dim pose, " + ("distilled student" if student else "full THA4 model")),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE, "per_gpu_fps": round(fps / world, 2), "settle_seconds": args.settle_seconds}
+            "dtype": DTYPE, "per_gpu_fps": round(fps / world, 2), "settle_seconds": args.settle_seconds,
+            "settle_frames": getattr(work, "settle_steps", 0) * B}
         par = {"frames_per_gpu": K * B, "batch": B, "parallelism": f"frame-parallel x{world}",
-               "gather": ("rgba8" if args.rgba8_gather else "fp32") if gather else False}
+               "gather": ("rgba8 (display epilogue fused into the composing kernel)" if args.rgba8_gather else "fp32") if gather else False}
+        if gather:
+            par["gather_root_ring_bytes"] = getattr(work, "ring_bytes", None)
         if student:
             result["data"] = ("synthetic pose stream (seed 1234+rank, pose_parameters ranges); shipped student weights + character image "
                               "(tests/golden fixtures made from the reference's lambda_00 / lambda_01 .pt and .png)")
@@ -410,25 +448,54 @@ def student_extras(args, work, dev, world, fps, K, W, B):
                                              "what": "same stream on the exact-fp32 kernels (v_mfma_f32_16x16x4_f32, csrc/siren_kernels.h)"}
     if single and args.d2h_frames > 0:
         # SURVEY.md §8d config 2 also asks for the rate with the display epilogue + D2H of the RGBA8 frame included (what a
-        # puppeteer actually consumes): pose -> tha4_display_rgba8 -> async copy into a pinned ring.  PCIe-inclusive: never `value`.
+        # puppeteer actually consumes): pose with the epilogue FUSED into the composing kernel (tha4_display: the fp32 frame is
+        # neither written nor re-read) -> async copy into a pinned ring.  PCIe-inclusive: never `value`.
         from tha4_amd import image_io
-        ring = [torch.empty((1, 512, 512, 4), dtype=torch.uint8).pin_memory() for _ in range(4)]
-        with torch.no_grad():
-            for i in range(8):
-                ring[i % 4].copy_(image_io.to_display_rgba8(work.step(W + i)), non_blocking=True)
-            torch.cuda.synchronize(dev)
-            t0d = time.perf_counter()
-            for i in range(args.d2h_frames):
-                ring[i % 4].copy_(image_io.to_display_rgba8(work.step(W + (i % K))), non_blocking=True)
-            torch.cuda.synchronize(dev)
-            dtd = time.perf_counter() - t0d
-        out["with_rgba8_d2h"] = {"fps": round(args.d2h_frames / dtd, 2), "frames": args.d2h_frames,
-                                 "what": "pose + sRGB/uint8 display epilogue + async D2H of the 1 MiB RGBA8 frame into pinned host memory (PCIe-inclusive)"}
+        R = 4
+        host_ring = [torch.empty((1, 512, 512, 4), dtype=torch.uint8).pin_memory() for _ in range(R)]
+        dev_ring = [torch.empty((1, 512, 512, 4), dtype=torch.uint8, device=dev) for _ in range(R)]
+        side = torch.cuda.Stream(device=dev)
+        ready = [torch.cuda.Event() for _ in range(R)]
+        copied = [torch.cuda.Event() for _ in range(R)]
+
+        def d2h_rate(make):
+            """frame i -> device slot i % R on the compute stream; its copy to pinned host memory runs on a side stream (the copy
+            engine), so frame i + 1 is composed while frame i crosses PCIe; a slot is reused when its copy has completed"""
+            def one(i):
+                j = i % R
+                torch.cuda.current_stream(dev).wait_event(copied[j])
+                make(i, dev_ring[j])
+                ready[j].record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ready[j])
+                    host_ring[j].copy_(dev_ring[j], non_blocking=True)
+                    copied[j].record(side)
+            with torch.no_grad():
+                for j in range(R):
+                    copied[j].record(side)
+                for i in range(8):
+                    one(W + i)
+                torch.cuda.synchronize(dev)
+                t0d = time.perf_counter()
+                for i in range(args.d2h_frames):
+                    one(W + (i % K))
+                torch.cuda.synchronize(dev)
+                return args.d2h_frames / (time.perf_counter() - t0d)
+
+        fused = d2h_rate(lambda i, out: work.step_rgba8(i, out=out))
+        unfused = d2h_rate(lambda i, out: out.copy_(image_io.to_display_rgba8(work.step(i))))
+        out["with_rgba8_d2h"] = {"fps": round(fused, 2), "frames": args.d2h_frames,
+                                 "what": "pose with the sRGB/uint8 display epilogue fused into the composing kernel (tha4_display) + async D2H of the "
+                                         "1 MiB RGBA8 frame into pinned host memory on a side stream, 4-slot ring (PCIe-inclusive)",
+                                 "unfused_fps": round(unfused, 2),
+                                 "unfused_what": "pose (fp32 frame) -> tha4_display_rgba8 as a second kernel -> the same D2H (round 2's path)"}
     if world == 1 and args.cpu_seconds > 0:
         from oracle import student_oracle as so          # cpu_baseline leg only (oracle/ is test infrastructure)
         w, image_np, poses_cpu = work.w, work.image_np, work.poses_cpu
         out["cpu_baseline"] = cpu_baseline(lambda i: so.student_forward_torch(w, image_np, poses_cpu[i % poses_cpu.shape[0]].numpy(), "float32"),
                                            f"{work.character} student stream, oracle.student_forward_torch fp32", args.cpu_seconds, 48)
+        out["cpu_baseline"]["port_fidelity"] = ("the oracle dispatches the same ATen ops as the reference and equals the unmodified reference bit for bit on "
+                                                "every committed fixture (tests/test_oracle_golden.py; /root/reference does not exist on the GPU box)")
     if single and args.full_frames > 0:
         try:      # secondary: configs[2] in the same process (the headline must not depend on it)
             poser.free()
@@ -437,6 +504,36 @@ def student_extras(args, work, dev, world, fps, K, W, B):
             fw.poser.free()
         except Exception as e:
             out["full_model"] = {"error": repr(e)}
+    if single and args.batched_steps > 0:
+        # the batched configurations of BASELINE.json, one GPU's share each, in the driver-visible line (the N = 8 runs of the
+        # same commands are `--gpus 8 --batch 32` / `--gpus 8 --model full --batch 8`)
+        for key, make, gflop, b in (("student_b32", lambda: StudentWork(dev, 0, 32, args.batched_steps + 4, "lambda_00"), GFLOP_FRAME, 32),
+                                    ("full_b8", lambda: FullWork(dev, 0, 8, args.batched_steps + 3, steady=False), GFLOP_FULL_COLD, 8)):
+            try:
+                try:
+                    poser.free()
+                except Exception:
+                    pass
+                bw = make()
+                n = args.batched_steps if key == "student_b32" else max(4, args.batched_steps // 2)
+                with torch.no_grad():
+                    for i in range(3):
+                        bw.step(i)
+                    torch.cuda.synchronize(dev)
+                    t0b = time.perf_counter()
+                    for i in range(n):
+                        bw.step(3 + i if key == "full_b8" else 4 + i)
+                    torch.cuda.synchronize(dev)
+                    dtb = time.perf_counter() - t0b
+                f = n * b / dtb
+                out[key] = {"fps": round(f, 2), "batch": b, "steps": n, "ms_per_step": round(1e3 * dtb / n, 3),
+                            "achieved_tflops": round(f * gflop / 1e3, 2), "frac_of_f16_mfma_peak": round(f * gflop / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
+                            "frac_of_split_ceiling": round(f * gflop * MFMA_PASSES / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
+                            "workload": ("configs[3], one GPU's share: lambda_00 student, 32 poses per Poser.pose() call" if key == "student_b32" else
+                                         "configs[4], one GPU's share: full model, 8 distinct random images + poses per call, decomposer never cached")}
+                bw.poser.free()
+            except Exception as e:
+                out[key] = {"error": repr(e)}
     return out
 
 

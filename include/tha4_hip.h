@@ -143,6 +143,12 @@ int tha4_student_set_weights(tha4_student* h, const tha4_student_weights* weight
 /* Replaces: GeneralPoser02.free (general_poser_02.py:84-85).  NULL is a no-op. */
 void tha4_student_destroy(tha4_student* h);
 
+/* Test / tuning hook (no reference counterpart): copies to host memory the inter-level hand-off image the most recent pose
+ * call left in the handle's workspace for batch slot `frame`: which = 0: z1 = 30 W_{1,0}[:, :180] h_0
+ * at 128^2 (12 x 16 x 128^2 floats), 1: z2 = 30 W_{2,0}[:, :90] h_1 at 256^2 (6 x 16 x 256^2 floats); fp32, layout
+ * [block][4][pixels][4] with channel = 16 block + 4 g + j (csrc/siren_layout.h z_offset).  Synchronises the device. */
+int tha4_student_debug_read(tha4_student* h, int which, int frame, float* host_out);
+
 /* Introspection used by bench.py / tests (no reference counterpart). */
 int tha4_student_max_batch(const tha4_student* h);
 int tha4_student_device(const tha4_student* h);

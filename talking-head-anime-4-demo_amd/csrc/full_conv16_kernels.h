@@ -418,7 +418,9 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     // barrier.  Double-buffered: Q+1 goes into the OTHER buffer (nobody reads it during K group Q) before the deferred last
     // chunk barrier, which then also publishes it - one barrier per K group less, and the write overlaps the other waves'
     // last MFMAs.  (ONE call site of write_window: a second one inside the chunk loop cost 90 VGPRs and 17 % fps.)
+    THA4_PRIO_VALU();
     if (Q + 1 < q_end) write_window(go, WB ? WB - rd : 0);
+    THA4_PRIO_MFMA();
     THA4_CSTAMP();                                         // next window written
     if (WB || Q + 1 < q_end) __syncthreads();
     THA4_CSTAMP();                                         // window barrier passed

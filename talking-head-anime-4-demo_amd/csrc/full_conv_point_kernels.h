@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       // the raw stage dies in prepare(): the re-request lands in the same registers (no copies, no drain at the back edge)
+      THA4_PRIO_VALU();
       const Frag f = prepare(c * D + d, st[d]);
+      THA4_PRIO_MFMA();
       THA4_SCHED_FENCE();
       request((c + 1) * D + d, st[d]);
       multiply(d, c & 1, f);

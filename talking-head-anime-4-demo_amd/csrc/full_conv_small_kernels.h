@@ -312,7 +312,9 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     const int t0 = (u % upq) * tpu, t1 = min(a.ntaps, t0 + tpu);
     if (Q != curQ) { load_window(Q); curQ = Q; staged = false; }
     if (!staged) {                                         // wave-private LDS: program order, no workgroup barrier
+      THA4_PRIO_VALU();
       write_window();
+      THA4_PRIO_MFMA();
       staged = true;
       THA4_WAVE_SYNC();
     }

@@ -183,6 +183,7 @@ THA4_DEV void sine16_layer(const char*& gw, const float*& bias, const float*& sc
   f32x4 acc[NBW][PG];
   zero_acc<NBW, PG>(acc);
   gemm16_stream<G, NB, NBW, KG, HB, CQ, NEXT_PIECES>(gw, ring, slot, act, acc, w, true);
+  THA4_PRIO_VALU();
   const int g4 = (w.lane >> 4) * 4;
   const float inv = *scl++;
 #pragma unroll
@@ -197,6 +198,7 @@ THA4_DEV void sine16_layer(const char*& gw, const float*& bias, const float*& sc
     }
   }
   bias += NB * 16;
+  THA4_PRIO_MFMA();
   if (G::MS > 1) __syncthreads();
 }
 
@@ -503,6 +505,9 @@ THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bia
     wv += body_source(img, face, g, y1, x1) * wse;
     const float blended = (1.0f - al) * wv + al * col;
     const size_t pix = (size_t)pix0[pg] + p;
+#if defined(THA4_HUNT_WAIT_BEFORE_STORES) && !defined(THA4_EMU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // hazard hunt (tools/sin_cliff.py): no load outstanding when a store issues
+#endif
     if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
     if (d.out_rgba8) store_display(d, n, pix, g, p, blended);
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
@@ -644,6 +649,9 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   const int strip0 = xcd_tile(blockIdx.x, gridDim.x) * PGW * WAVES;
 #pragma unroll 1
   for (int k = w.wave; k < PGW * WAVES; k = wave_take_ticket(ticket, w.lane)) {
+#if defined(THA4_HUNT_WAIT_TOP) && !defined(THA4_EMU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // hazard hunt: the previous strip's stores are complete before this strip's loads
+#endif
     const int strip = strip0 + k;
     const int n = strip / STRIPS;
     int pix0[PG], X0[PG], Y[PG];
@@ -657,6 +665,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
       py[pg] = d.pos512[Y[pg]];
     }
     f16x8 xh[kKG2][PG], xl[kKG2][PG];
+    THA4_PRIO_VALU();
     first16_up_to<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py,
                            [&](int pg, int b, const f32x4& v) { put_rows<PG>(xh, xl, pg, b, v); }, w);
     const float* bias = d.b_l2;
@@ -664,7 +673,9 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
     for (int layer = 0; layer < 2; ++layer) {
       f32x4 acc[kNB2][PG];
       zero_acc<kNB2, PG>(acc);
+      THA4_PRIO_MFMA();
       mma_resident<kNB2, kKG2, PG>(layer == 0 ? w1 : w2, xh, xl, acc);
+      THA4_PRIO_VALU();
       const float inv = d.s_l2[layer];
 #pragma unroll
       for (int b = 0; b < kNB2; ++b) {
@@ -681,7 +692,9 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
     }
     f32x4 a1[1][PG];
     zero_acc<1, PG>(a1);
+    THA4_PRIO_MFMA();
     mma_resident<1, kKG2, PG>(w3, xh, xl, a1);
+    THA4_PRIO_VALU();
     warp_blend_store<PG>(d, n, bias, d.s_l2[2], pix0, px, py, a1, w);
   }
 }

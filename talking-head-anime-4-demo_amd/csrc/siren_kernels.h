@@ -122,7 +122,17 @@ THA4_DEV float sin_u(float u) {
     const float kh = th - 12582912.0f;
     float rh = fmaf(-kh, 6.28125f, u);
     rh = fmaf(-kh, 0x1.fb5444p-10f, rh);
+#if defined(THA4_HW_SIN_NOP)
+    float sv;                                              // the same instruction with wait states behind it (hazard experiment)
+    asm volatile("v_sin_f32 %0, %1\n\ts_nop 7\n\ts_nop 7" : "=v"(sv) : "v"(rh * 0x1.45f306p-3f));
+    return sv;
+#elif defined(THA4_HW_SIN_INPLACE)
+    float sv = rh * 0x1.45f306p-3f;                        // source == destination: nothing can overwrite the source early (hazard experiment)
+    asm volatile("v_sin_f32 %0, %0\n\ts_nop 1" : "+v"(sv));
+    return sv;
+#else
     return __builtin_amdgcn_sinf(rh * 0x1.45f306p-3f);
+#endif
   }
 #endif
   const float t = fmaf(u, 0x1.45f306p-2f, 12582912.0f);

@@ -378,6 +378,18 @@ int tha4_student_set_weights(tha4_student* h, const tha4_student_weights* weight
   return THA4_OK;
 }
 
+int tha4_student_debug_read(tha4_student* h, int which, int frame, float* host_out) {
+  if (!h || !host_out) return fail(THA4_ERR_INVALID_ARGUMENT, "handle/host_out must not be NULL");
+  if (frame < 0 || frame >= h->max_batch) return fail(THA4_ERR_INVALID_ARGUMENT, "frame out of range");
+  if (which != 0 && which != 1) return fail(THA4_ERR_INVALID_ARGUMENT, "which must be 0 (z1) or 1 (z2)");
+  const size_t per = which == 0 ? (size_t)kNB1 * 128 * 128 * 16 : (size_t)kNB2 * 256 * 256 * 16;
+  const float* src = (which == 0 ? h->dev.z1 : h->dev.z2) + (size_t)frame * per;
+  DeviceGuard guard(h->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, src, per * sizeof(float), hipMemcpyDeviceToHost));
+  return THA4_OK;
+}
+
 int tha4_student_max_batch(const tha4_student* h) { return h ? h->max_batch : THA4_ERR_INVALID_ARGUMENT; }
 int tha4_student_device(const tha4_student* h) { return h ? h->device : THA4_ERR_INVALID_ARGUMENT; }
 

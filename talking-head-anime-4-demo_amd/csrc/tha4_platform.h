@@ -23,6 +23,15 @@
 #define THA4_SCHED_FENCE()
 #endif
 
+// hazard hunt (tools/sin_cliff.py, never in a shipped build): drain one memory counter at every scheduling fence
+#if !defined(THA4_EMU) && defined(THA4_HUNT_FENCE_LGKM)
+#undef THA4_SCHED_FENCE
+#define THA4_SCHED_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#elif !defined(THA4_EMU) && defined(THA4_HUNT_FENCE_VM)
+#undef THA4_SCHED_FENCE
+#define THA4_SCHED_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // wave-level ordering point for wave-PRIVATE LDS traffic (one lane writes, another lane of the same wave reads): the
 // hardware executes a wave's DS instructions in program order, so nothing is needed but a fence for the compiler's
 // scheduler; the fiber emulator runs lanes one after the other and needs a real rendezvous
@@ -58,6 +67,18 @@
 #define THA4_BARRIER_LDS() __syncthreads()
 #else
 #define THA4_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+// Issue priority of a wave's current phase (round 3, tools/microbench/mfma_valu_overlap2.hip): two waves share a SIMD; by default
+// a wave issuing back-to-back MFMAs starves its partner's VALU instructions and the two phases take the SUM of their times,
+// with the VALU-phase wave at s_setprio 1 they overlap (cross-wave 16x16x32: 1059 -> 766 us for 494 us of MFMA + 565 us of FMA).
+// THA4_PRIO_VALU() opens a VALU-heavy phase (sine / staging epilogues), THA4_PRIO_MFMA() a matrix phase.
+#if !defined(THA4_EMU) && defined(THA4_PHASE_PRIO) && THA4_PHASE_PRIO
+#define THA4_PRIO_VALU() __builtin_amdgcn_s_setprio(1)
+#define THA4_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
+#else
+#define THA4_PRIO_VALU()
+#define THA4_PRIO_MFMA()
 #endif
 
 namespace tha4 {

@@ -41,8 +41,20 @@ class FrameShardedStream:
 
     def __init__(self, frame_fn: Callable[[int, int], torch.Tensor], total: int, frame_shape: Sequence[int],
                  dtype: torch.dtype, device: torch.device, chunk: int = 32,
-                 group: Optional[dist.ProcessGroup] = None, gather: bool = True):
+                 group: Optional[dist.ProcessGroup] = None, gather: bool = True,
+                 on_chunk: Optional[Callable[[int, int, torch.Tensor], None]] = None, ring_slots: int = 3):
+        """``on_chunk(lo, hi, frames)`` switches the root from an ARCHIVE of the whole stream (``allocate_result``:
+        ``total`` frames on rank 0 - 2000 steps x 32 frames x 8 ranks would be 2 TB) to a STREAM: rank 0 owns a ring of
+        ``ring_slots`` buffers of one gather round each (``world x chunk`` frames: 3 x 8 x 32 x 4 MiB = 3 GiB) and hands
+        every arrived span - global frame ids [lo, hi), a view into the ring - to the consumer, which is what a real
+        receiver (encoder, compositor, network sender) looks like.  The callback runs with the gather's side stream
+        current, i.e. whatever it enqueues there is ordered after the arrival of the data and before the slot is
+        overwritten ``ring_slots`` rounds later; a consumer that works on another stream must make that stream wait on
+        an event it records in the callback and must be done before the slot comes round again.  ``run()`` then
+        returns None."""
         self.frame_fn = frame_fn
+        self.on_chunk = on_chunk
+        self.ring_slots = max(2, int(ring_slots))
         self.total = int(total)
         self.frame_shape = tuple(int(s) for s in frame_shape)
         self.dtype = dtype
@@ -68,10 +80,24 @@ class FrameShardedStream:
             return self._empty(self.hi - self.lo)
         return self._empty(self.total) if self.rank == 0 else None
 
+    def ring_bytes(self) -> int:
+        """Bytes rank 0 holds in streaming mode (``on_chunk``): the whole receive side of the exchange."""
+        n = 1
+        for d in self.frame_shape:
+            n *= d
+        return self.ring_slots * self.world * self.chunk * n * torch.empty((), dtype=self.dtype).element_size()
+
     def run(self, result: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         sizes = all_shard_sizes(self.total, self.world)
         rounds = max((s + self.chunk - 1) // self.chunk for s in sizes)
-        if result is None:
+        streaming = self.gather and self.on_chunk is not None
+        ring = None
+        if streaming:
+            if result is not None:
+                raise RuntimeError("a result buffer and on_chunk are exclusive: the stream is consumed, not archived")
+            if self.rank == 0:
+                ring = [self._empty(self.world * self.chunk) for _ in range(self.ring_slots)]
+        elif result is None:
             result = self.allocate_result()
         else:
             want = (self.hi - self.lo if not self.gather else self.total,) + self.frame_shape
@@ -86,6 +112,11 @@ class FrameShardedStream:
             a = min(rlo + c * self.chunk, rhi)
             return a, min(a + self.chunk, rhi)
 
+        if self.gather and rounds > 0:
+            # RCCL builds a group's communicator lazily inside the first operation and that blocks until EVERY rank of the
+            # group has joined: a ragged first round in which some rank has no rows (total < world) would leave the others
+            # waiting in batch_isend_irecv forever.  One cheap collective that all ranks issue settles it.
+            dist.barrier(group=self.group)
         for c in range(rounds):
             a, b = span(self.rank, c)
             block = self.frame_fn(a, b) if b > a else None
@@ -102,17 +133,22 @@ class FrameShardedStream:
                 if block is not None:
                     block.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+                if self.rank == 0:
+                    if streaming:        # this round's slot of the ring: rank r's rows at [r * chunk, r * chunk + its count)
+                        slot = ring[c % self.ring_slots]
+                        dest = [slot[r * self.chunk:r * self.chunk + (rb - ra)] for r, (ra, rb) in enumerate(spans)]
+                    else:                # archive: every chunk lands directly in its rows of `result`
+                        dest = [result[ra:rb] for ra, rb in spans]
                 if full_round:
-                    # regular round: ONE collective, every chunk lands directly in its rows of `result` on the root
-                    recv = [result[ra:rb] for ra, rb in spans] if self.rank == 0 else None
-                    dist.gather(block, recv, dst=root, group=self.group)
+                    # regular round: ONE collective, no staging copy on the root
+                    dist.gather(block, dest if self.rank == 0 else None, dst=root, group=self.group)
                 else:
                     # ragged round (the tail of the stream): exact-size point-to-point transfers - a rank with a short
                     # or empty tail sends only what it has (nothing is zero-padded to a full chunk)
                     if self.rank == 0:
                         if block is not None:
-                            result[a:b] = block
-                        ops = [dist.P2POp(dist.irecv, result[ra:rb], dist.get_global_rank(self.group, r) if self.group is not None else r,
+                            dest[0].copy_(block)
+                        ops = [dist.P2POp(dist.irecv, dest[r], dist.get_global_rank(self.group, r) if self.group is not None else r,
                                           group=self.group)
                                for r, (ra, rb) in enumerate(spans) if r != 0 and rb > ra]
                     else:
@@ -120,6 +156,10 @@ class FrameShardedStream:
                     if ops:
                         for req in dist.batch_isend_irecv(ops):
                             req.wait()
+                if streaming and self.rank == 0:
+                    for r, (ra, rb) in enumerate(spans):
+                        if rb > ra:
+                            self.on_chunk(ra, rb, dest[r])
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
         return result

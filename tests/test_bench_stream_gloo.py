@@ -71,3 +71,50 @@ def test_measure_two_ranks(K, W, B, chunk):
     for f in range(2 * K * B):
         r, j = divmod(f, K * B)
         assert rows[f].item() == 1000.0 * r + W + j // B           # frame f at row f, made by rank r at its step W + j // B
+
+
+def _stream_worker(rank, world, rendezvous, K, W, B, rgba8, q):
+    os.environ["GLOO_SOCKET_IFNAME"] = os.environ.get("GLOO_SOCKET_IFNAME", "lo")
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
+    work = _StubWork(rank, B)
+
+    def step_rgba8(i, out=None):                       # what StudentWork.step_rgba8 does: uint8 [B,512,512,4] straight into `out`
+        work.calls.append(i)
+        if out is None:
+            out = torch.empty(B, 512, 512, 4, dtype=torch.uint8)
+        out.fill_((7 * rank + i) % 251)
+        return out
+    work.step_rgba8 = step_rgba8
+    args = argparse.Namespace(no_gather=False, rgba8_gather=rgba8, gather_chunk=4, settle_seconds=0.0)
+    elapsed = bench.measure(work, args, torch.device("cpu"), rank, world, K, W, B, dist)       # the driver's path: the root streams
+    q.put((rank, elapsed, work.calls, getattr(work, "delivered", None), getattr(work, "ring_bytes", None)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rgba8", [False, True])
+def test_measure_streams_through_a_ring_on_the_root(rgba8):
+    """What `bench.py --gpus N` runs: rank 0 holds a ring of three gather rounds, not the whole stream, and its consumer sees every
+    frame of every rank once (fp32 frames, or RGBA8 frames from the fused display epilogue)."""
+    K, W, B = 30, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_stream_worker, args=(r, 2, os.path.join(d, "rendezvous"), K, W, B, rgba8, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(2):
+            r = q.get(timeout=240)
+            res[r[0]] = r
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    frame_bytes = 512 * 512 * 4 * (1 if rgba8 else 4)
+    assert res[0][3] == 2 * K * B and res[0][4] == 3 * 2 * 4 * frame_bytes        # delivered everything through 3 slots of 2 ranks x 4 frames
+    assert res[0][4] * 4 < 2 * K * B * frame_bytes
+    for r in (0, 1):
+        timed = [i for i in res[r][2] if i >= W]
+        assert timed == list(range(W, W + K))

@@ -422,3 +422,36 @@ def test_numeric_range_guard_and_regrow_policy(weights, golden_io, full_io):
         p.pose(image, pose.unsqueeze(0).repeat(3, 1))
     assert p._max_batch == 2
     p.free()
+
+
+def test_content_equivalent_decomposer_cache(weights, full_io, golden_io):
+    """`content_cache = True`: the reference's rule (mode_07.py:56-61, reuse while max|image - cached| == 0) behind the
+    identity rules - a caller that re-uploads an identical image every frame hits the cache like it does in the reference,
+    and an in-place edit can never serve a stale result (the comparison is against a private copy)."""
+    from oracle.student_oracle import synthetic_image
+    dev = torch.device("cuda:0")
+    p = mode_07.create_poser_from_state_dicts(dev, weights, max_batch=1)
+    p.content_cache = True
+    pose = torch.from_numpy(full_io["poses"][1]).to(dev)
+    a_np, b_np = golden_io["image_f32"], synthetic_image(seed=123)
+    cold_a = p.pose(torch.from_numpy(a_np).to(dev), pose, image_changed=True).clone()
+    lib, calls = p._lib, []
+    real = lib.tha4_full_pose_ex
+
+    class Spy:                                            # records the reuse_decomposer flag of every native call
+        def __call__(self, *args):
+            calls.append(int(args[6]))
+            return real(*args)
+    p._lib = type("L", (), {"tha4_full_pose_ex": Spy(), "tha4_last_error": lib.tha4_last_error, "tha4_full_destroy": lib.tha4_full_destroy,
+                            "tha4_full_create_ex": lib.tha4_full_create_ex, "tha4_full_numeric_status": lib.tha4_full_numeric_status})()
+    for _ in range(3):                                    # a FRESH upload of the same content every frame
+        assert torch.equal(p.pose(torch.from_numpy(a_np.copy()).to(dev), pose), cold_a)
+    assert calls == [1, 1, 1], calls                      # cache hits by content
+    out_b = p.pose(torch.from_numpy(b_np).to(dev), pose)
+    assert calls[-1] == 0 and not torch.equal(out_b, cold_a)
+    img = torch.from_numpy(b_np).to(dev)
+    assert torch.equal(p.pose(img, pose), out_b) and calls[-1] == 1
+    img.copy_(torch.from_numpy(a_np).to(dev))             # in-place edit of the tensor just posed
+    assert torch.equal(p.pose(img, pose), cold_a) and calls[-1] == 0
+    p._lib = lib
+    p.free()

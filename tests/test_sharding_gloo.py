@@ -122,3 +122,56 @@ def test_two_rank_rgba8_gather():
     assert full.dtype == torch.uint8 and full.shape == (total, 4, 4, 2)
     for i in range(total):
         assert torch.equal(full[i], _to_u8(_frame(i)[None])[0])
+
+
+def _stream_worker(rank, world, rendezvous, total, chunk, slots, q):
+    os.environ["GLOO_SOCKET_IFNAME"] = os.environ.get("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
+    got = []
+
+    def frame_fn(lo, hi):
+        return torch.stack([_frame(i) for i in range(lo, hi)])
+
+    def on_chunk(lo, hi, frames):                    # the consumer: must take what it needs before the slot comes round again
+        assert frames.shape == (hi - lo, 2, 4, 4)
+        got.append((lo, hi, frames.numpy().copy()))       # numpy: pickled by value through the queue
+
+    s = FrameShardedStream(frame_fn, total, (2, 4, 4), torch.float32, torch.device("cpu"), chunk=chunk, gather=True,
+                           on_chunk=on_chunk, ring_slots=slots)
+    out = s.run()
+    q.put((rank, out is None, s.ring_bytes(), got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,chunk,slots", [(203, 4, 2), (64, 8, 3), (1, 4, 2)])
+def test_two_rank_streaming_gather_with_a_small_ring(total, chunk, slots):
+    """The root as a STREAM, not an archive: a ring of `slots` gather rounds on rank 0 (a few frames) carries a stream far
+    larger than itself; every frame reaches the consumer exactly once, with its global index, whichever rank made it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_stream_worker, args=(r, 2, os.path.join(d, "rendezvous"), total, chunk, slots, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(2):
+            r = q.get(timeout=120)
+            res[r[0]] = r
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    assert res[0][1] and res[1][1]                                  # run() returns None in streaming mode
+    frame_bytes = 2 * 4 * 4 * 4
+    assert res[0][2] == slots * 2 * chunk * frame_bytes
+    if total > 100:
+        assert res[0][2] * 4 < total * frame_bytes                  # the ring is a fraction of the stream
+    assert res[1][3] == []                                          # only the root consumes
+    seen = {}
+    for lo, hi, frames in res[0][3]:
+        for i in range(lo, hi):
+            assert i not in seen
+            seen[i] = frames[i - lo]
+    assert sorted(seen) == list(range(total))
+    for i in range(total):
+        assert (seen[i] == _frame(i).numpy()).all()

@@ -448,3 +448,36 @@ def test_64_pose_sweep(character, dev, char_weights, char_io):
     print(f"PARITY sweep {character}: max {errs.max():.3e} median {np.median(errs):.3e}; pinned max {errs_pinned.max():.3e}")
     assert errs.max() <= 1e-3 and errs_pinned.max() <= 1e-3
     p.free()
+
+
+def test_hand_off_images_vs_oracle(poser, dev, golden_weights, golden_io):
+    """The inter-level hand-off images on the device (z1 at 128^2, z2 at 256^2: DESIGN.md §2 item 3, read back through
+    tha4_student_debug_buffer) against the fp64 restatement of the same restructured quantities
+    (oracle.student_intermediates, proven equal to the reference's order of operations on CPU)."""
+    pose_np = golden_io["poses"][1]
+    poser.pose(torch.from_numpy(golden_io["image_f32"]).to(dev), torch.from_numpy(pose_np).to(dev))
+    inter = so.student_intermediates(golden_weights, pose_np)
+    for level, c in ((1, 180), (2, 90)):
+        z = poser.debug_hand_off(level).numpy()
+        ref = inter[f"z{level}"]
+        err = float(np.abs(z[:c] / 30.0 - ref).max())
+        print(f"PARITY hand-off z{level}: max abs err {err:.3e} (max |z| {np.abs(ref).max():.2f})")
+        assert err <= 2e-4 * max(1.0, float(np.abs(ref).max())), (level, err)
+        assert np.abs(z[c:]).max() == 0.0                       # padded channels are exact zeros
+
+
+def test_determinism_stress(poser, dev, golden_io):
+    """500 evaluations of four poses (batch 1 and batch 4, dynamic strip hand-out in level 2): every evaluation of a pose gives
+    the same bytes on all six outputs.  (A -DTHA4_HW_SIN build of level2_16p_kernel<8,4,2> - never shipped - produced run-to-run
+    varying pixels on the device, profiles/r03_sin_cliff.md: this is the guard that the shipped build does not.)"""
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    poses = torch.from_numpy(golden_io["poses"][:4]).to(dev)
+    base = [o.clone() for o in poser.get_posing_outputs(image, poses)]
+    bad = 0
+    for it in range(100):
+        outs = poser.get_posing_outputs(image, poses)
+        bad += sum(int(not torch.equal(a, b)) for a, b in zip(outs, base))
+        for i in range(4):
+            one = poser.pose(image, poses[i])
+            bad += int(not torch.equal(one[0], base[0][i]))
+    assert bad == 0, f"{bad} evaluations differed"

@@ -1,0 +1,4 @@
+set -x
+mkdir -p gpurun_out; export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+timeout 600 python tools/sin_cliff.py 0 --skip-eval --libs=hwsin_nop,hwsin_inplace > gpurun_out/r03_sin_cliff_variants5.txt 2> gpurun_out/r03_sin_cliff_variants5.err; grep "^|" gpurun_out/r03_sin_cliff_variants5.txt; tail -3 gpurun_out/r03_sin_cliff_variants5.err

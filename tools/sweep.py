@@ -17,18 +17,39 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "p881": ["-DTHA4_L216P_CFG=8,8,1"],
+    "hwsin": ["-DTHA4_HW_SIN"],          # v_sin_f32 sine (tools/sin_cliff.py; never shipped)
+    "hwsin_nop": ["-DTHA4_HW_SIN", "-DTHA4_HW_SIN_NOP"],
+    "hwsin_stream": ["-DTHA4_HW_SIN", "-DTHA4_L2_RESIDENT=0"],
+    "hwsin_pg1": ["-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1"],
+    "hwsin_wait0": ["-DTHA4_HW_SIN", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],     # hazard hunt: every memory wait forced to zero
+    "hwsin_nopipe": ["-DTHA4_HW_SIN", "-DTHA4_NO_PIPELINE"],                         # hazard hunt: no sched_barrier fences
+    "hwsin_pad": ["-DTHA4_HW_SIN", "-mllvm", "-amdgpu-mfma-padding-ratio=100"],      # hazard hunt: MFMAs padded apart
+    "hwsin_ws": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_WAIT_BEFORE_STORES"],
+    "hwsin_wt": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_WAIT_TOP"],
+    "hwsin_fl": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_FENCE_LGKM"],
+    "hwsin_fv": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_FENCE_VM"],
+    "hwsin_inplace": ["-DTHA4_HW_SIN", "-DTHA4_HW_SIN_INPLACE"],
+    "wait0": ["-mllvm", "-amdgpu-waitcnt-forcezero=1"],          # the shipped source with every memory wait forced to zero (tools/compare_libs.py)
+    "hwsin_pg1_wait0": ["-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "hwsin_pg1": ["-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1"],
+    "pg1": ["-DTHA4_L216P_CFG=8,8,1"],    # weights-resident level 2 with one pixel group per strip
+    "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
+if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["THA4_SWEEP_VARIANTS"].split(",")}
 
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    for name, flags in VARIANTS.items():
+    procs = []
+    for name, flags in VARIANTS.items():            # all variants at once: one hipcc process each
         out = os.path.join(OUT, f"libtha4_{name}.so")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, "-I",
                os.path.join(ROOT, "include")] + flags + [os.path.join(CSRC, "tha4_capi.hip"), "-o", out]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        print(name, "OK" if r.returncode == 0 else "FAILED\n" + r.stderr[-2000:])
+        procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for name, p in procs:
+        _, err = p.communicate()
+        print(name, "OK" if p.returncode == 0 else "FAILED\n" + err[-2000:])
 
 
 def run(steps):
