@@ -144,10 +144,13 @@ int tha4_student_set_weights(tha4_student* h, const tha4_student_weights* weight
 void tha4_student_destroy(tha4_student* h);
 
 /* Test / tuning hook (no reference counterpart): copies to host memory the inter-level hand-off image the most recent pose
- * call left in the handle's workspace for batch slot `frame`: which = 0: z1 = 30 W_{1,0}[:, :180] h_0
- * at 128^2 (12 x 16 x 128^2 floats), 1: z2 = 30 W_{2,0}[:, :90] h_1 at 256^2 (6 x 16 x 256^2 floats); fp32, layout
+ * call left in the handle's workspace for batch slot `frame`: which = 0: z1 = s W_{1,0}[:, :180] h_0
+ * at 128^2 (12 x 16 x 128^2 floats), 1: z2 = s W_{2,0}[:, :90] h_1 at 256^2, s = tha4_student_hand_off_scale() (6 x 16 x 256^2 floats); fp32, layout
  * [block][4][pixels][4] with channel = 16 block + 4 g + j (csrc/siren_layout.h z_offset).  Synchronises the device. */
 int tha4_student_debug_read(tha4_student* h, int which, int frame, float* host_out);
+/* The factor the hand-off images (and every sine argument) carry: omega_0 / (2 pi) = 4.7746 - the sine takes turns - in the
+ * default kernels, 1 with THA4_STUDENT_EXACT_FP32. */
+float tha4_student_hand_off_scale(const tha4_student* h);
 
 /* Introspection used by bench.py / tests (no reference counterpart). */
 int tha4_student_max_batch(const tha4_student* h);

@@ -612,6 +612,14 @@ THA4_DEV void mma_resident(const char* wv, const f16x8 (&xh)[KG][PG], const f16x
   }
 }
 
+constexpr bool defined_hw_sin() {
+#ifdef THA4_HW_SIN
+  return true;
+#else
+  return false;
+#endif
+}
+
 template <int WAVES, int PGW, int PG>
 struct Level2PCfg {
   static constexpr int kHidden = kNB2 * kKG2;                         // pieces of one 96->96 layer
@@ -622,6 +630,11 @@ struct Level2PCfg {
   static constexpr int PX = WAVES * PGW * PG * 16;
   using G = Geo16<WAVES, 1, PG, kKG2, 1>;
   static_assert((kImg * kImg) % PX == 0, "a frame must be a whole number of workgroups");
+#if !defined(THA4_ALLOW_L216P_PG2) && !defined(THA4_EMU)
+  static_assert(PG == 1 || !(THA4_SIN_TURNS || defined_hw_sin()),
+                "level2_16p_kernel with two pixel groups per strip is faulty on the device with a v_sin_f32 sine (see THA4_L216P_CFG); "
+                "-DTHA4_ALLOW_L216P_PG2 builds it anyway (fault-hunt builds only)");
+#endif
   static_assert(LDS + 16 * kNB2 * 4 <= 80 * 1024, "two workgroups per CU must still fit");
 };
 
@@ -714,11 +727,18 @@ namespace cfg {
 #define THA4_L216_CFG 4, 1, 1, 1            // NS, MS, PG, CQ
 #endif
 #ifndef THA4_L216P_CFG
-// WAVES, strips per wave, pixel groups per strip (weights-resident level 2): one A fragment feeds two pixel groups.
-// An earlier build of this geometry needed 256 VGPRs + scratch (all 24 tap loads of both pixel groups in flight) and
-// produced wrong, run-to-run varying pixels on the device while passing the emulator; since the tap loads are
-// capped (first16_up_to) no student kernel uses scratch, which tests/test_api_surface.py now gates on.
-#define THA4_L216P_CFG 8, 4, 2
+// WAVES, strips per wave, pixel groups per strip (weights-resident level 2).  ONE pixel group per strip since round 3.
+// Rounds 1-2 shipped <8, 4, 2> (one A fragment feeds two pixel groups; +1.6 % with the 12-op polynomial sine).  That
+// instantiation is FAULTY as soon as the sine is a v_sin_f32 - with the turn-based sine as much as with a Cody-Waite +
+// v_sin_f32 build: run-to-run varying pixels (30-100 per frame, errors up to 1.5), z1 / z2 / the face and every other kernel
+// correct, the sine instruction itself accurate to 3.8e-7 on every argument of the frame.  The same source compiled with
+// `-mllvm -amdgpu-waitcnt-forcezero=1` is correct and deterministic; neither wait states behind the v_sin_f32, an in-place
+// v_sin_f32, MFMA padding, nor draining vmcnt / lgkmcnt at every scheduling fence or around the stores repairs it
+// (profiles/r03_sin_cliff.md: the whole hunt).  <8, 8, 1> with the same sine equals ITS forced-wait build bit for bit over both
+// characters' sweeps, is deterministic under tests/test_student_gpu.py::test_determinism_stress, and is as fast (50.8 us
+// against 51.5).  The round-1 "256 VGPRs + scratch -> wrong, varying pixels" incident of this geometry was most likely the
+// same fault, not the spill it was blamed on.
+#define THA4_L216P_CFG 8, 8, 1
 #endif
 #ifndef THA4_L2_RESIDENT
 #define THA4_L2_RESIDENT 1                  // 1: level2_16p_kernel, 0: streamed level2_16_kernel
@@ -794,7 +814,7 @@ struct StudentPacked16 {
 // mirrors pack_student (siren_layout.h); `p1` is the generation-1 pack of the same weights (bias / first-layer tables)
 inline void pack_student16(const StudentWeightsView& v, const StudentPacked& p1, StudentPacked16& p) {
   p = StudentPacked16();
-  constexpr float W30 = kOmega;
+  constexpr float W30 = kSineScale16;          // omega_0 in the unit the sine takes: turns (default) or radians
   for (int i = 1; i < 8; ++i) p.s_face.push_back(pack_layer16(v.face_sine[i].weight, kCF, 0, kCF, kCF, kNBF, kKGF, cfg::kFaceMS, 1, W30, p.w_face));
   p.s_face.push_back(pack_layer16(v.face_last.weight, kCF, 0, 4, kCF, 1, kKGF, 1, 1, 1.0f, p.w_face));
   p.s_l0.push_back(pack_layer16(v.body_sine[0][1].weight, kC0, 0, kC0, kC0, kNB0, kKG0, cfg::kL0MS, cfg::kL0HBA, W30, p.w_l0));

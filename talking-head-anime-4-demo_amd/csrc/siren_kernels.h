@@ -106,13 +106,24 @@ THA4_DEV float sin_omega(float z) {
   return __uint_as_float(__float_as_uint(s) ^ flip);
 }
 
-// sin(u) for a pre-scaled argument (generation 2 folds the 30x into weights and biases): k = rint(u/pi) comes from
+// The sine of generation 2 for a pre-scaled argument.  Default (THA4_SIN_TURNS): the argument is in TURNS (omega_0 / 2 pi is
+// folded into weights and biases, siren_layout.h) and the sine is ONE v_sin_f32, which reduces its argument itself (valid for
+// |t| <= 256 turns; the shipped students stay below 7) - 3.8e-7 max abs error over every argument of a frame
+// (tools/sin_cliff.py, profiles/r03_sin_cliff.md) against 1.4e-7 for the polynomial below, and the posed frame is as close to
+// the reference (64-pose sweeps, both characters).  THA4_SIN_TURNS=0: radians; k = rint(u/pi) comes from
 // adding 1.5*2^23 (valid for |u| < 2^22 pi; the low mantissa bit of the sum is the parity of k), r = u - k pi by a
-// 2-term Cody-Waite (k * 3.140625 is exact for |k| < 2^16; total error <= |k| 6e-11), same degree-9 polynomial.
+// 2-term Cody-Waite (k * 3.140625 is exact for |k| < 2^16; total error <= |k| 6e-11), degree-9 polynomial:
 // 12 VALU ops: fma, sub, 2 fma, mul, 3 fma, mul, fma, shift, xor.
 THA4_DEV float sin_u(float u) {
 #ifdef THA4_ABLATE_SIN   // timing ablation only (tools/sweep.py): results are wrong
   return u;
+#endif
+#if THA4_SIN_TURNS
+#ifdef THA4_EMU
+  return (float)sin(6.283185307179586476925 * (double)u);
+#else
+  return __builtin_amdgcn_sinf(u);
+#endif
 #endif
 #if defined(THA4_HW_SIN) && !defined(THA4_EMU)
   // A/B variant (tools/sin_cliff.py, profiles/r03_sin_cliff.md; never shipped): k = rint(u / 2 pi) by the magic add, 2-term

@@ -24,6 +24,18 @@ constexpr int kFaceSize = 128;
 constexpr int kFaceTop = 80;       // mode_14.py:61-63: centre (256,144) +- 64
 constexpr int kFaceLeft = 192;
 constexpr float kOmega = 30.0f;    // siren.py:17
+// Generation 2 measures sine arguments in TURNS: the packed weights, biases, first-layer tables and z hand-off of every layer
+// that feeds a sine carry omega_0 / (2 pi) instead of omega_0, so that sin(30 (W x + b)) is ONE v_sin_f32 on the accumulator
+// (the instruction takes revolutions and reduces the argument itself: fract() of an fp32 value is exact).  Round 2 carried 30 and
+// spent 12 VALU slots per sine on k = rint(u / pi), a 2-term Cody-Waite reduction and a degree-9 polynomial; VALU time is
+// additive to MFMA time on this chip (profiles/r03_mfma_valu_overlap2.txt) and the student evaluates 131.8 M sines per frame.
+// fl32(30 / 2 pi) * 2 pi = 30 (1 - 2.2e-8): the posed frame moves by 3-4e-5 (fp64 simulation, 3 poses), a tenth of the distance
+// between two correct fp32 evaluations of the reference.  -DTHA4_SIN_TURNS=0 restores the radian pipeline (A/B builds).
+#ifndef THA4_SIN_TURNS
+#define THA4_SIN_TURNS 1
+#endif
+constexpr float kSineTurns = 4.774648292756860f;     // 30 / (2 pi)
+constexpr float kSineScale16 = THA4_SIN_TURNS ? kSineTurns : kOmega;
 
 // z hand-off image between levels: z[n][block][g][pixel][4] - rows 4g..4g+3 of a 16-row block are what lane group g
 // of an MFMA C/D fragment holds, so a quarter wave (fixed g, 16 consecutive pixels) writes one 256 B run and the x2

@@ -262,7 +262,7 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   }
   d.pos128 = F(o.p128); d.pos256 = F(o.p256); d.pos512 = F(o.p512);
   d.s_face = F(o.sf); d.s_l0 = F(o.s0); d.s_l1 = F(o.s1); d.s_l2 = F(o.s2);
-  d.pb_scale = exact ? 1.0f : kOmega;
+  d.pb_scale = exact ? 1.0f : kSineScale16;
   char* ws = h->workspace;
   d.pbias = reinterpret_cast<float*>(ws); ws += s_pb;
   d.face = reinterpret_cast<float*>(ws); ws += s_face;
@@ -389,6 +389,8 @@ int tha4_student_debug_read(tha4_student* h, int which, int frame, float* host_o
   HIP_TRY(hipMemcpy(host_out, src, per * sizeof(float), hipMemcpyDeviceToHost));
   return THA4_OK;
 }
+
+float tha4_student_hand_off_scale(const tha4_student* h) { return h ? h->dev.pb_scale : 0.0f; }
 
 int tha4_student_max_batch(const tha4_student* h) { return h ? h->max_batch : THA4_ERR_INVALID_ARGUMENT; }
 int tha4_student_device(const tha4_student* h) { return h ? h->device : THA4_ERR_INVALID_ARGUMENT; }

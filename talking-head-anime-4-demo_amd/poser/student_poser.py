@@ -261,12 +261,14 @@ class HipStudentPoser(Poser):
     def debug_hand_off(self, level: int, frame: int = 0) -> Tensor:
         """Test hook (tha4_student_debug_read): the z hand-off image the most recent pose call wrote for body level
         ``level`` (1 or 2) and batch slot ``frame``, un-permuted to ``[C_padded, S, S]`` fp32 on the CPU (S = 128 / 256) -
-        equal to ``30 * oracle.student_intermediates(...)["z<level>"]`` on the real channels."""
+        divided by the factor the kernels fold into it (``tha4_student_hand_off_scale``: omega_0 / 2 pi), i.e. equal to
+        ``oracle.student_intermediates(...)["z<level>"]`` on the real channels."""
         nb, side = (12, 128) if level == 1 else (6, 256)
         host = torch.empty(nb * 16 * side * side, dtype=torch.float32)
         _capi.check(self._lib, self._lib.tha4_student_debug_read(self._handle, level - 1, frame, host.data_ptr()),
                     "tha4_student_debug_read")
-        return host.view(nb, 4, side * side, 4).permute(0, 1, 3, 2).reshape(nb * 16, side, side)     # [block][g][pixel][j] -> channel 16b+4g+j
+        scale = float(self._lib.tha4_student_hand_off_scale(self._handle))
+        return host.view(nb, 4, side * side, 4).permute(0, 1, 3, 2).reshape(nb * 16, side, side) / scale   # [block][g][pixel][j] -> channel 16b+4g+j
 
     # ---- measurement hooks (bench.py) ----------------------------------------------------------
     def set_timing(self, enable: bool):

@@ -90,7 +90,7 @@ void* emu_student_create_gen(const tha4_student_weights* w, const tha4_position_
     d.b_face = q.b_face.data(); d.b_l0 = q.b_l0.data(); d.b_l1 = q.b_l1.data(); d.b_l2 = q.b_l2.data();
     d.s_face = q.s_face.data(); d.s_l0 = q.s_l0.data(); d.s_l1 = q.s_l1.data(); d.s_l2 = q.s_l2.data();
     for (int i = 0; i < 4; ++i) { d.wx[i] = q.wx[i].data(); d.wy[i] = q.wy[i].data(); }
-    d.pb_scale = kOmega;
+    d.pb_scale = kSineScale16;
   }
   d.pos128 = e->pos128.data(); d.pos256 = e->pos256.data(); d.pos512 = e->pos512.data();
   d.pbias = b["pbias"].data(); d.z1 = b["z1"].data(); d.z2 = b["z2"].data(); d.face = b["face"].data();
@@ -177,6 +177,7 @@ void emu_student_block_pixels(int kernel, int block, int* first, int* count) { e
 
 float emu_sin_omega(float z) { return sin_omega(z); }
 float emu_sin_u(float u) { return sin_u(u); }
+float emu_sine_scale16() { return kSineScale16; }      // what generation 2 folds into biases / z hand-off: omega_0 / 2 pi (turns) or omega_0
 
 void emu_student_destroy(void* h) { delete static_cast<EmuStudent*>(h); }
 

@@ -68,8 +68,12 @@ class EmuStudent:
 
     @property
     def handoff_scale(self):
-        """Generation 2 folds the sine's 30x into the pose-folded biases and the z hand-off images."""
-        return 30.0 if self.gen == 2 else 1.0
+        """Generation 2 folds the sine's frequency - omega_0 / 2 pi, the sine takes turns - into the pose-folded biases and the
+        z hand-off images."""
+        if self.gen != 2:
+            return 1.0
+        self.lib.emu_sine_scale16.restype = C.c_float
+        return float(self.lib.emu_sine_scale16())
 
     def close(self):
         if self.h:

@@ -460,7 +460,7 @@ def test_hand_off_images_vs_oracle(poser, dev, golden_weights, golden_io):
     for level, c in ((1, 180), (2, 90)):
         z = poser.debug_hand_off(level).numpy()
         ref = inter[f"z{level}"]
-        err = float(np.abs(z[:c] / 30.0 - ref).max())
+        err = float(np.abs(z[:c] - ref).max())
         print(f"PARITY hand-off z{level}: max abs err {err:.3e} (max |z| {np.abs(ref).max():.2f})")
         assert err <= 2e-4 * max(1.0, float(np.abs(ref).max())), (level, err)
         assert np.abs(z[c:]).max() == 0.0                       # padded channels are exact zeros

@@ -29,7 +29,7 @@ def student():
     if os.path.exists(os.path.join(G, "student_b1_traffic.json")):
         shutil.copy(os.path.join(G, "student_b1_traffic.json"), os.path.join(P, f"{tag}_student_b1_traffic.json"))
     md = [f"# {tag} - student path, batch 1 stream (`bench.py --steps 200 --warmup 50 --profile-frames 5 --full-frames 0 --d2h-frames 0 --exact-frames 0`), MI355X",
-          "Source: `tools/profile_r02.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes; FETCH_SIZE and WRITE_SIZE each in",
+          f"Source: `tools/profile_{tag}.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes; FETCH_SIZE and WRITE_SIZE each in",
           "its own pass: together they abort rocprofv3 on this image).  Kernels: generation 2 (fp16 hi/lo split MFMA), weights-resident",
           f"level 2, XCD-aware tile order, face + level 0 in one launch, pose bias folded into the prologues.  Machine-readable traffic: `{tag}_student_b1_traffic.json`.", "",
           f"## rocprofv3 --kernel-trace --stats (full CSV: {tag}_student_b1_kernel_stats.csv)", stats_table(os.path.join(G, "ps_kernel_stats.csv")), "",
@@ -46,7 +46,7 @@ def full():
     if os.path.exists(os.path.join(G, "full_b1_traffic.json")):
         shutil.copy(os.path.join(G, "full_b1_traffic.json"), os.path.join(P, f"{tag}_full_b1_traffic.json"))
     md = [f"# {tag} - full THA4 model (mode_07), batch 1, MI355X",
-          "Source: `tools/profile_r02.sh` (`rocprofv3 --kernel-trace --stats -- python tools/time_full.py`: 3 warm-up + 20 steady + 20 cold",
+          f"Source: `tools/profile_{tag}.sh` (`rocprofv3 --kernel-trace --stats -- python tools/time_full.py`: 3 warm-up + 20 steady + 20 cold",
           "frames = 43 frames, 21 of them run the eyebrow decomposer; PMC passes over 9 frames; FETCH_SIZE / WRITE_SIZE passes over steady-only",
           f"and cold-only runs -> `{tag}_full_b1_traffic.json`; per-layer join of the schedule dump with the kernel trace).  Synthetic seeded weights.", "",
           "Un-profiled wall clock of the same script:", "```", read(os.path.join(G, "pf_time.log")).strip(), "```", "",
@@ -59,6 +59,37 @@ def full():
     open(os.path.join(P, f"{tag}_full_b1_profile.md"), "w").write("\n".join(md))
 
 
+def batched():
+    """configs[3] / configs[4], one GPU's share each (tools/profile_r03.sh): student batch 32, full model batch 8"""
+    if os.path.exists(os.path.join(G, "pb32_kernel_stats.csv")):
+        shutil.copy(os.path.join(G, "pb32_kernel_stats.csv"), os.path.join(P, f"{tag}_student_b32_kernel_stats.csv"))
+        if os.path.exists(os.path.join(G, "student_b32_traffic.json")):
+            shutil.copy(os.path.join(G, "student_b32_traffic.json"), os.path.join(P, f"{tag}_student_b32_traffic.json"))
+        md = [f"# {tag} - student path, batch 32 per Poser.pose() call (BASELINE configs[3], one GPU's share), MI355X",
+              f"Source: `tools/profile_{tag}.sh`: `bench.py --batch 32 --characters lambda_00 --steps 24 --warmup 4` under rocprofv3 --kernel-trace --stats, one SQ PMC",
+              f"pass, FETCH_SIZE and WRITE_SIZE in separate passes (-> `{tag}_student_b32_traffic.json`).  Un-profiled `bench.py --batch 32 --steps 64`:", "```",
+              read(os.path.join(G, "pb32_bench.json")).strip()[:700], "```", "",
+              f"## rocprofv3 --kernel-trace --stats (full CSV: {tag}_student_b32_kernel_stats.csv)", stats_table(os.path.join(G, "pb32_kernel_stats.csv"), 8), "",
+              "## PMC pass (per-launch averages summed over the chip; a launch = 32 frames)", "```", read(os.path.join(G, "pb32_pmc_summary.txt")).strip(), "```", "",
+              "## HBM-side traffic (KiB per launch of 32 frames)", "```", read(os.path.join(G, "pb32_traffic_summary.txt")).strip(), "```", "",
+              read(os.path.join(P, f"{tag}_student_b32_reading.md"))]
+        open(os.path.join(P, f"{tag}_student_b32_profile.md"), "w").write("\n".join(md))
+    if os.path.exists(os.path.join(G, "pfb8_kernel_stats.csv")):
+        shutil.copy(os.path.join(G, "pfb8_kernel_stats.csv"), os.path.join(P, f"{tag}_full_b8_kernel_stats.csv"))
+        if os.path.exists(os.path.join(G, "full_b8_traffic.json")):
+            shutil.copy(os.path.join(G, "full_b8_traffic.json"), os.path.join(P, f"{tag}_full_b8_traffic.json"))
+        md = [f"# {tag} - full THA4 model, batch 8 distinct images per call (BASELINE configs[4], one GPU's share), MI355X",
+              f"Source: `tools/profile_{tag}.sh`: `tools/time_full.py --batch 8` (a `max_batch = 8` handle: no K split, no conv_small, no folded normalisations where 8",
+              f"frames fill the chip; every step is cold) under rocprofv3 --kernel-trace --stats (3 warm-up + 10 steps), one SQ PMC pass and FETCH_SIZE / WRITE_SIZE passes",
+              f"(3 + 5 steps -> `{tag}_full_b8_traffic.json`).  Un-profiled wall clock:", "```", read(os.path.join(G, "pfb8_time.log")).strip(), "```", "",
+              f"## rocprofv3 --kernel-trace --stats (full CSV: {tag}_full_b8_kernel_stats.csv)", stats_table(os.path.join(G, "pfb8_kernel_stats.csv"), 30), "",
+              "## PMC pass (per-launch averages summed over the chip; a launch covers the 8 frames of the step)", "```",
+              "\n".join(l for l in read(os.path.join(G, "pfb8_pmc_summary.txt")).splitlines() if l.startswith("==") or "conv_" in l or "norm_" in l or "attention" in l),
+              "```", "", read(os.path.join(P, f"{tag}_full_b8_reading.md"))]
+        open(os.path.join(P, f"{tag}_full_b8_profile.md"), "w").write("\n".join(md))
+
+
 if __name__ == "__main__":
     student()
     full()
+    batched()

@@ -110,7 +110,7 @@ z1, z2 = p.debug_hand_off(1).numpy(), p.debug_hand_off(2).numpy()
 again = p.get_posing_outputs(img, pose)
 np.savez(sys.argv[1], *[o.cpu().numpy() for o in outs], z1=z1, z2=z2, rerun_equal=np.array([bool(torch.equal(a, b)) for a, b in zip(outs, again)]))
 """ % (ROOT, ROOT, pose_index)
-    print("\n| library | blended | alpha | colour | warped | grid | face | z1 / 30 (level 0 -> 1) | z2 / 30 (level 1 -> 2) | rerun bitwise equal |   (max abs vs oracle, pose %d)" % pose_index)
+    print("\n| library | blended | alpha | colour | warped | grid | face | z1 (level 0 -> 1) | z2 (level 1 -> 2) | rerun bitwise equal |   (max abs vs oracle, pose %d)" % pose_index)
     print("|---|---|---|---|---|---|---|---|---|---|")
     got = {}
     extra = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--libs=")]
@@ -126,8 +126,8 @@ np.savez(sys.argv[1], *[o.cpu().numpy() for o in outs], z1=z1, z2=z2, rerun_equa
         subprocess.run([sys.executable, "-c", code, out], check=True, env=env)
         z = np.load(out)
         got[label] = [z[f"arr_{k}"] for k in range(6)] + [z["z1"], z["z2"]]
-        ez1 = np.abs(z["z1"][:180] / 30.0 - inter["z1"]).max()
-        ez2 = np.abs(z["z2"][:90] / 30.0 - inter["z2"]).max()
+        ez1 = np.abs(z["z1"][:180] - inter["z1"]).max()
+        ez2 = np.abs(z["z2"][:90] - inter["z2"]).max()
         print(f"| {label} | " + " | ".join(f"{np.abs(got[label][k] - ref6[k]).max():.3e}" for k in range(6)) +
               f" | {ez1:.3e} (max abs z1 {np.abs(inter['z1']).max():.2f}) | {ez2:.3e} (max abs z2 {np.abs(inter['z2']).max():.2f}) | {z['rerun_equal'].all()} |")
     if "-DTHA4_HW_SIN" in got:
@@ -143,9 +143,9 @@ np.savez(sys.argv[1], *[o.cpu().numpy() for o in outs], z1=z1, z2=z2, rerun_equa
             dk = np.abs(a[k] - b[k])[0].max(0)
             print(f"  {name}: pixels differing by more than {lim:g}: {(dk > lim).sum()}; max {dk.max():.3e}")
         for zi, lvl, side in ((6, 1, 128), (7, 2, 256)):
-            dz = np.abs(a[zi] - b[zi]).max(0) / 30.0
+            dz = np.abs(a[zi] - b[zi]).max(0)
             ys, xs = np.nonzero(dz > 1e-4)
-            print(f"  z{lvl} / 30 (level {lvl - 1} output side, {side}^2): max delta {dz.max():.3e}; positions above 1e-4: {ys.size}" +
+            print(f"  z{lvl} (level {lvl - 1} output side, {side}^2): max delta {dz.max():.3e}; positions above 1e-4: {ys.size}" +
                   (f" (rows {ys.min()}..{ys.max()}, columns {xs.min()}..{xs.max()})" if ys.size else ""))
 
 

@@ -17,22 +17,17 @@ OUT = os.path.join(ROOT, "build_variants")
 
 VARIANTS = {
     "default": [],
-    "hwsin": ["-DTHA4_HW_SIN"],          # v_sin_f32 sine (tools/sin_cliff.py; never shipped)
-    "hwsin_nop": ["-DTHA4_HW_SIN", "-DTHA4_HW_SIN_NOP"],
-    "hwsin_stream": ["-DTHA4_HW_SIN", "-DTHA4_L2_RESIDENT=0"],
-    "hwsin_pg1": ["-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1"],
-    "hwsin_wait0": ["-DTHA4_HW_SIN", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],     # hazard hunt: every memory wait forced to zero
-    "hwsin_nopipe": ["-DTHA4_HW_SIN", "-DTHA4_NO_PIPELINE"],                         # hazard hunt: no sched_barrier fences
-    "hwsin_pad": ["-DTHA4_HW_SIN", "-mllvm", "-amdgpu-mfma-padding-ratio=100"],      # hazard hunt: MFMAs padded apart
-    "hwsin_ws": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_WAIT_BEFORE_STORES"],
-    "hwsin_wt": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_WAIT_TOP"],
-    "hwsin_fl": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_FENCE_LGKM"],
-    "hwsin_fv": ["-DTHA4_HW_SIN", "-DTHA4_HUNT_FENCE_VM"],
-    "hwsin_inplace": ["-DTHA4_HW_SIN", "-DTHA4_HW_SIN_INPLACE"],
-    "wait0": ["-mllvm", "-amdgpu-waitcnt-forcezero=1"],          # the shipped source with every memory wait forced to zero (tools/compare_libs.py)
-    "hwsin_pg1_wait0": ["-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
-    "hwsin_pg1": ["-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1"],
-    "pg1": ["-DTHA4_L216P_CFG=8,8,1"],    # weights-resident level 2 with one pixel group per strip
+    # ---- the sine (profiles/r03_sin_cliff.md) ----
+    "wait0": ["-mllvm", "-amdgpu-waitcnt-forcezero=1"],                              # the shipped source with every memory wait forced to zero (tools/compare_libs.py)
+    "turns_pg2": ["-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2"],               # the faulty geometry with the shipped sine
+    "turns_pg2_wait0": ["-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "poly": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,4,2"],                                                  # round 2: radians, 12-op polynomial
+    "poly_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,4,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "poly_pg1": ["-DTHA4_SIN_TURNS=0"],
+    "hwsin": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2"],                                # radians, Cody-Waite + v_sin_f32: level2_16p<8,4,2> is faulty in this build
+    "hwsin_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "hwsin_pg1": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1"],
+    "hwsin_stream": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L2_RESIDENT=0"],
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset

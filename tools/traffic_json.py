@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--cold-write")
     ap.add_argument("--cold-frames", type=int, default=0)
     ap.add_argument("--command", default="")
+    ap.add_argument("--batch", type=int, default=1, help="frames per launch set (batched captures: per-frame bytes = per-step bytes / batch)")
+    ap.add_argument("--steps", type=int, default=0, help="full model, batched: pose() calls in the capture incl. warm-up (all cold)")
     ap.add_argument("-o", required=True)
     a = ap.parse_args()
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per-launch averages; tools/traffic_json.py",
@@ -49,6 +51,17 @@ def main():
             if k in fe:
                 ks[short] = {"fetch_kib": round(sum(fe[k]) / len(fe[k]), 2), "write_kib": round(sum(wr[k]) / len(wr[k]), 2), "launches": len(fe[k])}
         out["kernels"] = ks
+        out["batch"] = a.batch
+        out["frame_bytes"] = int(round(sum((2.0 * k["fetch_kib"] + k["write_kib"]) * 1024 for k in ks.values()) / max(1, a.batch)))
+    elif a.steps:
+        # batched full model: every step is cold (distinct images each call)
+        tot = sum(2.0 * sum(v) for v in fe.values()) * 1024 + sum(sum(v) for v in wr.values()) * 1024
+        out["batch"] = a.batch
+        out["captured"] = {"steps": a.steps, "bytes": int(tot)}
+        out["step_bytes"] = int(round(tot / a.steps))
+        out["cold_frame_bytes"] = int(round(tot / a.steps / a.batch))
+        out["kernels"] = {k: {"fetch_kib": round(sum(v) / len(v), 2), "write_kib": round(sum(wr[k]) / max(1, len(wr[k])), 2), "launches_per_step": round(len(v) / a.steps, 2)}
+                          for k, v in sorted(fe.items(), key=lambda kv: -sum(kv[1]))}
     else:
         def total_bytes(fe, wr):
             return sum(2.0 * sum(v) for v in fe.values()) * 1024 + sum(sum(v) for v in wr.values()) * 1024
