@@ -482,8 +482,11 @@ def student_extras(args, work, dev, world, fps, K, W, B):
                 torch.cuda.synchronize(dev)
                 return args.d2h_frames / (time.perf_counter() - t0d)
 
-        fused = d2h_rate(lambda i, out: work.step_rgba8(i, out=out))
-        unfused = d2h_rate(lambda i, out: out.copy_(image_io.to_display_rgba8(work.step(i))))
+        fused_make = lambda i, out: work.step_rgba8(i, out=out)                                       # noqa: E731
+        unfused_make = lambda i, out: out.copy_(image_io.to_display_rgba8(work.step(i)))              # noqa: E731
+        d2h_rate(fused_make)            # untimed: the first pass over a pinned ring pays for mapping it (measured: 2-3x slower than the second)
+        fused = max(d2h_rate(fused_make), d2h_rate(fused_make))
+        unfused = max(d2h_rate(unfused_make), d2h_rate(unfused_make))
         out["with_rgba8_d2h"] = {"fps": round(fused, 2), "frames": args.d2h_frames,
                                  "what": "pose with the sRGB/uint8 display epilogue fused into the composing kernel (tha4_display) + async D2H of the "
                                          "1 MiB RGBA8 frame into pinned host memory on a side stream, 4-slot ring (PCIe-inclusive)",

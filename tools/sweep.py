@@ -28,6 +28,16 @@ VARIANTS = {
     "hwsin_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "hwsin_pg1": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1"],
     "hwsin_stream": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L2_RESIDENT=0"],
+    # ---- streamed kernels with two pixel groups per slot (one A fragment read feeds both; measured neutral in round 2 under the 12-op sine) ----
+    "l1pg2": ["-DTHA4_L116_CFG=4,2,2,1,1"], "l0pg2": ["-DTHA4_L016_CFG=2,4,2,3,1"], "facepg2": ["-DTHA4_FACE16_CFG=2,4,2,2"],
+    "l1pg2_wait0": ["-DTHA4_L116_CFG=4,2,2,1,1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "allpg2": ["-DTHA4_L116_CFG=4,2,2,1,1", "-DTHA4_L016_CFG=2,4,2,3,1", "-DTHA4_FACE16_CFG=2,4,2,2"],
+    "allpg2_wait0": ["-DTHA4_L116_CFG=4,2,2,1,1", "-DTHA4_L016_CFG=2,4,2,3,1", "-DTHA4_FACE16_CFG=2,4,2,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    # ---- timing ablations (results are wrong; tools/gpu_r03_ablate.sh) ----
+    "ab_mfma": ["-DTHA4_ABLATE_MFMA"], "ab_sin": ["-DTHA4_ABLATE_SIN"], "ab_fetch": ["-DTHA4_ABLATE_FETCH"], "ab_barrier": ["-DTHA4_ABLATE_BARRIER"],
+    "ab_zload": ["-DTHA4_ABLATE_ZLOAD"], "ab_mfma_sin": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN"],
+    "ab_fetch_barrier": ["-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER"],
+    "ab_all": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER", "-DTHA4_ABLATE_ZLOAD"],
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
