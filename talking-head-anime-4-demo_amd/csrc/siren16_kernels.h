@@ -263,6 +263,9 @@ THA4_DEV void first16_pos(const float* wx, const float* wy, const float* pb, con
   }
 }
 
+#ifndef THA4_TAP_BLOCKS
+#define THA4_TAP_BLOCKS 4     // blocks whose 4 upsample taps are requested together in the first layers (power of two)
+#endif
 // sink(pg, block, v): where the layer's output rows go (the LDS activation image, or registers)
 template <class G, int NB, class Sink>
 THA4_DEV void first16_up_to(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb,
@@ -303,7 +306,7 @@ THA4_DEV void first16_up_to(const float* zframe, int lowS, const float* wx, cons
         v[j] = sin_u(up + fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));                           // z and tables carry the 30x
       }
       sink(pg, b, v);
-      if ((bb & 3) == 3) THA4_SCHED_FENCE();      // at most 4 blocks (16 tap loads) in flight: 12 blocks at once spill
+      if ((bb & (THA4_TAP_BLOCKS - 1)) == THA4_TAP_BLOCKS - 1) THA4_SCHED_FENCE();      // at most THA4_TAP_BLOCKS blocks (4 tap loads each) in flight: 12 blocks at once spill
     }
   }
 }
@@ -573,10 +576,14 @@ THA4_DEV void put_rows(f16x8 (&xh)[kKG2][PG], f16x8 (&xl)[kKG2][PG], int pg, int
   }
 }
 
+#ifndef THA4_L2_GROUP_BLOCKS
+#define THA4_L2_GROUP_BLOCKS 3    // A fragments of this many blocks (hi + lo) are double-buffered in registers: 3 -> 48 VGPRs, 2 -> 32
+#endif
 // acc += W' x for one resident layer: pieces [Q][NB] at wv (lane offset applied), x in registers
 template <int NB, int KG, int PG>
 THA4_DEV void mma_resident(const char* wv, const f16x8 (&xh)[KG][PG], const f16x8 (&xl)[KG][PG], f32x4 (&acc)[NB][PG]) {
-  constexpr int GB = group_blocks(NB), NGB = NB / GB, T = KG * NGB;
+  constexpr int GB = (NB == kNB2) ? THA4_L2_GROUP_BLOCKS : group_blocks(NB), NGB = NB / GB, T = KG * NGB;
+  static_assert(NB % GB == 0, "the block group must divide the layer");
   f16x8 ah[2][GB], al[2][GB];
 #pragma unroll
   for (int b = 0; b < GB; ++b) {
@@ -620,14 +627,16 @@ constexpr bool defined_hw_sin() {
 #endif
 }
 
-template <int WAVES, int PGW, int PG>
+// WAVES waves share SPW strips of PG pixel groups each; the strips are handed out by an LDS ticket, so WAVES need not divide SPW
+// (12 waves = 3 per SIMD take 64 strips as well as 8 waves do)
+template <int WAVES, int SPW, int PG>
 struct Level2PCfg {
   static constexpr int kHidden = kNB2 * kKG2;                         // pieces of one 96->96 layer
   static constexpr int kPieces = 2 * kHidden + kKG2;                  // + head (1 block x 3 groups)
   static constexpr int kWeightBytes = kPieces * 2048;
   static constexpr int LDS = kWeightBytes + 16;                       // + the strip ticket counter (+ pb_lds_bytes(kNB2) at launch)
   static constexpr int THREADS = WAVES * 64;
-  static constexpr int PX = WAVES * PGW * PG * 16;
+  static constexpr int PX = SPW * PG * 16;
   using G = Geo16<WAVES, 1, PG, kKG2, 1>;
   static_assert((kImg * kImg) % PX == 0, "a frame must be a whole number of workgroups");
 #if !defined(THA4_ALLOW_L216P_PG2) && !defined(THA4_EMU)
@@ -638,9 +647,10 @@ struct Level2PCfg {
   static_assert(LDS + 16 * kNB2 * 4 <= 80 * 1024, "two workgroups per CU must still fit");
 };
 
-template <int WAVES, int PGW, int PG>
+template <int WAVES, int SPW, int PG>
 __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
-  using Cfg = Level2PCfg<WAVES, PGW, PG>;
+  using Cfg = Level2PCfg<WAVES, SPW, PG>;
+  static_assert(SPW >= WAVES, "every wave takes its first strip statically");
   using G = typename Cfg::G;
   constexpr int S = kImg, STRIPS = S * S / (16 * PG);
   THA4_DYN_LDS(smem);
@@ -653,15 +663,15 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   if (threadIdx.x == 0) *ticket = WAVES;                               // strips 0..WAVES-1 are taken statically
   // a workgroup's strips all belong to one frame (STRIPS is a multiple of PGW * WAVES): its pose-folded bias goes to LDS
   float* pb = reinterpret_cast<float*>(smem + Cfg::LDS);
-  pose_bias_to_lds<kNB2, WAVES * 64>(d, 3, (xcd_tile(blockIdx.x, gridDim.x) * PGW * WAVES) / STRIPS, pb);
+  pose_bias_to_lds<kNB2, WAVES * 64>(d, 3, (xcd_tile(blockIdx.x, gridDim.x) * SPW) / STRIPS, pb);
   __syncthreads();
   const char* w1 = smem + w.lane * 16;
   const char* w2 = w1 + (size_t)Cfg::kHidden * 2048;
   const char* w3 = w2 + (size_t)Cfg::kHidden * 2048;
   const int g4 = (w.lane >> 4) * 4;
-  const int strip0 = xcd_tile(blockIdx.x, gridDim.x) * PGW * WAVES;
+  const int strip0 = xcd_tile(blockIdx.x, gridDim.x) * SPW;
 #pragma unroll 1
-  for (int k = w.wave; k < PGW * WAVES; k = wave_take_ticket(ticket, w.lane)) {
+  for (int k = w.wave; k < SPW; k = wave_take_ticket(ticket, w.lane)) {
 #if defined(THA4_HUNT_WAIT_TOP) && !defined(THA4_EMU)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // hazard hunt: the previous strip's stores are complete before this strip's loads
 #endif
@@ -727,18 +737,24 @@ namespace cfg {
 #define THA4_L216_CFG 4, 1, 1, 1            // NS, MS, PG, CQ
 #endif
 #ifndef THA4_L216P_CFG
-// WAVES, strips per wave, pixel groups per strip (weights-resident level 2).  ONE pixel group per strip since round 3.
+// WAVES, strips per workgroup, pixel groups per strip (weights-resident level 2).  ONE pixel group per strip since round 3, and
+// TWELVE waves (three per SIMD) share the 64 strips of a workgroup: the strips are handed out by ticket, so the wave count need
+// not divide them, and a strip spends half its time waiting (777 VALU + 117 MFMA instructions ~ 3.9 k issue cycles against 7.5 k
+// measured at two waves per SIMD).  168 VGPRs; two loop-invariant 64-bit addresses are spilled once before the strip loop and
+// reloaded once per strip (4 VGPRs, 20 B of scratch - the only VGPR spill in the library, allowed by name in
+// tests/test_api_surface.py).  50.4 -> 47.6 us, 7193 -> 7386 frames/s on the same box; equal to its forced-wait build bit for bit.
+// (16 waves: 128 VGPRs, 16 spilled, 50.6 us.)
 // Rounds 1-2 shipped <8, 4, 2> (one A fragment feeds two pixel groups; +1.6 % with the 12-op polynomial sine).  That
 // instantiation is FAULTY as soon as the sine is a v_sin_f32 - with the turn-based sine as much as with a Cody-Waite +
 // v_sin_f32 build: run-to-run varying pixels (30-100 per frame, errors up to 1.5), z1 / z2 / the face and every other kernel
 // correct, the sine instruction itself accurate to 3.8e-7 on every argument of the frame.  The same source compiled with
 // `-mllvm -amdgpu-waitcnt-forcezero=1` is correct and deterministic; neither wait states behind the v_sin_f32, an in-place
 // v_sin_f32, MFMA padding, nor draining vmcnt / lgkmcnt at every scheduling fence or around the stores repairs it
-// (profiles/r03_sin_cliff.md: the whole hunt).  <8, 8, 1> with the same sine equals ITS forced-wait build bit for bit over both
+// (profiles/r03_sin_cliff.md: the whole hunt).  <8, 64, 1> (one pixel group per strip) with the same sine equals ITS forced-wait build bit for bit over both
 // characters' sweeps, is deterministic under tests/test_student_gpu.py::test_determinism_stress, and is as fast (50.8 us
 // against 51.5).  The round-1 "256 VGPRs + scratch -> wrong, varying pixels" incident of this geometry was most likely the
 // same fault, not the spill it was blamed on.
-#define THA4_L216P_CFG 8, 8, 1
+#define THA4_L216P_CFG 12, 64, 1
 #endif
 #ifndef THA4_L2_RESIDENT
 #define THA4_L2_RESIDENT 1                  // 1: level2_16p_kernel, 0: streamed level2_16_kernel

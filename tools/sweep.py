@@ -19,15 +19,17 @@ VARIANTS = {
     "default": [],
     # ---- the sine (profiles/r03_sin_cliff.md) ----
     "wait0": ["-mllvm", "-amdgpu-waitcnt-forcezero=1"],                              # the shipped source with every memory wait forced to zero (tools/compare_libs.py)
-    "turns_pg2": ["-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2"],               # the faulty geometry with the shipped sine
-    "turns_pg2_wait0": ["-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
-    "poly": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,4,2"],                                                  # round 2: radians, 12-op polynomial
-    "poly_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,4,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "turns_pg2": ["-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2"],               # the faulty geometry with the shipped sine
+    "turns_pg2_wait0": ["-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "poly": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,32,2"],                                                  # round 2: radians, 12-op polynomial
+    "poly_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,32,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "poly_pg1": ["-DTHA4_SIN_TURNS=0"],
-    "hwsin": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2"],                                # radians, Cody-Waite + v_sin_f32: level2_16p<8,4,2> is faulty in this build
-    "hwsin_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,4,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
-    "hwsin_pg1": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,8,1"],
+    "hwsin": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2"],                                # radians, Cody-Waite + v_sin_f32: level2_16p<8,4,2> is faulty in this build
+    "hwsin_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "hwsin_pg1": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L216P_CFG=8,64,1"],
     "hwsin_stream": ["-DTHA4_SIN_TURNS=0", "-DTHA4_HW_SIN", "-DTHA4_L2_RESIDENT=0"],
+    # ---- weights-resident level 2 with three / four waves per SIMD (strips are handed out by ticket: any wave count shares the 64 strips) ----
+    "l2w8": ["-DTHA4_L216P_CFG=8,64,1"], "l2w16": ["-DTHA4_L216P_CFG=16,64,1"],
     # ---- streamed kernels with two pixel groups per slot (one A fragment read feeds both; measured neutral in round 2 under the 12-op sine) ----
     "l1pg2": ["-DTHA4_L116_CFG=4,2,2,1,1"], "l0pg2": ["-DTHA4_L016_CFG=2,4,2,3,1"], "facepg2": ["-DTHA4_FACE16_CFG=2,4,2,2"],
     "l1pg2_wait0": ["-DTHA4_L116_CFG=4,2,2,1,1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
