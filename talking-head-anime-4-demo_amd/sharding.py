@@ -42,7 +42,8 @@ class FrameShardedStream:
     def __init__(self, frame_fn: Callable[[int, int], torch.Tensor], total: int, frame_shape: Sequence[int],
                  dtype: torch.dtype, device: torch.device, chunk: int = 32,
                  group: Optional[dist.ProcessGroup] = None, gather: bool = True,
-                 on_chunk: Optional[Callable[[int, int, torch.Tensor], None]] = None, ring_slots: int = 3):
+                 on_chunk: Optional[Callable[[int, int, torch.Tensor], None]] = None, ring_slots: int = 3,
+                 force_collective: bool = False):
         """``on_chunk(lo, hi, frames)`` switches the root from an ARCHIVE of the whole stream (``allocate_result``:
         ``total`` frames on rank 0 - 2000 steps x 32 frames x 8 ranks would be 2 TB) to a STREAM: rank 0 owns a ring of
         ``ring_slots`` buffers of one gather round each (``world x chunk`` frames: 3 x 8 x 32 x 4 MiB = 3 GiB) and hands
@@ -51,7 +52,9 @@ class FrameShardedStream:
         current, i.e. whatever it enqueues there is ordered after the arrival of the data and before the slot is
         overwritten ``ring_slots`` rounds later; a consumer that works on another stream must make that stream wait on
         an event it records in the callback and must be done before the slot comes round again.  ``run()`` then
-        returns None."""
+        returns None.  ``force_collective`` (tests) takes the gather path - side stream, ``dist.gather`` into views of the
+        destination - even in a one-rank group: the only way a 1-GPU box executes RCCL at all (it refuses two ranks on one
+        device)."""
         self.frame_fn = frame_fn
         self.on_chunk = on_chunk
         self.ring_slots = max(2, int(ring_slots))
@@ -64,7 +67,7 @@ class FrameShardedStream:
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.world = dist.get_world_size(group) if self.distributed else 1
-        self.gather = gather and self.world > 1
+        self.gather = gather and (self.world > 1 or (force_collective and self.distributed))
         self.lo, self.hi = shard_bounds(self.total, self.rank, self.world)
 
     def local_range(self) -> Tuple[int, int]:

@@ -71,3 +71,71 @@ def test_two_rank_rccl_gather_real_poser(total, chunk):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}
+
+
+def _solo_worker(port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        import tha4_amd  # noqa: F401
+        from tha4_amd.poser.modes import mode_14
+        from tha4_amd.sharding import FrameShardedStream
+        from tha4_amd.weights import split_flat_weights
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        w = dict(np.load(os.path.join(GOLDEN, "student_lambda_00_weights.npz")))
+        io = np.load(os.path.join(GOLDEN, "student_lambda_00_io.npz"))
+        poser = mode_14.create_poser_from_state_dicts(dev, *split_flat_weights(w), max_batch=4)
+        image = torch.from_numpy(io["image_f32"]).to(dev)
+        total = 11
+        poses = torch.from_numpy(np.resize(io["poses"], (total, 45))).to(dev)
+
+        def frames(lo, hi):
+            blk = torch.empty((hi - lo, 4, 512, 512), dtype=torch.float32, device=dev)
+            for i in range(lo, hi):
+                poser.pose(image, poses[i], out=blk[i - lo:i - lo + 1])
+            return blk
+
+        def frames_u8(lo, hi):
+            blk = torch.empty((hi - lo, 512, 512, 4), dtype=torch.uint8, device=dev)
+            for i in range(lo, hi):
+                poser.pose_display_rgba8(image, poses[i], out=blk[i - lo:i - lo + 1])
+            return blk
+
+        with torch.no_grad():
+            mine = frames(0, total)
+            full = FrameShardedStream(frames, total, (4, 512, 512), torch.float32, dev, chunk=4, gather=True, force_collective=True).run()
+            got = {}
+            FrameShardedStream(frames_u8, total, (512, 512, 4), torch.uint8, dev, chunk=4, gather=True, force_collective=True, ring_slots=2,
+                               on_chunk=lambda lo, hi, fr: got.update({i: fr[i - lo].clone() for i in range(lo, hi)})).run()
+            torch.cuda.synchronize(dev)
+            from tha4_amd import image_io
+            want = image_io.to_display_rgba8(mine)
+            ok = bool(torch.equal(full, mine)) and sorted(got) == list(range(total)) and all(bool(torch.equal(got[i], want[i])) for i in range(total))
+        q.put("ok" if ok else "WRONG DATA")
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                     # noqa: BLE001
+        q.put("ERROR " + repr(e)[:600])
+
+
+def test_one_rank_rccl_executes_the_gather_path():
+    """A 1-GPU box cannot host two RCCL ranks ("Duplicate GPU detected"), so the gather never ran on hardware.  With
+    `force_collective` a ONE-rank RCCL group takes the same code path - the side stream, `record_stream`, `dist.gather` into VIEWS of the
+    destination (archive rows and ring slots), the opening barrier - on device tensors produced by the real poser (fp32 frames, and RGBA8
+    frames from the fused display epilogue through the streaming root)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = ctx.Process(target=_solo_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=120)
+    assert res == "ok", res
+    assert p.exitcode == 0
