@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -100,6 +101,11 @@ struct tha4_student {
   size_t blob_bytes = 0;
   std::vector<float> pos128, pos256, pos512;   // position axes given at create (reused by tha4_student_set_weights)
   StreamOrder order;                           // the handle's workspace is shared by consecutive calls
+  // fault-hunt aid (profiles/r03_sin_cliff.md): level 2 from an externally assembled code object instead of the built-in kernel
+  // (env THA4_L2_CODE_OBJECT = path, THA4_L2_KERNEL = mangled name, THA4_L2_THREADS, THA4_L2_PX = pixels per workgroup)
+  hipModule_t l2_module = nullptr;
+  hipFunction_t l2_function = nullptr;
+  int l2_threads = 0, l2_px = 0;
 };
 
 namespace {
@@ -249,6 +255,13 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   if (e == hipSuccess) e = allow_lds(THA4_L116_KERNEL, v2::cfg::kL1Lds);
   if (e == hipSuccess) e = allow_lds(THA4_L216_KERNEL, v2::cfg::kL2Lds);
   if (e == hipSuccess) e = allow_lds(THA4_L216P_KERNEL, v2::cfg::kL2PLds);
+  if (e == hipSuccess && std::getenv("THA4_L2_CODE_OBJECT") && std::getenv("THA4_L2_KERNEL")) {
+    e = hipModuleLoad(&h->l2_module, std::getenv("THA4_L2_CODE_OBJECT"));
+    if (e == hipSuccess) e = hipModuleGetFunction(&h->l2_function, h->l2_module, std::getenv("THA4_L2_KERNEL"));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->l2_function), hipFuncAttributeMaxDynamicSharedMemorySize, v2::cfg::kL2PLds);
+    h->l2_threads = std::getenv("THA4_L2_THREADS") ? std::atoi(std::getenv("THA4_L2_THREADS")) : 512;
+    h->l2_px = std::getenv("THA4_L2_PX") ? std::atoi(std::getenv("THA4_L2_PX")) : 1024;
+  }
   if (e != hipSuccess) {
     cleanup();
     return fail(THA4_ERR_HIP, std::string("tha4_student_create: ") + hipGetErrorString(e));
@@ -337,7 +350,10 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
     hipLaunchKernelGGL((THA4_L116_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L1G>(batch, 256)), dim3(v2::cfg::L1G::THREADS),
                        v2::cfg::kL1Lds, s, d);
     if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
-    if (THA4_L2_RESIDENT)
+    if (h->l2_function) {
+      void* params[] = {&d};
+      HIP_TRY(hipModuleLaunchKernel(h->l2_function, batch * (512 * 512) / h->l2_px, 1, 1, h->l2_threads, 1, 1, v2::cfg::kL2PLds, s, params, nullptr));
+    } else if (THA4_L2_RESIDENT)
       hipLaunchKernelGGL((THA4_L216P_KERNEL), dim3(batch * (512 * 512) / v2::cfg::L2P::PX), dim3(v2::cfg::L2P::THREADS),
                          v2::cfg::kL2PLds, s, d);
     else
@@ -358,6 +374,7 @@ void tha4_student_destroy(tha4_student* h) {
   if (h->ev_valid)
     for (auto& e : h->ev) (void)hipEventDestroy(e);
   h->order.destroy();
+  if (h->l2_module) (void)hipModuleUnload(h->l2_module);
   if (h->blob) (void)hipFree(h->blob);
   if (h->workspace) (void)hipFree(h->workspace);
   delete h;
