@@ -11,6 +11,11 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(CSRC, "libtha4_hip.so")
 RESOURCES = os.path.join(CSRC, "libtha4_hip.resources.txt")
 SOURCES = ["tha4_capi.hip"]
+# No packed-fp32 VALU instructions (v_pk_mul / v_pk_fma / v_pk_add_f32) in any kernel of the library: the compiler's packed arithmetic is
+# what made level2_16p_kernel<8,.,2> produce run-to-run varying pixels on gfx950 once the sine shrank to one instruction
+# (profiles/r03_sin_cliff.md: wait states in front of every v_pk_* all but cure it, a build without them equals its forced-wait twin
+# bit for bit), and it buys nothing here (a v_pk_fma_f32 costs two v_fma_f32).  THA4_NO_PACKED_FP32 tells the sources so.
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DTHA4_NO_PACKED_FP32=1"]
 
 
 def _headers():
@@ -32,11 +37,11 @@ def hipcc_path() -> str:
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
-    deps = [os.path.join(CSRC, f) for f in SOURCES + _headers()] + [os.path.join(INCLUDE, "tha4_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + _headers()] + [os.path.join(INCLUDE, "tha4_hip.h"), os.path.abspath(__file__)]
     if not force and not _stale(LIB, deps) and os.path.exists(RESOURCES):
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
-           "-I", CSRC, "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage"] + DEVICE_FLAGS + \
+          ["-I", CSRC, "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)

@@ -639,10 +639,11 @@ struct Level2PCfg {
   static constexpr int PX = SPW * PG * 16;
   using G = Geo16<WAVES, 1, PG, kKG2, 1>;
   static_assert((kImg * kImg) % PX == 0, "a frame must be a whole number of workgroups");
-#if !defined(THA4_ALLOW_L216P_PG2) && !defined(THA4_EMU)
+#if !defined(THA4_ALLOW_L216P_PG2) && !defined(THA4_EMU) && !defined(THA4_NO_PACKED_FP32)
   static_assert(PG == 1 || !(THA4_SIN_TURNS || defined_hw_sin()),
-                "level2_16p_kernel with two pixel groups per strip is faulty on the device with a v_sin_f32 sine (see THA4_L216P_CFG); "
-                "-DTHA4_ALLOW_L216P_PG2 builds it anyway (fault-hunt builds only)");
+                "level2_16p_kernel with two pixel groups per strip is faulty on the device when the compiler may use packed-fp32 instructions "
+                "and the sine is a v_sin_f32 (see THA4_L216P_CFG): build with tha4_amd._build.DEVICE_FLAGS (-packed-fp32-ops off, "
+                "-DTHA4_NO_PACKED_FP32=1); -DTHA4_ALLOW_L216P_PG2 builds it anyway (fault-hunt builds only)");
 #endif
   static_assert(LDS + 16 * kNB2 * 4 <= 80 * 1024, "two workgroups per CU must still fit");
 };
@@ -737,23 +738,23 @@ namespace cfg {
 #define THA4_L216_CFG 4, 1, 1, 1            // NS, MS, PG, CQ
 #endif
 #ifndef THA4_L216P_CFG
-// WAVES, strips per workgroup, pixel groups per strip (weights-resident level 2).  ONE pixel group per strip since round 3, and
-// TWELVE waves (three per SIMD) share the 64 strips of a workgroup: the strips are handed out by ticket, so the wave count need
-// not divide them, and a strip spends half its time waiting (777 VALU + 117 MFMA instructions ~ 3.9 k issue cycles against 7.5 k
-// measured at two waves per SIMD).  168 VGPRs; two loop-invariant 64-bit addresses are spilled once before the strip loop and
-// reloaded once per strip (4 VGPRs, 20 B of scratch - the only VGPR spill in the library, allowed by name in
-// tests/test_api_surface.py).  50.4 -> 47.6 us, 7193 -> 7386 frames/s on the same box; equal to its forced-wait build bit for bit.
-// (16 waves: 128 VGPRs, 16 spilled, 50.6 us.)
-// Rounds 1-2 shipped <8, 4, 2> (one A fragment feeds two pixel groups; +1.6 % with the 12-op polynomial sine).  That
-// instantiation is FAULTY as soon as the sine is a v_sin_f32 - with the turn-based sine as much as with a Cody-Waite +
-// v_sin_f32 build: run-to-run varying pixels (30-100 per frame, errors up to 1.5), z1 / z2 / the face and every other kernel
-// correct, the sine instruction itself accurate to 3.8e-7 on every argument of the frame.  The same source compiled with
-// `-mllvm -amdgpu-waitcnt-forcezero=1` is correct and deterministic; neither wait states behind the v_sin_f32, an in-place
-// v_sin_f32, MFMA padding, nor draining vmcnt / lgkmcnt at every scheduling fence or around the stores repairs it
-// (profiles/r03_sin_cliff.md: the whole hunt).  <8, 64, 1> (one pixel group per strip) with the same sine equals ITS forced-wait build bit for bit over both
-// characters' sweeps, is deterministic under tests/test_student_gpu.py::test_determinism_stress, and is as fast (50.8 us
-// against 51.5).  The round-1 "256 VGPRs + scratch -> wrong, varying pixels" incident of this geometry was most likely the
-// same fault, not the spill it was blamed on.
+// WAVES, strips per workgroup, pixel groups per strip (weights-resident level 2).  TWELVE waves (three per SIMD) share the 64
+// one-group strips of a workgroup: the strips are handed out by an LDS ticket, so the wave count need not divide them, and a strip
+// spends half its time waiting (777 VALU + 117 MFMA instructions ~ 3.9 k issue cycles against 7.5 k measured at two waves per SIMD).
+// Same box, library built without packed fp32 (below): <12,64,1> 46.9 us / 7413 frames/s, <12,32,2> 47.9 / 7368, <8,32,2> 48.9 / 7281
+// (<16,64,1>: 128 VGPRs, 16 spilled, no gain).
+//
+// The two-group geometry <8,.,2> that rounds 1-2 shipped has a history (profiles/r03_sin_cliff.md).  With the compiler's packed-fp32
+// arithmetic (v_pk_mul / v_pk_fma / v_pk_add_f32: SLP vectorisation + float4 expressions) it is FAULTY on gfx950 as soon as the sine is
+// a v_sin_f32 - round 2's "3e-2 cliff" of the hardware-sine A/B build, and errors of up to 1.5 with the turn-based sine: 30-100
+// run-to-run varying pixels per frame in this one kernel, every hand-off image and every other kernel correct, the sine instruction
+// accurate to 3.8e-7 on every argument of the frame.  Forced memory waits only lowered the rate, making every counted wait total changed
+// nothing; eight wait states in FRONT of every v_pk_* (re-assembled ISA, tools/hunt/) all but cured it, in front of every VALU
+// instruction cured it: an instruction-issue hazard around the two-pass packed ops that the backend does not pad, exposed once the
+// 11 VALU instructions per sine of the polynomial no longer spaced the stream.  The library is therefore built WITHOUT packed-fp32
+// instructions (tha4_amd/_build.py DEVICE_FLAGS; a v_pk_fma_f32 costs two v_fma_f32: nothing is lost), every geometry is then sound -
+// each equals its forced-wait twin bit for bit (tools/compare_libs.py) - and with packed ops the two-group form is refused at compile
+// time.  The round-1 "256 VGPRs + scratch -> wrong, varying pixels" incident of that geometry was most likely the same hazard.
 #define THA4_L216P_CFG 12, 64, 1
 #endif
 #ifndef THA4_L2_RESIDENT

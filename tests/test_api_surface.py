@@ -146,14 +146,9 @@ def test_no_kernel_spills(built):
 
     def num(l, key):
         return int(re.search(key + r"=(\d+)", l).group(1))
-    # the one VGPR spill of the library: level2_16p_kernel at three waves per SIMD (168 VGPRs) keeps two loop-invariant 64-bit addresses
-    # in scratch - stored once before the strip loop, reloaded once per strip (csrc/siren16_kernels.h THA4_L216P_CFG)
-    def allowed_spill(l):
-        return "level2_16p_kernel" in l and num(l, "vgpr_spill") <= 4 and num(l, "scratch") <= 24
-    bad = [l for l in lines if not allowed_spill(l) and
-           (num(l, "vgpr_spill") != 0 or (num(l, "scratch") > 0 and not (num(l, "sgpr_spill") > 0 and num(l, "scratch") <= 40)))]
+    bad = [l for l in lines if num(l, "vgpr_spill") != 0 or (num(l, "scratch") > 0 and not (num(l, "sgpr_spill") > 0 and num(l, "scratch") <= 40))]
     assert not bad, bad
-    student = [l for l in lines if ("tha42v2" in l or "posebias" in l) and "level2_16p_kernel" not in l]
+    student = [l for l in lines if "tha42v2" in l or "posebias" in l]
     assert all("scratch=0" in l for l in student), student
 
 
@@ -181,3 +176,28 @@ def test_new_entry_points_validate_arguments(built):
     out = (C.c_uint8 * 16)()
     assert lib.tha4_display_rgba8(buf, 1, 2, 2, None, out, None) == -1
     assert lib.tha4_ingest_rgba8(out, 1, 2, 2, buf, None) == -1
+
+
+def test_library_holds_no_packed_fp32_instructions(built):
+    """The library is built with the packed-fp32 VALU instructions switched off (tha4_amd/_build.py DEVICE_FLAGS): they are the hazard
+    class behind the run-to-run varying pixels of level2_16p_kernel<8,.,2> (profiles/r03_sin_cliff.md).  Disassemble what ships and look."""
+    import shutil
+    import subprocess
+    import tempfile
+    from tha4_amd import _build
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    if not (os.path.exists(objdump) and os.path.exists(bundler)):
+        pytest.skip("llvm-objdump / clang-offload-bundler not available")
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", _build.LIB, fat], check=True)
+        co = os.path.join(d, "gfx950.co")
+        r = subprocess.run([bundler, "--type=o", "--unbundle", f"--input={fat}", f"--output={co}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], capture_output=True, text=True)
+        assert r.returncode == 0 and os.path.getsize(co) > 0, r.stderr
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+    assert dis.count("v_mfma_f32_16x16x32") > 1000                     # it is the kernels' code that was disassembled
+    assert dis.count("v_sin_f32") > 100
+    packed = [l for l in dis.splitlines() if "v_pk_" in l and "_f32" in l.split("v_pk_", 1)[1].split()[0]]
+    assert not packed, packed[:5]

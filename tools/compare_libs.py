@@ -38,22 +38,50 @@ open(sys.argv[1], "w").write("\n".join(out))
 """ % (ROOT, ROOT)
 
 
+CODE_FULL = r"""
+import os, sys, numpy as np, torch, hashlib
+sys.path.insert(0, %r)
+import tha4_amd
+from tha4_amd import synthetic
+from tha4_amd.poser.modes import mode_07
+from oracle.student_oracle import random_poses, synthetic_image
+g = os.path.join(%r, "tests", "golden")
+n = int(sys.argv[2])
+io = np.load(os.path.join(g, "student_lambda_00_io.npz"))
+w = synthetic.synth_full_weights()
+out = []
+dev = torch.device("cuda:0")
+for mb in (1, 4, 8):
+    p = mode_07.create_poser_from_state_dicts(dev, w, max_batch=mb)
+    imgs = torch.from_numpy(np.stack([io["image_f32"]] + [synthetic_image(seed=300 + i) for i in range(mb - 1)])).to(dev) if mb > 1 else torch.from_numpy(io["image_f32"]).to(dev)
+    poses = torch.from_numpy(random_poses(n * mb, seed=4321)).to(dev)
+    for i in range(n):
+        outs = p.get_posing_outputs(imgs, poses[i * mb:(i + 1) * mb] if mb > 1 else poses[i], image_changed=(i %% 2 == 0))
+        out.append(hashlib.sha1(b"".join(o.cpu().numpy().tobytes() for o in outs)).hexdigest())
+    p.free()
+open(sys.argv[1], "w").write("\n".join(out))
+""" % (ROOT, ROOT)
+
+
 def run(lib, n, tag):
     env = dict(os.environ)
     env.pop("THA4_HIP_LIB", None)
     if lib != "default":
         env["THA4_HIP_LIB"] = os.path.join(ROOT, lib) if not os.path.isabs(lib) else lib
     out = f"/tmp/compare_libs_{tag}.txt"
-    subprocess.run([sys.executable, "-c", CODE, out, str(n)], check=True, env=env)
+    subprocess.run([sys.executable, "-c", CODE_FULL if "--full" in sys.argv else CODE, out, str(n)], check=True, env=env)
     return open(out).read().split("\n")
 
 
 def main():
-    a, b = sys.argv[1], sys.argv[2]
-    n = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    a, b = args[0], args[1]
+    n = int(args[2]) if len(args) > 2 else 64
     ha, hb = run(a, n, "a"), run(b, n, "b")
     diff = sum(x != y for x, y in zip(ha, hb))
-    print(f"{a} vs {b}: {len(ha)} evaluations (both characters, {n} poses in batches of 8 + single frames, all six outputs hashed); differing: {diff}")
+    what = ("full model: handles for 1 / 4 / 8 frames, all 33 outputs hashed, steady and cold calls" if "--full" in sys.argv else
+            f"both characters, {n} poses in batches of 8 + single frames, all six outputs hashed")
+    print(f"{a} vs {b}: {len(ha)} evaluations ({what}); differing: {diff}")
     sys.exit(1 if diff else 0)
 
 

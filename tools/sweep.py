@@ -15,12 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "talking-head-anime-4-demo_amd", "csrc")
 OUT = os.path.join(ROOT, "build_variants")
 
+NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DTHA4_NO_PACKED_FP32=1"]     # = tha4_amd._build.DEVICE_FLAGS
 VARIANTS = {
     "default": [],
-    # ---- the sine (profiles/r03_sin_cliff.md) ----
     "wait0": ["-mllvm", "-amdgpu-waitcnt-forcezero=1"],                              # the shipped source with every memory wait forced to zero (tools/compare_libs.py)
-    "turns_pg2": ["-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2"],               # the faulty geometry with the shipped sine
-    "turns_pg2_wait0": ["-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "pk": ["-DTHA4_PACKED_FP32_BUILD", "-DTHA4_L216P_CFG=12,64,1"],                                   # with the compiler's packed fp32 ops (one pixel group per strip: sound)
+    "pk_pg2": ["-DTHA4_PACKED_FP32_BUILD", "-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2"],     # the FAULTY combination: packed fp32 + two pixel groups
+    "pk_pg2_wait0": ["-DTHA4_PACKED_FP32_BUILD", "-DTHA4_L216P_CFG=8,32,2", "-DTHA4_ALLOW_L216P_PG2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "pg1w12": ["-DTHA4_L216P_CFG=12,64,1"], "pg1w8": ["-DTHA4_L216P_CFG=8,64,1"], "pg2w12": ["-DTHA4_L216P_CFG=12,32,2"],
+    "pg2w12_wait0": ["-DTHA4_L216P_CFG=12,32,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "poly": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,32,2"],                                                  # round 2: radians, 12-op polynomial
     "poly_wait0": ["-DTHA4_SIN_TURNS=0", "-DTHA4_L216P_CFG=8,32,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "poly_pg1": ["-DTHA4_SIN_TURNS=0"],
@@ -51,8 +54,9 @@ def build():
     procs = []
     for name, flags in VARIANTS.items():            # all variants at once: one hipcc process each
         out = os.path.join(OUT, f"libtha4_{name}.so")
+        base = [] if "-DTHA4_PACKED_FP32_BUILD" in flags else NOPK      # variants are relative to the shipped flags (no packed fp32)
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, "-I",
-               os.path.join(ROOT, "include")] + flags + [os.path.join(CSRC, "tha4_capi.hip"), "-o", out]
+               os.path.join(ROOT, "include")] + base + flags + [os.path.join(CSRC, "tha4_capi.hip"), "-o", out]
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     for name, p in procs:
         _, err = p.communicate()
