@@ -12,7 +12,10 @@
 
 namespace tha4 {
 
+// Every product and sum below is rounded on its own, like the reference's separate torch ops (`contract(off)`): the bytes must not depend
+// on which multiply-add the compiler happens to fuse in the kernel this code is inlined into (fused epilogues vs display_rgba8_kernel)
 THA4_DEV float linear_to_srgb(float x) {
+#pragma clang fp contract(off)
   x = fminf(fmaxf(x, 0.0f), 1.0f);
   return x <= 0.003130804953560372f ? x * 12.92f : 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
 }
@@ -23,6 +26,7 @@ THA4_DEV float linear_to_srgb_fast(float x) {
 #ifdef THA4_EMU
   return linear_to_srgb(x);
 #else
+#pragma clang fp contract(off)
   x = fminf(fmaxf(x, 0.0f), 1.0f);
   const float pw = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f));
   return x <= 0.003130804953560372f ? x * 12.92f : 1.055f * pw - 0.055f;
@@ -31,6 +35,7 @@ THA4_DEV float linear_to_srgb_fast(float x) {
 // display value of ONE channel of one pixel (the arithmetic of display_rgba8_kernel): v = poser output in [-1,1],
 // alpha01 = the pixel's clipped alpha in [0,1] (only read with a background)
 THA4_DEV unsigned char display_channel(float v, int channel, float alpha01, bool has_background, float bg) {
+#pragma clang fp contract(off)
   float c = fminf(fmaxf((v + 1.0f) * 0.5f, 0.0f), 1.0f);
   if (channel < 3) {
     c = linear_to_srgb_fast(c);
