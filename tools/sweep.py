@@ -38,7 +38,7 @@ VARIANTS = {
     "l1pg2_wait0": ["-DTHA4_L116_CFG=4,2,2,1,1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "allpg2": ["-DTHA4_L116_CFG=4,2,2,1,1", "-DTHA4_L016_CFG=2,4,2,3,1", "-DTHA4_FACE16_CFG=2,4,2,2"],
     "allpg2_wait0": ["-DTHA4_L116_CFG=4,2,2,1,1", "-DTHA4_L016_CFG=2,4,2,3,1", "-DTHA4_FACE16_CFG=2,4,2,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
-    # ---- timing ablations (results are wrong; tools/gpu_r03_ablate.sh) ----
+    # ---- timing ablations (results are wrong; tools/runs_r03/gpu_r03_ablate.sh) ----
     "ab_mfma": ["-DTHA4_ABLATE_MFMA"], "ab_sin": ["-DTHA4_ABLATE_SIN"], "ab_fetch": ["-DTHA4_ABLATE_FETCH"], "ab_barrier": ["-DTHA4_ABLATE_BARRIER"],
     "ab_zload": ["-DTHA4_ABLATE_ZLOAD"], "ab_mfma_sin": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN"],
     "ab_fetch_barrier": ["-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER"],
