@@ -382,8 +382,9 @@ __global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
 // ---- level 0 ----------------------------------------------------------------------------------------
 template <int NS, int MS, int PG, int HBA, int CQB>
 struct Level016Cfg {   // HBA: block slices per group of the 24/12-block layers; CQB: groups per chunk of the z layer
-  static constexpr int kP1 = kNB0 / HBA, kP2 = kNB1 / HBA, kP3 = CQB * kNB1;
-  static constexpr int kSlotPieces = kP1 > kP3 ? kP1 : kP3;
+  static constexpr int kHBB = (kNB1 / MS) % HBA == 0 ? HBA : HBA / 2;     // slices of the 12-block layer (a wave's share must divide)
+  static constexpr int kP1 = kNB0 / HBA, kP2 = kNB1 / kHBB, kP3 = CQB * kNB1;
+  static constexpr int kSlotPieces = (kP1 > kP2 ? kP1 : kP2) > kP3 ? (kP1 > kP2 ? kP1 : kP2) : kP3;
   using G = Geo16<NS, MS, PG, kKG0, kSlotPieces>;
 };
 
@@ -408,7 +409,7 @@ THA4_DEV void level0_16_body(const StudentDev& d, char* smem, const WaveCtx& w) 
   first16_pos<G, kNB0>(d.wx[1], d.wy[1], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL0, px, py, act, w);
   __syncthreads();
   sine16_layer<G, kNB0, kKG0, HBA, 1, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
-  sine16_layer<G, kNB1, kKG0, HBA, 1, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
+  sine16_layer<G, kNB1, kKG0, Cfg::kHBB, 1, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
   z16_layer<G, kNB1, kKG1, 1, CQB>(gw, scl, ring, slot, act, d.z1 + (size_t)n * kNB1 * NPIX * 16, NPIX, pix0, w);
 }
 
@@ -440,16 +441,17 @@ __global__ void __launch_bounds__(NS* MS * 64) front16_kernel(StudentDev d) {
 }
 
 // ---- level 1 ----------------------------------------------------------------------------------------
-template <int NS, int MS, int PG, int CQA, int CQB>
+template <int NS, int MS, int PG, int CQA, int CQB, int HBA = 1>   // HBA: block slices per group of the two sine layers (needs CQA == 1)
 struct Level116Cfg {
-  static constexpr int kP1 = CQA * kNB1, kP2 = CQA * kNB2, kP3 = CQB * kNB2;
-  static constexpr int kSlotPieces = kP1 > kP3 ? kP1 : kP3;
+  static constexpr int kHBA = HBA, kHBB = HBA > 1 ? HBA / 2 : 1;     // the 6-block layer is sliced half as often: equal chunk sizes
+  static constexpr int kP1 = CQA * kNB1 / kHBA, kP2 = CQA * kNB2 / kHBB, kP3 = CQB * kNB2;
+  static constexpr int kSlotPieces = (kP1 > kP2 ? kP1 : kP2) > kP3 ? (kP1 > kP2 ? kP1 : kP2) : kP3;
   using G = Geo16<NS, MS, PG, kKG1, kSlotPieces>;
 };
 
-template <int NS, int MS, int PG, int CQA, int CQB>
+template <int NS, int MS, int PG, int CQA, int CQB, int HBA = 1>
 __global__ void __launch_bounds__(NS* MS * 64) level1_16_kernel(StudentDev d) {
-  using Cfg = Level116Cfg<NS, MS, PG, CQA, CQB>;
+  using Cfg = Level116Cfg<NS, MS, PG, CQA, CQB, HBA>;
   using G = typename Cfg::G;
   constexpr int S = 256, NPIX = S * S;
   THA4_DYN_LDS(smem);
@@ -469,8 +471,8 @@ __global__ void __launch_bounds__(NS* MS * 64) level1_16_kernel(StudentDev d) {
   if (THA4_PB_FOLD) __syncthreads();
   first16_up<G, kNB1>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, d.wx[2], d.wy[2], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL1, X0, Y, px, py, act, w);
   __syncthreads();
-  sine16_layer<G, kNB1, kKG1, 1, CQA, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
-  sine16_layer<G, kNB2, kKG1, 1, CQA, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
+  sine16_layer<G, kNB1, kKG1, HBA, CQA, Cfg::kP2>(gw, bias, scl, ring, slot, act, w);
+  sine16_layer<G, kNB2, kKG1, Cfg::kHBB, CQA, Cfg::kP3>(gw, bias, scl, ring, slot, act, w);
   z16_layer<G, kNB2, kKG2, 1, CQB>(gw, scl, ring, slot, act, d.z2 + (size_t)n * kNB2 * NPIX * 16, NPIX, pix0, w);
 }
 
@@ -726,36 +728,39 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
 // ---- launch configuration ------------------------------------------------------------------------------
 namespace cfg {
 #ifndef THA4_FACE16_CFG
-#define THA4_FACE16_CFG 4, 2, 1, 4          // NS, MS, PG, CQ (groups per chunk; 4 = whole layer)
+#define THA4_FACE16_CFG 4, 4, 1, 4          // NS, MS, PG, CQ (groups per chunk; 4 = whole layer)
 #endif
 #ifndef THA4_L016_CFG
-#define THA4_L016_CFG 4, 2, 1, 2, 1         // NS, MS, PG, HBA (block slices per group), CQB
+#define THA4_L016_CFG 4, 4, 1, 2, 1         // NS, MS, PG, HBA (block slices per group), CQB
 #endif
 #ifndef THA4_L116_CFG
-#define THA4_L116_CFG 8, 1, 1, 1, 1         // NS, MS, PG, CQA, CQB
+#define THA4_L116_CFG 4, 2, 1, 1, 1, 2      // NS, MS, PG, CQA, CQB [, HBA]
 #endif
 #ifndef THA4_L216_CFG
 #define THA4_L216_CFG 4, 1, 1, 1            // NS, MS, PG, CQ
 #endif
 #ifndef THA4_L216P_CFG
-// WAVES, strips per workgroup, pixel groups per strip (weights-resident level 2).  TWELVE waves (three per SIMD) share the 64
+// WAVES, strips per workgroup, pixel groups per strip (weights-resident level 2).  SIXTEEN waves (four per SIMD) share the 64
 // one-group strips of a workgroup: the strips are handed out by an LDS ticket, so the wave count need not divide them, and a strip
 // spends half its time waiting (777 VALU + 117 MFMA instructions ~ 3.9 k issue cycles against 7.5 k measured at two waves per SIMD).
-// Same box, library built without packed fp32 (below): <12,64,1> 46.9 us / 7413 frames/s, <12,32,2> 47.9 / 7368, <8,32,2> 48.9 / 7281
-// (<16,64,1>: 128 VGPRs, 16 spilled, no gain).
+// Same box, library built without packed fp32 (below): <16,64,1> 45.4 us (126 VGPRs, no spill - with packed ops it was 128 + 16
+// spilled), <12,64,1> 46.9, <12,32,2> 47.9, <8,32,2> 48.9.  More waves per SIMD is what every kernel of this path wants (round 3):
+// the streamed kernels went from 8 to 16 waves per CU as well (rows of a pixel slot split over more waves: THA4_L016_CFG /
+// THA4_FACE16_CFG MS = 4, level 1 as two 8-wave workgroups per CU), front 55.4 -> 50.0 us, level 1 43.7 -> 41.1; two INDEPENDENT
+// 4-wave workgroups per CU (same waves per SIMD, no shared barrier) changed nothing - the stalls are each wave's own latency chain.
 //
 // The two-group geometry <8,.,2> that rounds 1-2 shipped has a history (profiles/r03_sin_cliff.md).  With the compiler's packed-fp32
 // arithmetic (v_pk_mul / v_pk_fma / v_pk_add_f32: SLP vectorisation + float4 expressions) it is FAULTY on gfx950 as soon as the sine is
 // a v_sin_f32 - round 2's "3e-2 cliff" of the hardware-sine A/B build, and errors of up to 1.5 with the turn-based sine: 30-100
 // run-to-run varying pixels per frame in this one kernel, every hand-off image and every other kernel correct, the sine instruction
 // accurate to 3.8e-7 on every argument of the frame.  Forced memory waits only lowered the rate, making every counted wait total changed
-// nothing; eight wait states in FRONT of every v_pk_* (re-assembled ISA, tools/hunt/) all but cured it, in front of every VALU
-// instruction cured it: an instruction-issue hazard around the two-pass packed ops that the backend does not pad, exposed once the
-// 11 VALU instructions per sine of the polynomial no longer spaced the stream.  The library is therefore built WITHOUT packed-fp32
+// nothing; eight wait states in FRONT of every v_pk_* (re-assembled ISA, tools/hunt/) lower the rate by orders of magnitude, a build
+// without packed ops removes the fault in every geometry; no pairwise producer -> v_pk_* hazard exists beyond the documented ones
+// (tools/microbench/gen_pk_hazard.py), so the mechanism stays open and the class is established by elimination.  The library is therefore built WITHOUT packed-fp32
 // instructions (tha4_amd/_build.py DEVICE_FLAGS; a v_pk_fma_f32 costs two v_fma_f32: nothing is lost), every geometry is then sound -
 // each equals its forced-wait twin bit for bit (tools/compare_libs.py) - and with packed ops the two-group form is refused at compile
 // time.  The round-1 "256 VGPRs + scratch -> wrong, varying pixels" incident of that geometry was most likely the same hazard.
-#define THA4_L216P_CFG 12, 64, 1
+#define THA4_L216P_CFG 16, 64, 1
 #endif
 #ifndef THA4_L2_RESIDENT
 #define THA4_L2_RESIDENT 1                  // 1: level2_16p_kernel, 0: streamed level2_16_kernel
@@ -767,6 +772,8 @@ using L0G = Level016Cfg<THA4_L016_CFG>::G;
 using L1G = Level116Cfg<THA4_L116_CFG>::G;
 using L2G = Level216Cfg<THA4_L216_CFG>::G;
 constexpr int kL0HBA = Level016Cfg<THA4_L016_CFG>::kP1 == kNB0 ? 1 : kNB0 / Level016Cfg<THA4_L016_CFG>::kP1;
+constexpr int kL0HBB = Level016Cfg<THA4_L016_CFG>::kHBB;
+constexpr int kL1HBA = Level116Cfg<THA4_L116_CFG>::kHBA, kL1HBB = Level116Cfg<THA4_L116_CFG>::kHBB;
 constexpr int kFaceMS = FaceG::MS, kL0MS = L0G::MS, kL1MS = L1G::MS, kL2MS = L2G::MS;
 #define THA4_FACE16_KERNEL v2::face16_kernel<THA4_FACE16_CFG>
 #define THA4_FRONT16_KERNEL v2::front16_kernel<THA4_FACE16_CFG, THA4_L016_CFG>
@@ -835,10 +842,10 @@ inline void pack_student16(const StudentWeightsView& v, const StudentPacked& p1,
   for (int i = 1; i < 8; ++i) p.s_face.push_back(pack_layer16(v.face_sine[i].weight, kCF, 0, kCF, kCF, kNBF, kKGF, cfg::kFaceMS, 1, W30, p.w_face));
   p.s_face.push_back(pack_layer16(v.face_last.weight, kCF, 0, 4, kCF, 1, kKGF, 1, 1, 1.0f, p.w_face));
   p.s_l0.push_back(pack_layer16(v.body_sine[0][1].weight, kC0, 0, kC0, kC0, kNB0, kKG0, cfg::kL0MS, cfg::kL0HBA, W30, p.w_l0));
-  p.s_l0.push_back(pack_layer16(v.body_sine[0][2].weight, kC0, 0, kC1, kC0, kNB1, kKG0, cfg::kL0MS, cfg::kL0HBA, W30, p.w_l0));
+  p.s_l0.push_back(pack_layer16(v.body_sine[0][2].weight, kC0, 0, kC1, kC0, kNB1, kKG0, cfg::kL0MS, cfg::kL0HBB, W30, p.w_l0));
   p.s_l0.push_back(pack_layer16(v.body_sine[1][0].weight, kC1 + 2 + kPose, 0, kC1, kC1, kNB1, kKG1, cfg::kL0MS, 1, W30, p.w_l0));
-  p.s_l1.push_back(pack_layer16(v.body_sine[1][1].weight, kC1, 0, kC1, kC1, kNB1, kKG1, cfg::kL1MS, 1, W30, p.w_l1));
-  p.s_l1.push_back(pack_layer16(v.body_sine[1][2].weight, kC1, 0, kC2, kC1, kNB2, kKG1, cfg::kL1MS, 1, W30, p.w_l1));
+  p.s_l1.push_back(pack_layer16(v.body_sine[1][1].weight, kC1, 0, kC1, kC1, kNB1, kKG1, cfg::kL1MS, cfg::kL1HBA, W30, p.w_l1));
+  p.s_l1.push_back(pack_layer16(v.body_sine[1][2].weight, kC1, 0, kC2, kC1, kNB2, kKG1, cfg::kL1MS, cfg::kL1HBB, W30, p.w_l1));
   p.s_l1.push_back(pack_layer16(v.body_sine[2][0].weight, kC2 + 2 + kPose, 0, kC2, kC2, kNB2, kKG2, cfg::kL1MS, 1, W30, p.w_l1));
   p.s_l2.push_back(pack_layer16(v.body_sine[2][1].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, W30, p.w_l2));
   p.s_l2.push_back(pack_layer16(v.body_sine[2][2].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, W30, p.w_l2));

@@ -43,6 +43,20 @@ VARIANTS = {
     "ab_zload": ["-DTHA4_ABLATE_ZLOAD"], "ab_mfma_sin": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN"],
     "ab_fetch_barrier": ["-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER"],
     "ab_all": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER", "-DTHA4_ABLATE_ZLOAD"],
+    # ---- level 1 with independent workgroups sharing a CU (half chunks of 12 KiB: 72 KiB of LDS per 64-pixel workgroup -> two per CU) ----
+    "l1w4": ["-DTHA4_L116_CFG=4,1,1,1,1,2"],       # 4 waves / workgroup: each SIMD hosts one wave of each of two workgroups
+    "l1w8x2": ["-DTHA4_L116_CFG=4,2,1,1,1,2"],     # 8 waves / workgroup (rows split over two waves): four waves per SIMD
+    "l1hb2": ["-DTHA4_L116_CFG=8,1,1,1,1,2"],      # control: the shipped 128-pixel workgroup with half chunks (twice the barriers)
+    "l1m2": ["-DTHA4_L116_CFG=8,2,1,1,1,1"],       # 16 waves on the shipped 128-pixel workgroup (rows split over two waves): four per SIMD, same weight stream
+    "l1m2h": ["-DTHA4_L116_CFG=8,2,1,1,1,2"],
+    "l1m3": ["-DTHA4_L116_CFG=4,3,1,1,1,2"],       # 12 waves per 64-pixel workgroup, two workgroups per CU: six per SIMD
+    "frontm4": ["-DTHA4_L016_CFG=4,4,1,2,1", "-DTHA4_FACE16_CFG=4,4,1,4"],     # front kernel with 16 waves (rows split over four)
+    "frontm4_l1w8x2": ["-DTHA4_L016_CFG=4,4,1,2,1", "-DTHA4_FACE16_CFG=4,4,1,4", "-DTHA4_L116_CFG=4,2,1,1,1,2"],
+    "frontm4_l1w8x2_wait0": ["-DTHA4_L016_CFG=4,4,1,2,1", "-DTHA4_FACE16_CFG=4,4,1,4", "-DTHA4_L116_CFG=4,2,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "all16": ["-DTHA4_L016_CFG=4,4,1,2,1", "-DTHA4_FACE16_CFG=4,4,1,4", "-DTHA4_L116_CFG=4,2,1,1,1,2", "-DTHA4_L216P_CFG=16,64,1"],
+    "all16_wait0": ["-DTHA4_L016_CFG=4,4,1,2,1", "-DTHA4_FACE16_CFG=4,4,1,4", "-DTHA4_L116_CFG=4,2,1,1,1,2", "-DTHA4_L216P_CFG=16,64,1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "l1w4_wait0": ["-DTHA4_L116_CFG=4,1,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "l1w8x2_wait0": ["-DTHA4_L116_CFG=4,2,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
