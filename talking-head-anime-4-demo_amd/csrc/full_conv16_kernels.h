@@ -134,13 +134,21 @@ THA4_DEV int fused_table_floats(const ConvArgs& a) {      // 2 x padded concaten
   return 2 * c;
 }
 
-template <int TMB, int PG, int INMODE>
-__global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
+// MSW = 2 (round 3): SIXTEEN waves on the same workgroup tile - the TMB output blocks are split over two halves of the workgroup
+// (wave w: pixel slot w & 7, block half w >> 3), so the window, the weight ring and every byte of traffic stay what they are while each
+// wave carries half the accumulators and a SIMD hosts four waves instead of two (what the student kernels gained 5-10 % from).
+template <int TMB, int PG, int INMODE, int MSW = 1>
+__global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs a) {
+  static_assert(MSW == 1 || (MSW == 2 && TMB % 2 == 0), "the block split needs an even block count");
   constexpr bool kPool = INMODE == IN_POOL2;
+  constexpr int kWaves = kTileWaves * MSW, kThreads = kTileThreads * MSW;      // waves / threads of this instantiation
+  constexpr int TMBW = TMB / MSW;                                              // output blocks per wave
+  constexpr int KI = MSW == 2 ? (kTileMaxItems + 1) / 2 : kTileMaxItems;       // staging items per thread
   THA4_DYN_LDS(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform_i32(tid >> 6);
+  const int pw = wave & (kTileWaves - 1), mh = wave / kTileWaves;      // pixel slot and block half of this wave
   const int p = lane & 15, g = lane >> 4, g4 = g * 4;
 
   // ---- tile decomposition -------------------------------------------------------------------
@@ -183,7 +191,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   bool inside[PG];
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) {
-    const int i = (wave * PG + pg) * 16 + p;
+    const int i = (pw * PG + pg) * 16 + p;
     ly[pg] = i >> twl;
     lx[pg] = i & (TWW - 1);
     boff[pg] = ((ly[pg] * a.in_stride) * WW + lx[pg] * a.in_stride) * 16 + g * PLANE;
@@ -193,10 +201,10 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   // ---- staging items of this thread (geometry is the same for every K group) --------------------
   const int sg = tid & 3;                                 // lane group plane this thread stages
   const int nitems = NPX * 4;
-  struct Offsets { int v[kTileMaxItems]; } go;             // byte offset of the item inside a quad's plane; < 0: zero padding
+  struct Offsets { int v[KI]; } go;                        // byte offset of the item inside a quad's plane; < 0: zero padding
 #pragma unroll
-  for (int k = 0; k < kTileMaxItems; ++k) {
-    const int item = tid + k * kTileThreads;
+  for (int k = 0; k < KI; ++k) {
+    const int item = tid + k * kThreads;
     const int px = item >> 2;
     const int wy = px / WW, wx = px - wy * WW;
     const int vy = vy0 + wy, vx = vx0 + wx;
@@ -209,14 +217,14 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   }
 
   // glds instructions EVERY wave issues per chunk (wave w issues ceil((pieces - w) / 8)): the lower bound the counted barrier uses
-  const int keep_per_chunk = ((a.ntaps - (ntc - 1) * a.taps_per_chunk) * TMB * 2) / kTileWaves;     // (of the shortest chunk)
+  const int keep_per_chunk = ((a.ntaps - (ntc - 1) * a.taps_per_chunk) * TMB * 2) / kWaves;     // (of the shortest chunk)
   auto fetch = [&](int chunk, int slot) {                  // chunk = K group * ntc + chunk of the group
     const int cq = chunk / ntc, ct = chunk - cq * ntc;
     const int t0 = ct * a.taps_per_chunk, nt = min(a.taps_per_chunk, a.ntaps - t0);
     const char* src = gw + ((size_t)cq * a.ntaps + t0) * TMB * 2048;
     char* dst = ring + slot * slot_bytes;
     const int pieces = nt * TMB * 2;
-    for (int pc = wave; pc < pieces; pc += kTileWaves) glds16(src + pc * 1024 + lane * 16, dst + pc * 1024);
+    for (int pc = wave; pc < pieces; pc += kWaves) glds16(src + pc * 1024 + lane * 16, dst + pc * 1024);
   };
 
   // one quad of one K group: which source, its scale/shift/activation for lane group sg
@@ -267,21 +275,21 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     return ((v00 + v01) + (v10 + v11)) * 0.25f;           // AvgPool2d(2,2) of the activated tensor (unet.py:58)
   };
 
-  f32x4 rawA[kTileMaxItems], rawB[kTileMaxItems];
+  f32x4 rawA[KI], rawB[KI];
   QuadCtx cA, cB;
   auto load_window = [&](int Q, const Offsets gofs) {
     cA = quad_ctx(2 * Q);
     cB = quad_ctx(2 * Q + 1);
 #pragma unroll
-    for (int k = 0; k < kTileMaxItems; ++k) {
+    for (int k = 0; k < KI; ++k) {
       rawA[k] = load_quad(cA, gofs.v[k]);
       rawB[k] = load_quad(cB, gofs.v[k]);
     }
   };
   auto write_window = [&](const Offsets gofs, int wofs) {   // wofs: byte offset of the window buffer written
 #pragma unroll
-    for (int k = 0; k < kTileMaxItems; ++k) {
-      const int item = tid + k * kTileThreads;
+    for (int k = 0; k < KI; ++k) {
+      const int item = tid + k * kThreads;
       if (item >= nitems) continue;
       f32x4 va = rawA[k], vb = rawB[k];
       if (!kPool) {                                        // (wave-uniform conditions only: no per-lane branch)
@@ -309,9 +317,9 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
     }
   };
 
-  f32x4 acc[TMB][PG];
+  f32x4 acc[TMBW][PG];
 #pragma unroll
-  for (int b = 0; b < TMB; ++b)
+  for (int b = 0; b < TMBW; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) acc[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
   // LDS offset of tap t inside the window, kept in lane t of one VGPR: the MFMA loop picks it with v_readlane instead of two
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   const int my_toff = ((a.tap_dy[tl] - a.win_dy0) * WW + (a.tap_dx[tl] - a.win_dx0)) * 16;
 
 #if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
-  long long* stamps = (a.dbg && a.phase != 2 && blockIdx.z == 0) ? a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kTileWaves + wave) * 64 : nullptr;
+  long long* stamps = (a.dbg && a.phase != 2 && blockIdx.z == 0) ? a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * 64 : nullptr;
   int nstamp = 0;
 #define THA4_CSTAMP() do { if (stamps && lane == 0 && nstamp < 64) stamps[nstamp] = clock64(); ++nstamp; } while (0)
 #else
@@ -338,7 +346,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       islot = islot + 1 == D ? 0 : islot + 1;
     }
     if (a.fnorm.enabled) {                                 // scale/shift table from the producer's moments (scratch: the window region)
-      fused_norm_table(a, n, tid, kTileThreads, tab_sc, tab_sh, reinterpret_cast<double*>(smem));
+      fused_norm_table(a, n, tid, kThreads, tab_sc, tab_sh, reinterpret_cast<double*>(smem));
       __syncthreads();
     }
     load_window(q_begin, go);
@@ -356,7 +364,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
         fetch(issued++, islot);
         islot = islot + 1 == D ? 0 : islot + 1;
       }
-      const char* wsl = ring + slot * slot_bytes + lane * 16;
+      const char* wsl = ring + slot * slot_bytes + lane * 16 + (size_t)(mh * TMBW) * 2048;      // this wave's blocks of every tap
       const int taps_here = min(a.taps_per_chunk, a.ntaps - tc * a.taps_per_chunk);
       for (int tt = 0; tt < taps_here; ++tt) {
         const int t = tc * a.taps_per_chunk + tt;
@@ -367,19 +375,19 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
           bh[pg] = *reinterpret_cast<const f16x8*>(win_hi + rd + boff[pg] + toff);
           bl[pg] = *reinterpret_cast<const f16x8*>(win_lo + rd + boff[pg] + toff);
         }
-        if (TMB == 4) {
+        if (TMBW == 4) {
           // all A fragments of the tap are requested together with the B fragments: one LDS wait per tap instead of one per
           // output block (the compiler otherwise reuses one register pair and waits lgkmcnt(0) before every block).  Only for
           // the four-block tiles: with two blocks the extra registers cost the <2,4> kernels their third wave per SIMD
-          f16x8 ah[TMB], al[TMB];
+          f16x8 ah[TMBW], al[TMBW];
 #pragma unroll
-          for (int b = 0; b < TMB; ++b) {
+          for (int b = 0; b < TMBW; ++b) {
             ah[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
             al[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
           }
           THA4_SCHED_FENCE();
 #pragma unroll
-          for (int b = 0; b < TMB; ++b) {
+          for (int b = 0; b < TMBW; ++b) {
 #pragma unroll
             for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah[b], bh[pg], acc[b][pg]);
 #pragma unroll
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
           }
         } else {
 #pragma unroll
-          for (int b = 0; b < TMB; ++b) {
+          for (int b = 0; b < TMBW; ++b) {
             const f16x8 ah = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
             const f16x8 al = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
 #pragma unroll
@@ -428,17 +436,17 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 
   // ---- split-K: phase 1 publishes the partial fragments, phase 2 adds them in split order ----------------
   if (PG < 4 && a.phase != 0) {      // the planner never splits K with the largest tile (its registers are all spoken for)
-    const size_t frag = (size_t)kTileWaves * PG * 64;                         // f32x4 fragments per output block
+    const size_t frag = (size_t)kTileWaves * PG * 64;                         // f32x4 fragments per output block (8 pixel slots)
     // partial layout [split][frame][output block][tile][fragment]: indexed by the OUTPUT BLOCK, not by (m-tile, b), so
     // that phase 2 can run with one output block per workgroup (TMB = 1: 4x the workgroups, a quarter of the serial
     // load rounds each) on partials written by a TMB = 4 phase 1
     const size_t stride_split = (size_t)a.batch * a.nb * tiles_per_frame * frag;      // wave-uniform strides (f32x4 units)
     const size_t stride_block = (size_t)tiles_per_frame * frag;
-    f32x4* part = reinterpret_cast<f32x4*>(a.partial) + (((size_t)n * a.nb + (size_t)mtile * TMB) * tiles_per_frame + tile) * frag +
-                  (size_t)(wave * PG) * 64 + lane;      // this lane's fragment of output block mtile*TMB, split 0, pixel group 0
+    f32x4* part = reinterpret_cast<f32x4*>(a.partial) + (((size_t)n * a.nb + (size_t)mtile * TMB + mh * TMBW) * tiles_per_frame + tile) * frag +
+                  (size_t)(pw * PG) * 64 + lane;        // this lane's fragment of this wave's first output block, split 0, pixel group 0
     if (a.phase == 1) {
 #pragma unroll
-      for (int b = 0; b < TMB; ++b)
+      for (int b = 0; b < TMBW; ++b)
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg)
           part[(size_t)ks * stride_split + (size_t)b * stride_block + (size_t)pg * 64] = acc[b][pg];
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
       return;
     }
 #pragma unroll
-    for (int b = 0; b < TMB; ++b)
+    for (int b = 0; b < TMBW; ++b)
 #pragma unroll
       for (int pg = 0; pg < PG; ++pg) {
         // up to 16 splits: all loads of a fragment in flight at once, added in split order
@@ -469,10 +477,10 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
 
   // ---- epilogue: 1/scale, bias, residual, activation, store, deterministic per-tile statistics ----
   const int out_px = a.out_h * a.out_w;
-  float ssum[TMB][4], ssq[TMB][4];
+  float ssum[TMBW][4], ssq[TMBW][4];
 #pragma unroll
-  for (int b = 0; b < TMB; ++b) {
-    const int bo = mtile * TMB + b;
+  for (int b = 0; b < TMBW; ++b) {
+    const int bo = mtile * TMB + mh * TMBW + b;
     f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
 #pragma unroll
@@ -508,7 +516,7 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
   }
   if (a.stats) {
 #pragma unroll
-    for (int b = 0; b < TMB; ++b)
+    for (int b = 0; b < TMBW; ++b)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s = ssum[b][j], q = ssq[b][j];
@@ -518,12 +526,12 @@ __global__ void __launch_bounds__(kTileThreads) conv_tile_kernel(ConvArgs a) {
           q += lane_read(q, lane ^ m);
         }
         if (p == 0) {
-          red[((wave * TMB + b) * 16 + g4 + j) * 2 + 0] = s;
-          red[((wave * TMB + b) * 16 + g4 + j) * 2 + 1] = q;
+          red[((pw * TMB + mh * TMBW + b) * 16 + g4 + j) * 2 + 0] = s;
+          red[((pw * TMB + mh * TMBW + b) * 16 + g4 + j) * 2 + 1] = q;
         }
       }
     __syncthreads();
-    for (int i = tid; i < TMB * 16; i += kTileThreads) {
+    for (int i = tid; i < TMB * 16; i += kThreads) {
       float s = 0.f, q = 0.f;
       for (int wv2 = 0; wv2 < kTileWaves; ++wv2) {
         s += red[((wv2 * TMB) * 16 + i) * 2 + 0];

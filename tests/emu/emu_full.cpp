@@ -142,10 +142,11 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
   Mirror M;
   const bool splitk = pg == 0;
-  const bool point = pg >= 30;              // conv_point_kernel<tmb, pg - 30> (1x1, IN_DIRECT)
-  const bool small = pg >= 20 && !point;    // conv_small_kernel<pg - 20> (tmb must be 1; `ksplit` carries units_per_q, 0 = planner's)
+  const bool tile16 = pg >= 40;             // conv_tile_kernel<tmb, pg - 40, ., 2>: sixteen waves, output blocks split over two wave halves
+  const bool point = pg >= 30 && !tile16;   // conv_point_kernel<tmb, pg - 30> (1x1, IN_DIRECT)
+  const bool small = pg >= 20 && !point && !tile16;    // conv_small_kernel<pg - 20> (tmb must be 1; `ksplit` carries units_per_q, 0 = planner's)
   const bool tiled = pg >= 10 && !small && !point;    // conv_tile_kernel<tmb, pg - 10>
-  const int tpg = pg - 10, spg = pg - 20, ppg = pg - 30;
+  const int tpg = tile16 ? pg - 40 : pg - 10, spg = pg - 20, ppg = pg - 30;
   if (point && (kind != 0 || k != 1 || in_mode != IN_DIRECT || vec1)) return -6;
   const FusedSpec fused = g_fused;
   g_fused.set = false;
@@ -265,13 +266,21 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
 #undef RUN
 #define RUNT(TM, PGV)                                                                                       \
-  if (tiled && run_tmb == TM && tpg == PGV) {                                                               \
+  if (tiled && run_tmb == TM && tpg == PGV && (!tile16 || a.phase == 2)) {                                  \
     if (in_mode == IN_DIRECT) THA4_RUN((conv_tile_kernel<TM, PGV, IN_DIRECT>), grid, kTileThreads, lds, a); \
     else if (in_mode == IN_UP2) THA4_RUN((conv_tile_kernel<TM, PGV, IN_UP2>), grid, kTileThreads, lds, a);  \
     else THA4_RUN((conv_tile_kernel<TM, PGV, IN_POOL2>), grid, kTileThreads, lds, a);                       \
   }
     RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 4) RUNT(1, 2) RUNT(1, 1)
 #undef RUNT
+#define RUNT2(TM, PGV)                                                                                              \
+  if (tiled && tile16 && a.phase != 2 && run_tmb == TM && tpg == PGV) {                                             \
+    if (in_mode == IN_DIRECT) THA4_RUN((conv_tile_kernel<TM, PGV, IN_DIRECT, 2>), grid, kTileThreads * 2, lds, a);  \
+    else if (in_mode == IN_UP2) THA4_RUN((conv_tile_kernel<TM, PGV, IN_UP2, 2>), grid, kTileThreads * 2, lds, a);   \
+    else THA4_RUN((conv_tile_kernel<TM, PGV, IN_POOL2, 2>), grid, kTileThreads * 2, lds, a);                        \
+  }
+    RUNT2(4, 2) RUNT2(4, 1) RUNT2(2, 4) RUNT2(2, 2) RUNT2(2, 1)
+#undef RUNT2
     if (splitk && tmb == 4) {
       if (in_mode == IN_DIRECT) THA4_RUN((conv_splitk_kernel<4, IN_DIRECT>), grid, 256, lds, a);
       else if (in_mode == IN_UP2) THA4_RUN((conv_splitk_kernel<4, IN_UP2>), grid, 256, lds, a);

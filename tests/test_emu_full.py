@@ -120,6 +120,16 @@ CASES = [
     (0, 3, 2, 12, 0, "relu", 64, 0, False, 24, 24, 32, True, False, False, True, (5, 2)),   # ragged 8x32 tiles (cols 24..31 masked) + split-K
     (2, 4, 2, 11, 0, "relu", 64, 0, False, 12, 12, 32, False, False, False, True, (4, 2)),  # convT on a 12x12 map: ragged + split-K, 4 classes
     (1, 4, 2, 11, 0, "relu", 32, 0, False, 48, 48, 32, False, False, False, True, (3, 1)),  # 4x4 s2 -> 24x24 in 16x8 tiles (34x18 window)
+    # conv_tile_kernel with SIXTEEN waves (pg = 40 + PG): the output blocks of the tile split over two halves of the workgroup
+    (0, 3, 4, 42, 0, "relu", 40, 0, False, 16, 32, 64, True, True, False, True, (4, 1)),    # <4,2>: 3x3, phantom quad, residual
+    (0, 3, 2, 44, 0, "silu", 32, 16, False, 32, 32, 32, True, False, False, True, (5, 1)),  # <2,4>: 16x32 tiles, concat of two tensors
+    (0, 3, 2, 41, 0, "relu", 16, 12, True, 16, 16, 32, False, False, False, True, (4, 1)),  # <2,1>: tensor ++ broadcast pose vector
+    (1, 4, 4, 41, 0, "relu", 16, 0, False, 32, 32, 64, False, False, False, True, (4, 1)),  # <4,1>: 4x4 stride 2 (18x34 window)
+    (2, 4, 2, 42, 0, "relu", 32, 0, False, 16, 16, 32, False, False, False, True, (4, 1)),  # <2,2>: convT 4x4 s2 (4 parity classes)
+    (0, 3, 2, 42, 1, "silu", 16, 0, False, 8, 16, 32, True, False, False, True, (4, 1)),    # nearest-up x2 on load
+    (0, 3, 4, 41, 2, "silu", 16, 0, False, 32, 32, 64, True, False, False, True, (4, 1)),   # avg-pool 2x2 on load
+    (0, 3, 2, 42, 0, "relu", 96, 27, True, 16, 16, 64, True, True, False, True, (4, 4)),    # split-K x4: phase 1 with 16 waves, phase 2 per block
+    (0, 3, 2, 41, 0, "relu", 32, 0, False, 24, 24, 32, True, True, False, True, (3, 1)),    # ragged 24x24 map in 16x8 tiles
     # conv_small_kernel (pg = 20 + PG, tmb = 1): K split across the 8 waves of a workgroup, weights from L2 to registers
     # last field: (log2 tile width, units per K group; 0 = the planner's choice)
     (0, 3, 1, 21, 0, "relu", 96, 0, False, 16, 16, 32, True, True, False, True, (4, 0)),    # 3x3, 1x16 row tiles, 3 K groups -> tap split x4, residual
@@ -420,6 +430,7 @@ FUSED_CASES = [
     (24, 1, "none", 128, 0, 16, 16, 48, 32, False, 8, (4, 0)),    # 1x1 qkv projection after GroupNorm
     (12, 3, "silu", 64, 32, 32, 32, 32, 32, True, 4, (4, 1)),     # conv_tile_kernel<2,2> with the table in its prologue
     (11, 3, "relu", 48, 0, 16, 16, 32, 0, False, 2, (4, 2)),      # conv_tile_kernel K split (phase 1 builds the table, phase 2 skips it)
+    (42, 3, "silu", 64, 32, 32, 32, 32, 32, True, 4, (4, 1)),     # conv_tile_kernel<2,2,.,2>: sixteen waves build the table (1024 threads)
     (32, 1, "silu", 96, 64, 16, 32, 32, 32, True, 4, (4, 0)),     # conv_point_kernel<2,2>: GroupNorm(32) over a concatenation + FiLM in its prologue
     (31, 1, "relu", 64, 0, 16, 16, 32, 0, False, 2, (4, 0)),      # conv_point_kernel<2,1>: InstanceNorm
 ]
