@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
   const int wave = uniform_i32(tid >> 6);
   const int pw = wave & (kTileWaves - 1), mh = wave / kTileWaves;      // pixel slot and block half of this wave
   const int p = lane & 15, g = lane >> 4, g4 = g * 4;
+  const float m1 = split_minus_one();
 
   // ---- tile decomposition -------------------------------------------------------------------
   const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (kTileWaves * PG * 16) >> twl;
@@ -304,12 +305,14 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
       }
       (void)keep;
       f16x8 hi, lo;
+{
+        _Float16 h[8], l[8];
+        split_pair(va[0], va[1], m1, h[0], h[1], l[0], l[1]);
+        split_pair(va[2], va[3], m1, h[2], h[3], l[2], l[3]);
+        split_pair(vb[0], vb[1], m1, h[4], h[5], l[4], l[5]);
+        split_pair(vb[2], vb[3], m1, h[6], h[7], l[6], l[7]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        hi[j] = (_Float16)va[j];
-        lo[j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[j], va[j]);          // one v_fma_mix
-        hi[4 + j] = (_Float16)vb[j];
-        lo[4 + j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[4 + j], vb[j]);
+        for (int j = 0; j < 8; ++j) { hi[j] = h[j]; lo[j] = l[j]; }
       }
       const int off = sg * PLANE + (item >> 2) * 16;
       *reinterpret_cast<f16x8*>(win_hi + wofs + off) = hi;

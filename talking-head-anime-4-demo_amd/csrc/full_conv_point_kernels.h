@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = uniform_i32(tid >> 6);
   const int p = lane & 15, g4 = (lane >> 4) * 4;
+  const float m1 = split_minus_one();
   const int px = a.tile_h * a.tile_w;                      // input = output pixels per frame
   constexpr int WGPX = kPointWaves * PG * 16;
   const int tiles_per_frame = (px + WGPX - 1) / WGPX;
@@ -134,14 +135,16 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
     for (int pg = 0; pg < PG; ++pg) {
       const f32x4 xa = apply_act4(cur.va[pg], sca, sha, acta);
       const f32x4 xb = apply_act4(cur.vb[pg], scb, shb, actb);
+      float ua[4], ub[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float ua = valid ? xa[j] : 0.0f, ub = valid ? xb[j] : 0.0f;
-        f.h[pg][j] = (_Float16)ua;
-        f.l[pg][j] = (_Float16)__builtin_fmaf(-1.0f, (float)f.h[pg][j], ua);
-        f.h[pg][4 + j] = (_Float16)ub;
-        f.l[pg][4 + j] = (_Float16)__builtin_fmaf(-1.0f, (float)f.h[pg][4 + j], ub);
-      }
+      for (int j = 0; j < 4; ++j) { ua[j] = valid ? xa[j] : 0.0f; ub[j] = valid ? xb[j] : 0.0f; }
+      _Float16 h[8], l[8];
+      split_pair(ua[0], ua[1], m1, h[0], h[1], l[0], l[1]);
+      split_pair(ua[2], ua[3], m1, h[2], h[3], l[2], l[3]);
+      split_pair(ub[0], ub[1], m1, h[4], h[5], l[4], l[5]);
+      split_pair(ub[2], ub[3], m1, h[6], h[7], l[6], l[7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { f.h[pg][j] = h[j]; f.l[pg][j] = l[j]; }
     }
     return f;
   };

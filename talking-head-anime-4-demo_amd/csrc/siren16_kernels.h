@@ -44,11 +44,12 @@ constexpr int piece_block(int NB, int MS, int HB, int idx) {   // inverse: globa
 
 // split 4 fp32 values (|v| <= 1: sines) into fp16 hi + fp16 lo, v = hi + lo
 THA4_DEV void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
+  const float m1 = split_minus_one();
+  _Float16 h[4], l[4];
+  split_pair(v[0], v[1], m1, h[0], h[1], l[0], l[1]);
+  split_pair(v[2], v[3], m1, h[2], h[3], l[2], l[3]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    hi[j] = (_Float16)v[j];
-    lo[j] = (_Float16)__builtin_fmaf(-1.0f, (float)hi[j], v[j]);     // one v_fma_mix: (f16 -> f32) * -1 + v, rounded to f16
-  }
+  for (int j = 0; j < 4; ++j) { hi[j] = h[j]; lo[j] = l[j]; }
 }
 
 // act image of one pixel slot: [pg][Q][hi|lo][lane][8 halves]; block b -> (Q = b>>1, half = b&1)

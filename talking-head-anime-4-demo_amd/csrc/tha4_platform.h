@@ -107,6 +107,7 @@ THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 THA4_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // the next value of a workgroup-shared LDS counter, fetched by lane 0 and broadcast to the wave
 THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {
   int v = 0;
@@ -140,5 +141,35 @@ THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {      // fibers run o
 THA4_DEV float lane_read(float v, int src_lane) { return emu::shfl(v, src_lane); }
 THA4_DEV int lane_pick(int v, int src_lane) { return (int)emu::shfl((float)v, src_lane); }       // |v| < 2^24: exact in fp32
 #endif
+
+// fp16 hi/lo split of a PAIR of fp32 values: v = hi + lo with hi = fp16(v), lo = fp16(v - hi).  One v_cvt_pk_f16_f32 for both hi halves
+// and one v_fma_mix per lo half (the f16 -> f32 conversion of hi rides inside the FMA): 3-4 instructions per pair where the plain
+// expression `lo = fp16(v - float(hi))` compiles to 8 (two v_cvt_f16_f32, two v_cvt_f32_f16, two v_sub_f32, two packing converts).  The
+// multiplier -1 has to come from a register the optimiser cannot see through - fma(hi, -1, v) is otherwise folded to v - hi and the mix
+// form is lost.  Same bits either way: v - hi is exact in fp32 and rounded to fp16 once.
+THA4_DEV float split_minus_one() {
+  float m1 = -1.0f;
+#ifndef THA4_EMU
+  asm("" : "+s"(m1));
+#endif
+  return m1;
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+THA4_DEV void split_pair(float a, float b, float m1, _Float16& ha, _Float16& hb, _Float16& la, _Float16& lb) {
+#ifdef THA4_PLAIN_SPLIT   // A/B build: the expression rounds 1-2 and most of round 3 used (8 instructions per pair)
+  (void)m1;
+  ha = (_Float16)a;
+  hb = (_Float16)b;
+  la = (_Float16)__builtin_fmaf(-1.0f, (float)ha, a);
+  lb = (_Float16)__builtin_fmaf(-1.0f, (float)hb, b);
+#else
+  const f16x2_t h = __builtin_convertvector((f32x2_t){a, b}, f16x2_t);
+  ha = h[0];
+  hb = h[1];
+  la = (_Float16)__builtin_fmaf((float)h[0], m1, a);
+  lb = (_Float16)__builtin_fmaf((float)h[1], m1, b);
+#endif
+}
 
 }  // namespace tha4

@@ -57,6 +57,7 @@ VARIANTS = {
     "all16_wait0": ["-DTHA4_L016_CFG=4,4,1,2,1", "-DTHA4_FACE16_CFG=4,4,1,4", "-DTHA4_L116_CFG=4,2,1,1,1,2", "-DTHA4_L216P_CFG=16,64,1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "l1w4_wait0": ["-DTHA4_L116_CFG=4,1,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "l1w8x2_wait0": ["-DTHA4_L116_CFG=4,2,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+    "plainsplit": ["-DTHA4_PLAIN_SPLIT"],          # hi/lo split as `lo = fp16(v - float(hi))` (8 instructions per pair instead of 3-4 with v_fma_mix)
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
