@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
     const char* src = gw + ((size_t)cq * a.ntaps + t0) * TMB * 2048;
     char* dst = ring + slot * slot_bytes;
     const int pieces = nt * TMB * 2;
-    for (int pc = wave; pc < pieces; pc += kWaves) glds16(src + pc * 1024 + lane * 16, dst + pc * 1024);
+    for (int pc = wave; pc < pieces; pc += kWaves) glds16(src + pc * 1024 + (unsigned)(lane * 16), dst + pc * 1024);
   };
 
   // one quad of one K group: which source, its scale/shift/activation for lane group sg

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int pieces = nq * piece_per_quad;
     const char* g = gw + (size_t)q0 * piece_per_quad * 1024;
     char* l = ring + slot * slot_bytes;
-    for (int pc = wave; pc < pieces; pc += 4) glds16(g + pc * 1024 + lane * 16, l + pc * 1024);
+    for (int pc = wave; pc < pieces; pc += 4) glds16(g + pc * 1024 + (unsigned)(lane * 16), l + pc * 1024);
   };
 
   // operand fetch for global quad q (over the concatenated sources) and tap t

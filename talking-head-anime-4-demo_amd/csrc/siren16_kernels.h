@@ -62,6 +62,12 @@ THA4_DEV void store_block(char* act, int pg, int b, int lane, const f32x4& v) {
   *reinterpret_cast<f16x4*>(base + 1024) = lo;
 }
 
+// 16-byte load at (wave-uniform pointer) + (32-bit per-lane byte offset): the compiler emits the SGPR-base form of global_load and
+// no 64-bit VALU address arithmetic (v_lshl_add_u64 / v_add_co + v_addc per load otherwise)
+THA4_DEV f32x4 ldg4(const float* uniform_base, unsigned lane_bytes) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(uniform_base) + lane_bytes);
+}
+
 // Geometry: ACTQ counts K groups (2 KiB each) here; SLOT pieces are 2 KiB.
 template <int NS_, int MS_, int PG_, int ACTG_, int SLOT_PIECES_>
 struct Geo16 {
@@ -189,7 +195,7 @@ THA4_DEV void sine16_layer(const char*& gw, const float*& bias, const float*& sc
   const float inv = *scl++;
 #pragma unroll
   for (int b = 0; b < NBW; ++b) {
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + (mbase + b) * 16 + g4);
+    const f32x4 bb = ldg4(bias + (mbase + b) * 16, g4 * 4u);
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       f32x4 v;
@@ -218,7 +224,8 @@ THA4_DEV void z16_layer(const char*& gw, const float*& scl, char* ring, int& slo
   for (int b = 0; b < NBW; ++b)
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg)
-      *reinterpret_cast<f32x4*>(zframe + z_offset(mbase + b, w.lane >> 4, pix0[pg] + p, npix)) = acc[b][pg] * inv;
+      *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(zframe + z_offset(mbase + b, 0, 0, npix)) +
+                                (unsigned)(z_offset(0, w.lane >> 4, pix0[pg] + p, npix) * sizeof(float))) = acc[b][pg] * inv;
 }
 
 // The pose-folded first-layer bias of one network, computed by the CONSUMER: pb[c] = (b[c] + sum_k Wpose[k][c] pose[n][k])
@@ -251,8 +258,8 @@ THA4_DEV void first16_pos(const float* wx, const float* wy, const float* pb, con
 #pragma unroll
   for (int bb = 0; bb < NBW; ++bb) {
     const int b = mbase + bb;
-    const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
-    const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
+    const f32x4 vx = ldg4(wx + b * 16, g4 * 4u);
+    const f32x4 vy = ldg4(wy + b * 16, g4 * 4u);
     const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
@@ -281,30 +288,35 @@ THA4_DEV void first16_up_to(const float* zframe, int lowS, const float* wx, cons
     float lx0, lx1, ly0, ly1;
     up2_taps(X0[pg] + p, lowS, x0, x1, lx0, lx1);
     up2_taps(Y[pg], lowS, y0, y1, ly0, ly1);
-    const float* z00 = zframe + z_offset(0, w.lane >> 4, y0 * lowS + x0, npix);
-    const float* z01 = zframe + z_offset(0, w.lane >> 4, y0 * lowS + x1, npix);
-    const float* z10 = zframe + z_offset(0, w.lane >> 4, y1 * lowS + x0, npix);
-    const float* z11 = zframe + z_offset(0, w.lane >> 4, y1 * lowS + x1, npix);
+    const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+    // tap addresses as (wave-uniform block base) + (32-bit per-lane byte offset): global_load with an SGPR base, no 64-bit VALU address
+    // arithmetic per load (48 v_lshl_add_u64 per pixel group in level 1 otherwise)
+    const unsigned o00 = (unsigned)(z_offset(0, w.lane >> 4, y0 * lowS + x0, npix) * sizeof(float));
+    const unsigned o01 = (unsigned)(z_offset(0, w.lane >> 4, y0 * lowS + x1, npix) * sizeof(float));
+    const unsigned o10 = (unsigned)(z_offset(0, w.lane >> 4, y1 * lowS + x0, npix) * sizeof(float));
+    const unsigned o11 = (unsigned)(z_offset(0, w.lane >> 4, y1 * lowS + x1, npix) * sizeof(float));
 #pragma unroll
     for (int bb = 0; bb < NBW; ++bb) {
       const int b = mbase + bb;
-      const size_t off = (size_t)b * npix * 16;
-      const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
+      const char* zb = reinterpret_cast<const char*>(zframe) + (size_t)b * npix * 16 * sizeof(float);      // wave-uniform
+      const f32x4 vx = ldg4(wx + b * 16, g4 * 4u);
 #ifdef THA4_ABLATE_ZLOAD   // timing ablation only: results are wrong
       const f32x4 a = vx, bq = vx, c = vx, d = vx;
 #else
-      const f32x4 a = *reinterpret_cast<const f32x4*>(z00 + off);
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(z01 + off);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(z10 + off);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(z11 + off);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(zb + o00);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(zb + o01);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(zb + o10);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(zb + o11);
 #endif
-      const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
+      const f32x4 vy = ldg4(wy + b * 16, g4 * 4u);
       const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float up = ly0 * (lx0 * a[j] + lx1 * bq[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
-        v[j] = sin_u(up + fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));                           // z and tables carry the 30x
+        // six FMAs per value: position + pose bias, then the four taps with their products of the axis weights (the separable
+        // form ly0 (lx0 a + lx1 b) + ly1 (lx0 c + lx1 d) + position term took nine VALU instructions)
+        const float t = fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j]));                               // z and tables carry the 30x
+        v[j] = sin_u(fmaf(w00, a[j], fmaf(w01, bq[j], fmaf(w10, c[j], fmaf(w11, d[j], t)))));
       }
       sink(pg, b, v);
       if ((bb & (THA4_TAP_BLOCKS - 1)) == THA4_TAP_BLOCKS - 1) THA4_SCHED_FENCE();      // at most THA4_TAP_BLOCKS blocks (4 tap loads each) in flight: 12 blocks at once spill
@@ -706,7 +718,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
       const float inv = d.s_l2[layer];
 #pragma unroll
       for (int b = 0; b < kNB2; ++b) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + b * 16 + g4);
+        const f32x4 bb = ldg4(bias + b * 16, g4 * 4u);
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) {
           f32x4 v;

@@ -203,7 +203,7 @@ THA4_DEV void fetch_pieces(const char* g, char* l, int wave, int lane) {
   for (int i = 0; i < (PIECES + WAVES - 1) / WAVES; ++i) {
     const int pc = i * WAVES + wave;
 #ifndef THA4_ABLATE_FETCH
-    if (pc < PIECES) glds16(g + pc * 1024 + lane * 16, l + pc * 1024);
+    if (pc < PIECES) glds16(g + pc * 1024 + (unsigned)(lane * 16), l + pc * 1024);
 #endif
   }
 }
