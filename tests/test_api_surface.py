@@ -201,3 +201,6 @@ def test_library_holds_no_packed_fp32_instructions(built):
     assert dis.count("v_sin_f32") > 100
     packed = [l for l in dis.splitlines() if "v_pk_" in l and "_f32" in l.split("v_pk_", 1)[1].split()[0]]
     assert not packed, packed[:5]
+    # the hi/lo operand split rides on v_fma_mix (tha4_platform.h split_pair): if the optimiser ever folds the opaque -1 again the
+    # split decays to 8 instructions per pair and these disappear
+    assert dis.count("v_fma_mix") > 1000, dis.count("v_fma_mix")
