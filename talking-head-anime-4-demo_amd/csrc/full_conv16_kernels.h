@@ -293,19 +293,18 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
       const int item = tid + k * kThreads;
       if (item >= nitems) continue;
       f32x4 va = rawA[k], vb = rawB[k];
-      if (!kPool) {                                        // (wave-uniform conditions only: no per-lane branch)
-        if (cA.base) va = activate(va, cA);
-        if (cB.base) vb = activate(vb, cB);
+      const bool pad = gofs.v[k] < 0;                      // zero padding is applied AFTER normalisation + activation
+      if (!kPool) {                                        // (wave-uniform conditions only: no per-lane branch; pooled samples were activated at load)
+        if (cA.base) va = apply_act4(va, cA.sc, cA.sh, cA.act);
+        if (cB.base) vb = apply_act4(vb, cB.sc, cB.sh, cB.act);
       }
-      const float keep = gofs.v[k] < 0 ? 0.0f : 1.0f;      // zero padding is applied AFTER normalisation + activation
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        va[j] = gofs.v[k] < 0 ? 0.0f : va[j];
-        vb[j] = gofs.v[k] < 0 ? 0.0f : vb[j];
+      for (int j = 0; j < 4; ++j) {                        // (merged into the ReLU select this costs 28-30 VGPRs and spills the <4,4> tile: kept apart)
+        va[j] = pad ? 0.0f : va[j];
+        vb[j] = pad ? 0.0f : vb[j];
       }
-      (void)keep;
       f16x8 hi, lo;
-{
+      {
         _Float16 h[8], l[8];
         split_pair(va[0], va[1], m1, h[0], h[1], l[0], l[1]);
         split_pair(va[2], va[3], m1, h[2], h[3], l[2], l[3]);

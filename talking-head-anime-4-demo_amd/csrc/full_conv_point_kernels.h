@@ -133,11 +133,11 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
     Frag f;
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
-      const f32x4 xa = apply_act4(cur.va[pg], sca, sha, acta);
-      const f32x4 xb = apply_act4(cur.vb[pg], scb, shb, actb);
+      const f32x4 xa = apply_act4(cur.va[pg], sca, sha, acta, !valid);
+      const f32x4 xb = apply_act4(cur.vb[pg], scb, shb, actb, !valid);
       float ua[4], ub[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ua[j] = valid ? xa[j] : 0.0f; ub[j] = valid ? xb[j] : 0.0f; }
+      for (int j = 0; j < 4; ++j) { ua[j] = xa[j]; ub[j] = xb[j]; }
       _Float16 h[8], l[8];
       split_pair(ua[0], ua[1], m1, h[0], h[1], l[0], l[1]);
       split_pair(ua[2], ua[3], m1, h[2], h[3], l[2], l[3]);

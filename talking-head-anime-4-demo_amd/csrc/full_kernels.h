@@ -146,23 +146,22 @@ THA4_DEV float apply_act(float v, int act) {
   return v;
 }
 
-// act(x * sc + sh) on four values with ONE (uniform) dispatch on the activation; ReLU / none share a branch-free path
-THA4_DEV f32x4 apply_act4(const f32x4& x, const f32x4& sc, const f32x4& sh, int act) {
+// INPUT-side activation of the convolution kernels: act(x * sc + sh) on four values, `act` in {none, ReLU, SiLU} and wave-uniform (sigmoid / tanh only
+// occur as OUTPUT activations of the head blocks - apply_act - and FullNet::conv rejects them on the input side: their per-element dispatch used to
+// turn the staging code into a maze of scalar branches).  `zero` (per lane) forces the result to 0 - the zero padding of the window, which applies AFTER
+// normalisation + activation - and shares ONE select per value with the ReLU clamp (compare, scalar mask logic, v_cndmask).  NaN-transparent like
+// torch.relu: t < 0 is false for a NaN, so a NaN produced upstream reaches the moments of the next normalisation (the numeric-range guard).
+THA4_DEV f32x4 apply_act4(const f32x4& x, const f32x4& sc, const f32x4& sh, int act, bool zero = false) {
   f32x4 o;
-  // ReLU clamps; every other activation passes the value through untouched so that a NaN produced upstream stays a NaN
-  // (fmaxf(x, -inf) would turn it into -inf).  `act` is wave-uniform: the select is on a scalar condition
-  const bool relu = act == ACT_RELU;
+  const float lim = act == ACT_RELU ? 0.0f : -__builtin_inff();      // clamp threshold as a scalar FLOAT: no second lane mask to keep alive
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float t = fmaf(x[j], sc[j], sh[j]);
-    o[j] = relu ? fmaxf(t, 0.0f) : t;
+    o[j] = (zero || t < lim) ? 0.0f : t;
   }
   if (act == ACT_SILU) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = o[j] * fast_sigmoid(o[j]);
-  } else if (act == ACT_SIGMOID || act == ACT_TANH) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act);
+    for (int j = 0; j < 4; ++j) o[j] = o[j] * fast_sigmoid(o[j]);      // 0 * sigmoid(0) = 0: padding stays zero
   }
   return o;
 }

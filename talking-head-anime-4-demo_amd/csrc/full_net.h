@@ -250,6 +250,10 @@ class FullModel {
                const HostTensor& weight, const float* bias_host, int cout, bool want_stats,
                const FTensor* residual = nullptr, int res_mode = IN_DIRECT, const std::vector<int>* act_out = nullptr,
                const std::vector<float>* bias_override = nullptr) {
+    if (act_in != ACT_NONE && act_in != ACT_RELU && act_in != ACT_SILU) {      // apply_act4: sigmoid / tanh exist on the output side only
+      if (error.empty()) error = "convolution input activation must be none, ReLU or SiLU";
+      return FTensor();
+    }
     const FTensor& t0 = srcs[0].t;
     const int ih = t0.h, iw = t0.w;
     const int vh = in_mode == IN_UP2 ? ih * 2 : (in_mode == IN_POOL2 ? ih / 2 : ih);
