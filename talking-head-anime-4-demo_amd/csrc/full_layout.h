@@ -10,6 +10,14 @@
 
 namespace tha4 {
 
+// Launch-plan knobs (THA4_WANT_WGS, THA4_KSPLIT_MAX, THA4_TILE_TAPS_MAX, ...) are tuning aids of tools/sweep_plan_knobs.sh: they are
+// honoured only when THA4_TUNING is set, so that a stray variable in a production environment cannot change the plan that the
+// parity tests pinned.  (Diagnostics that only print - THA4_DUMP_SCHEDULE, THA4_DBG_CONV - read the environment directly.)
+inline const char* tune_env(const char* name) {
+  static const bool on = std::getenv("THA4_TUNING") != nullptr;
+  return on ? std::getenv(name) : nullptr;
+}
+
 constexpr int kMaxTapsHost = 16;
 
 // One launch of conv_mfma_kernel in "tile coordinates": which taps it visits and how tile
@@ -184,13 +192,13 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   t.taps_per_chunk = 1;
   // One chunk barrier per streamed weight chunk: whole K groups (9 taps of a 3x3, 8 of the 16 of a 4x4) per chunk where two
   // ring slots of that size fit beside the window, else up to 4 taps / 32 KiB (measured: 155.9 -> 158.4 fps, batch 8 294.7 -> 297.3)
-  const int taps_max = std::getenv("THA4_TILE_TAPS_MAX") ? std::atoi(std::getenv("THA4_TILE_TAPS_MAX")) : 9;            // tuning aid
-  const int slot_max = std::getenv("THA4_TILE_SLOT_MAX_KB") ? std::atoi(std::getenv("THA4_TILE_SLOT_MAX_KB")) * 1024 : 72 * 1024;
+  const int taps_max = tune_env("THA4_TILE_TAPS_MAX") ? std::atoi(tune_env("THA4_TILE_TAPS_MAX")) : 9;            // tuning aid
+  const int slot_max = tune_env("THA4_TILE_SLOT_MAX_KB") ? std::atoi(tune_env("THA4_TILE_SLOT_MAX_KB")) * 1024 : 72 * 1024;
   const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
   const size_t red = 8 * (size_t)TMB * 16 * 2 * sizeof(float);
   // the largest chunk that still leaves room for two ring slots; chunks need not divide the taps (9 = 5 + 4: two barriers
   // instead of three for the four-block tiles), but a chunk size is only taken if it lowers the chunk count
-  const bool uneven = std::getenv("THA4_TILE_EVEN_CHUNKS") == nullptr;     // tuning aid (measured: 157.15 -> 157.75 fps with 5 + 4)
+  const bool uneven = tune_env("THA4_TILE_EVEN_CHUNKS") == nullptr;     // tuning aid (measured: 157.15 -> 157.75 fps with 5 + 4)
   int best_chunks = g.ntaps + 1;
   for (int d = 1; d <= g.ntaps; ++d) {
     const int chunks = (g.ntaps + d - 1) / d;
@@ -204,7 +212,7 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   // deeper while it costs no occupancy: never push a workgroup that fits twice on a CU (<= 80 KiB) over that line
   t.ring_slots = 2;
   // second window buffer where it fits beside two ring slots (PG <= 2 tiles)
-  t.win_buffers = (!std::getenv("THA4_NO_DOUBLE_WINDOW") && 16 * plane + 2 * slot + red + extra_lds <= 160 * 1024) ? 2 : 1;
+  t.win_buffers = (!tune_env("THA4_NO_DOUBLE_WINDOW") && 16 * plane + 2 * slot + red + extra_lds <= 160 * 1024) ? 2 : 1;
   const size_t win = 8 * plane * t.win_buffers;
   const size_t base = win + 2 * slot + red + extra_lds;           // extra_lds: scale/shift table of a fused normalisation
   const size_t cap = base <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
@@ -225,9 +233,9 @@ struct TilePlan {
 // the chip without a K split where a single frame needs one
 inline TilePlan plan_tile_conv(const ConvGeom& g, int tile_h, int tile_w, int TMB, int mtiles, int nq, int want_wgs = 256, int frames = 1) {
   TilePlan best;
-  if (std::getenv("THA4_WANT_WGS")) want_wgs = std::atoi(std::getenv("THA4_WANT_WGS"));   // tuning aid
-  const int kmax = std::getenv("THA4_KSPLIT_MAX") ? std::atoi(std::getenv("THA4_KSPLIT_MAX")) : 16;   // tuning aid
-  const int min_nq = std::getenv("THA4_KSPLIT_MIN_NQ") ? std::atoi(std::getenv("THA4_KSPLIT_MIN_NQ")) : 0;   // tuning aid
+  if (tune_env("THA4_WANT_WGS")) want_wgs = std::atoi(tune_env("THA4_WANT_WGS"));   // tuning aid
+  const int kmax = tune_env("THA4_KSPLIT_MAX") ? std::atoi(tune_env("THA4_KSPLIT_MAX")) : 16;   // tuning aid
+  const int min_nq = tune_env("THA4_KSPLIT_MIN_NQ") ? std::atoi(tune_env("THA4_KSPLIT_MIN_NQ")) : 0;   // tuning aid
   float best_eff = 0.f;
   for (int pg : {4, 2, 1})
     for (int twl : {5, 4, 3}) {
@@ -344,8 +352,8 @@ inline SmallPlan plan_small_conv(const ConvGeom& g, int tile_h, int tile_w, int 
     }
     return b;
   };
-  const int cap = std::getenv("THA4_SMALL_MAX_WGS") ? std::atoi(std::getenv("THA4_SMALL_MAX_WGS")) : max_wgs;   // tuning aid
-  const bool big_first = std::getenv("THA4_SMALL_BIG_FIRST") != nullptr;                                        // tuning aid
+  const int cap = tune_env("THA4_SMALL_MAX_WGS") ? std::atoi(tune_env("THA4_SMALL_MAX_WGS")) : max_wgs;   // tuning aid
+  const bool big_first = tune_env("THA4_SMALL_BIG_FIRST") != nullptr;                                        // tuning aid
   for (int i = 0; i < 3; ++i) {
     const int pg = big_first ? (4 >> i) : (1 << i);
     const SmallPlan t = pick(pg);

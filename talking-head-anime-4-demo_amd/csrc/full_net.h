@@ -170,7 +170,7 @@ class FullModel {
   }
   // THA4_TILE16 (tuning aid): bit mask of the (TMB, PG) classes that run with sixteen waves: 1 <4,1>  2 <2,4>  4 <2,1>  8 <2,2>  16 <4,2>
   static int tile16_mask() {
-    static const int m = std::getenv("THA4_TILE16") ? std::atoi(std::getenv("THA4_TILE16")) : THA4_TILE16_DEFAULT;
+    static const int m = tune_env("THA4_TILE16") ? std::atoi(tune_env("THA4_TILE16")) : THA4_TILE16_DEFAULT;
     return m;
   }
   static bool tile16(int tmb, int pg) {
@@ -282,25 +282,25 @@ class FullModel {
     for (auto& sx : srcs)
       if (!sx.vector) { ctab += sx.t.cb * 16; if (sx.pend.fused) fpend = &sx.pend; }
     const size_t table_bytes = fpend ? (size_t)2 * ctab * sizeof(float) : 0;
-    if ((kind != K_SAME1 || std::getenv("THA4_TILE_1X1")) && !std::getenv("THA4_NO_TILE_CONV")) {
+    if ((kind != K_SAME1 || tune_env("THA4_TILE_1X1")) && !tune_env("THA4_NO_TILE_CONV")) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
       plan = plan_tile_conv(g0, th, tw, tmb, mtiles, nq, 256, max_batch);
       if (plan.ok && table_bytes && !tile_geom(g0, th, tw, plan.pg, tmb, plan.geom.tw_log2, table_bytes).ok) plan.ok = false;
       // a half-filled chip without K split: halve the output tile instead (the window is staged twice as often, but
       // no partial-sum traffic and no second launch)
-      if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles * max_batch < 200 && !std::getenv("THA4_NO_TMB_HALVE")) {
+      if (plan.ok && plan.ksplit == 1 && tmb == 4 && plan.geom.tiles * mtiles * max_batch < 200 && !tune_env("THA4_NO_TMB_HALVE")) {
         const TilePlan p2 = plan_tile_conv(g0, th, tw, 2, mtiles * 2, nq, 256, max_batch);
         if (p2.ok && p2.ksplit == 1 && p2.pg >= plan.pg) { plan = p2; tmb = 2; mtiles *= 2; }
       }
       tiled = plan.ok;
-      if (std::getenv("THA4_NO_TILE_SPLITK") && plan.ksplit > 1) tiled = false;
+      if (tune_env("THA4_NO_TILE_SPLITK") && plan.ksplit > 1) tiled = false;
     }
     // 1x1 convolutions on maps above 32x32: conv_point_kernel (operands straight from C16 global memory, fp16 hi/lo MFMA,
     // the K loop free of control flow around memory operations)
-    const int max1x1 = std::getenv("THA4_SMALL_1X1_MAX_PX") ? std::atoi(std::getenv("THA4_SMALL_1X1_MAX_PX")) : 32 * 32;
+    const int max1x1 = tune_env("THA4_SMALL_1X1_MAX_PX") ? std::atoi(tune_env("THA4_SMALL_1X1_MAX_PX")) : 32 * 32;
     bool point = false;
     PointPlan pp;
-    if (kind == K_SAME1 && in_mode == IN_DIRECT && tile_px > max1x1 && !tiled && !std::getenv("THA4_NO_POINT_CONV") &&
+    if (kind == K_SAME1 && in_mode == IN_DIRECT && tile_px > max1x1 && !tiled && !tune_env("THA4_NO_POINT_CONV") &&
         (!residual || res_mode == IN_DIRECT) && point_act_supported(act_in)) {
       bool tensors = true;
       for (auto& sx : srcs) tensors = tensors && !sx.vector;
@@ -318,12 +318,12 @@ class FullModel {
       // the tile plan would split over two launches, not the 16-tap stride-2 convolutions (their 108-pixel window per 16
       // outputs makes staging dominate) and not average-pooled inputs (four dependent samples per staged item)
       bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
-      if (!std::getenv("THA4_SMALL_ALL_KINDS") && (kind == K_S2K4 || in_mode == IN_POOL2)) want = false;
-      if (want && !std::getenv("THA4_NO_SMALL_CONV")) {
+      if (!tune_env("THA4_SMALL_ALL_KINDS") && (kind == K_S2K4 || in_mode == IN_POOL2)) want = false;
+      if (want && !tune_env("THA4_NO_SMALL_CONV")) {
         sp = plan_small_conv(g0, th, tw, nb, nq, 256, max_batch);
         small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
       }
-      if (!small && fpend && !tiled && !std::getenv("THA4_NO_SMALL_CONV")) {
+      if (!small && fpend && !tiled && !tune_env("THA4_NO_SMALL_CONV")) {
         // a folded normalisation needs one of the two kernels that can evaluate it: take conv_small_kernel even if its grid
         // runs in several rounds (1x1 projections behind a GroupNorm when the schedule is built for 2 frames)
         sp = plan_small_conv(g0, th, tw, nb, nq, 1 << 30, max_batch);
@@ -487,11 +487,11 @@ class FullModel {
     // few tiles: no finalize launch - every consumer reduces the per-tile moments itself (FusedNorm / FusedInstanceNorm)
     int total_tiles = 0;
     for (auto& t : srcs) total_tiles += t.stats_tiles;
-    const int fuse_max = std::getenv("THA4_FUSED_NORM_MAX_TILES") ? std::atoi(std::getenv("THA4_FUSED_NORM_MAX_TILES")) : 64;
+    const int fuse_max = tune_env("THA4_FUSED_NORM_MAX_TILES") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_TILES")) : 64;
     // (a batched call multiplies the consumers' workgroups, each of which would redo the reduction, while one finalize launch
     // serves all frames: fusing pays for max_batch <= 2 only - measured, profiles/r02_full_b1_reading.md)
-    const int fuse_batch = std::getenv("THA4_FUSED_NORM_MAX_BATCH") ? std::atoi(std::getenv("THA4_FUSED_NORM_MAX_BATCH")) : 2;
-    if (total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !std::getenv("THA4_NO_SMALL_CONV") && !std::getenv("THA4_NO_TILE_CONV")) {
+    const int fuse_batch = tune_env("THA4_FUSED_NORM_MAX_BATCH") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_BATCH")) : 2;
+    if (total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !tune_env("THA4_NO_SMALL_CONV") && !tune_env("THA4_NO_TILE_CONV")) {
       Pending p;
       p.fused = true;
       for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].stats_off; p.tiles[i] = srcs[i].stats_tiles; }
@@ -523,7 +523,7 @@ class FullModel {
       a.film1 = film1_off == kNone ? nullptr : Wk(film1_off); a.film1_stride = film1_stride;
       a.fault = fault;
       const int ctot = cbt * 16;
-      a.cpb = std::getenv("THA4_NORM_ONE_WG") ? ctot : norm_channels_per_block(ctot, channels, groups);
+      a.cpb = tune_env("THA4_NORM_ONE_WG") ? ctot : norm_channels_per_block(ctot, channels, groups);
       const int S = std::max(1, kNormThreads / a.cpb);
       hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch, (ctot + a.cpb - 1) / a.cpb), dim3(kNormThreads),
                          ((size_t)S * a.cpb * 2 + 2 * a.cpb) * sizeof(double), f.stream, a);

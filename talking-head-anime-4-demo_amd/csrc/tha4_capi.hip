@@ -101,11 +101,14 @@ struct tha4_student {
   size_t blob_bytes = 0;
   std::vector<float> pos128, pos256, pos512;   // position axes given at create (reused by tha4_student_set_weights)
   StreamOrder order;                           // the handle's workspace is shared by consecutive calls
-  // fault-hunt aid (profiles/r03_sin_cliff.md): level 2 from an externally assembled code object instead of the built-in kernel
-  // (env THA4_L2_CODE_OBJECT = path, THA4_L2_KERNEL = mangled name, THA4_L2_THREADS, THA4_L2_PX = pixels per workgroup)
+#ifdef THA4_L2_HOOK
+  // fault-hunt aid (profiles/r03_sin_cliff.md, tools/hunt/): level 2 from an externally assembled code object instead of the built-in kernel
+  // (env THA4_L2_CODE_OBJECT = path, THA4_L2_KERNEL = mangled name, THA4_L2_THREADS, THA4_L2_PX = pixels per workgroup).  Only in builds
+  // with -DTHA4_L2_HOOK: the shipped library never loads code from outside itself
   hipModule_t l2_module = nullptr;
   hipFunction_t l2_function = nullptr;
   int l2_threads = 0, l2_px = 0;
+#endif
 };
 
 namespace {
@@ -255,6 +258,7 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   if (e == hipSuccess) e = allow_lds(THA4_L116_KERNEL, v2::cfg::kL1Lds);
   if (e == hipSuccess) e = allow_lds(THA4_L216_KERNEL, v2::cfg::kL2Lds);
   if (e == hipSuccess) e = allow_lds(THA4_L216P_KERNEL, v2::cfg::kL2PLds);
+#ifdef THA4_L2_HOOK
   if (e == hipSuccess && std::getenv("THA4_L2_CODE_OBJECT") && std::getenv("THA4_L2_KERNEL")) {
     e = hipModuleLoad(&h->l2_module, std::getenv("THA4_L2_CODE_OBJECT"));
     if (e == hipSuccess) e = hipModuleGetFunction(&h->l2_function, h->l2_module, std::getenv("THA4_L2_KERNEL"));
@@ -262,6 +266,7 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
     h->l2_threads = std::getenv("THA4_L2_THREADS") ? std::atoi(std::getenv("THA4_L2_THREADS")) : 512;
     h->l2_px = std::getenv("THA4_L2_PX") ? std::atoi(std::getenv("THA4_L2_PX")) : 1024;
   }
+#endif
   if (e != hipSuccess) {
     cleanup();
     return fail(THA4_ERR_HIP, std::string("tha4_student_create: ") + hipGetErrorString(e));
@@ -350,10 +355,13 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
     hipLaunchKernelGGL((THA4_L116_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L1G>(batch, 256)), dim3(v2::cfg::L1G::THREADS),
                        v2::cfg::kL1Lds, s, d);
     if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
+#ifdef THA4_L2_HOOK
     if (h->l2_function) {
       void* params[] = {&d};
       HIP_TRY(hipModuleLaunchKernel(h->l2_function, batch * (512 * 512) / h->l2_px, 1, 1, h->l2_threads, 1, 1, v2::cfg::kL2PLds, s, params, nullptr));
-    } else if (THA4_L2_RESIDENT)
+    } else
+#endif
+    if (THA4_L2_RESIDENT)
       hipLaunchKernelGGL((THA4_L216P_KERNEL), dim3(batch * (512 * 512) / v2::cfg::L2P::PX), dim3(v2::cfg::L2P::THREADS),
                          v2::cfg::kL2PLds, s, d);
     else
@@ -374,7 +382,9 @@ void tha4_student_destroy(tha4_student* h) {
   if (h->ev_valid)
     for (auto& e : h->ev) (void)hipEventDestroy(e);
   h->order.destroy();
+#ifdef THA4_L2_HOOK
   if (h->l2_module) (void)hipModuleUnload(h->l2_module);
+#endif
   if (h->blob) (void)hipFree(h->blob);
   if (h->workspace) (void)hipFree(h->workspace);
   delete h;

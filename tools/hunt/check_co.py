@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: pose one frame three times with level 2 taken from each given code object (THA4_L2_CODE_OBJECT hook of the C ABI) and report
-max |posed frame - oracle| and whether the three evaluations are bitwise equal.   python tools/hunt/check_co.py dir_or_files..."""
+max |posed frame - oracle| and whether the three evaluations are bitwise equal.  Needs a library built with -DTHA4_L2_HOOK
+(THA4_HIP_LIB=build_variants/libtha4_hook.so; `THA4_SWEEP_VARIANTS=hook python tools/sweep.py build`).   python tools/hunt/check_co.py dir_or_files..."""
 import glob
 import os
 import subprocess

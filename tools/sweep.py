@@ -58,6 +58,7 @@ VARIANTS = {
     "l1w4_wait0": ["-DTHA4_L116_CFG=4,1,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "l1w8x2_wait0": ["-DTHA4_L116_CFG=4,2,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "plainsplit": ["-DTHA4_PLAIN_SPLIT"],          # hi/lo split as `lo = fp16(v - float(hi))` (8 instructions per pair instead of 3-4 with v_fma_mix)
+    "hook": ["-DTHA4_L2_HOOK"],                      # with the level-2 code-object hook of the fault hunt (tools/hunt/check_co.py)
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset

@@ -2,6 +2,6 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 : > gpurun_out/knobs.txt
-run() { echo "== $*" >> gpurun_out/knobs.txt; env "$@" timeout 300 python tools/time_full.py --mode steady --frames 60 2>/dev/null | grep "full model" >> gpurun_out/knobs.txt; }
+run() { echo "== $*" >> gpurun_out/knobs.txt; env THA4_TUNING=1 "$@" timeout 300 python tools/time_full.py --mode steady --frames 60 2>/dev/null | grep "full model" >> gpurun_out/knobs.txt; }
 for k in "$@"; do run $k; done
 cat gpurun_out/knobs.txt
