@@ -40,8 +40,11 @@ def _worker(rank, world, rendezvous, K, W, B, chunk, q):
     rows = None if frames is None else frames[:, 0, 0, 0].clone()
     uniform = None if frames is None else bool((frames == frames[:, :1, :1, :1]).all())
     q.put((rank, elapsed, work.calls, rows, uniform))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:                                    # scaffolding only (the result is already in the queue): a rank that leaves the barrier first and closes
+        dist.barrier()                      # its sockets can make the peer's last receive fail ("connection closed by peer") - seen once in ~30 runs
+        dist.destroy_process_group()
+    except Exception:                       # noqa: BLE001
+        pass
 
 
 @pytest.mark.parametrize("K,W,B,chunk", [(7, 2, 1, None), (5, 1, 2, 4), (20, 5, 1, None)])
@@ -90,8 +93,11 @@ def _stream_worker(rank, world, rendezvous, K, W, B, rgba8, q):
     args = argparse.Namespace(no_gather=False, rgba8_gather=rgba8, gather_chunk=4, settle_seconds=0.0)
     elapsed = bench.measure(work, args, torch.device("cpu"), rank, world, K, W, B, dist)       # the driver's path: the root streams
     q.put((rank, elapsed, work.calls, getattr(work, "delivered", None), getattr(work, "ring_bytes", None)))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:                                    # scaffolding only (the result is already in the queue): a rank that leaves the barrier first and closes
+        dist.barrier()                      # its sockets can make the peer's last receive fail ("connection closed by peer") - seen once in ~30 runs
+        dist.destroy_process_group()
+    except Exception:                       # noqa: BLE001
+        pass
 
 
 @pytest.mark.parametrize("rgba8", [False, True])

@@ -44,8 +44,11 @@ def _worker(rank, world, rendezvous, total, chunk, gather, q, rgba8=False):
     s = FrameShardedStream(frame_fn, total, shape, dtype, torch.device("cpu"), chunk=chunk, gather=gather)
     out = s.run(s.allocate_result()) if total % 2 else s.run()      # both entry points: caller-provided / internal buffer
     q.put((rank, s.local_range(), calls, None if out is None else out.clone()))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:                                    # scaffolding only (the result is already in the queue): a rank that leaves the barrier first and closes
+        dist.barrier()                      # its sockets can make the peer's last receive fail ("connection closed by peer") - seen once in ~30 runs
+        dist.destroy_process_group()
+    except Exception:                       # noqa: BLE001
+        pass
 
 
 def _to_u8(blk):
@@ -140,8 +143,11 @@ def _stream_worker(rank, world, rendezvous, total, chunk, slots, q):
                            on_chunk=on_chunk, ring_slots=slots)
     out = s.run()
     q.put((rank, out is None, s.ring_bytes(), got))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:                                    # scaffolding only (the result is already in the queue): a rank that leaves the barrier first and closes
+        dist.barrier()                      # its sockets can make the peer's last receive fail ("connection closed by peer") - seen once in ~30 runs
+        dist.destroy_process_group()
+    except Exception:                       # noqa: BLE001
+        pass
 
 
 @pytest.mark.parametrize("total,chunk,slots", [(203, 4, 2), (64, 8, 3), (1, 4, 2)])
