@@ -38,9 +38,6 @@ namespace tha4 {
 // 1 % SLOWER (146.5 vs 148.3 fps; batch 8 263 vs 268) - the barriers wait for wave skew, not for the fetches - so it stays off.
 #define THA4_TILE_COUNTED_WAIT 0
 #endif
-#ifndef THA4_TILE_TAP_PREFETCH
-#define THA4_TILE_TAP_PREFETCH 0     // 1: fragments of the next tap are requested under the MFMAs of the current one (candidate, unmeasured)
-#endif
 constexpr int kTileWaves = 8;
 constexpr int kTileThreads = kTileWaves * 64;
 constexpr int kTileMaxItems = 5;     // staging items (pixel, g) per thread and K group: window <= 640 pixels
@@ -371,50 +368,9 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
       }
       const char* wsl = ring + slot * slot_bytes + lane * 16 + (size_t)(mh * TMBW) * 2048;      // this wave's blocks of every tap
       const int taps_here = min(a.taps_per_chunk, a.ntaps - tc * a.taps_per_chunk);
-#if THA4_TILE_TAP_PREFETCH
-      // Register double-buffering across the taps of a chunk (candidate, default off: NOT yet measured on the device - DESIGN.md section 7): the
-      // fragments of tap tt + 1 are requested before the MFMAs of tap tt issue, so a wave does not sit out an LDS round trip per tap.
-      // Costs 4 * (PG + TMBW) * 2 more VGPRs; refused where that cannot fit (the <4,4> tile).
-      if (TMBW * PG >= 4 && TMBW * PG < 16) {          // (the small register tiles share a CU two workgroups at a time: they keep their 128-VGPR budget)
-        struct Frags { f16x8 bh[PG], bl[PG], ah[TMBW], al[TMBW]; };
-        auto load_frags = [&](int tt, Frags& f) {
-          const int toff = lane_pick(my_toff, tc * a.taps_per_chunk + tt);
-#pragma unroll
-          for (int pg = 0; pg < PG; ++pg) {
-            f.bh[pg] = *reinterpret_cast<const f16x8*>(win_hi + rd + boff[pg] + toff);
-            f.bl[pg] = *reinterpret_cast<const f16x8*>(win_lo + rd + boff[pg] + toff);
-          }
-#pragma unroll
-          for (int b = 0; b < TMBW; ++b) {
-            f.ah[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
-            f.al[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
-          }
-        };
-        auto mma_frags = [&](const Frags& f) {
-#pragma unroll
-          for (int b = 0; b < TMBW; ++b) {
-#pragma unroll
-            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(f.ah[b], f.bh[pg], acc[b][pg]);
-#pragma unroll
-            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(f.ah[b], f.bl[pg], acc[b][pg]);
-#pragma unroll
-            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(f.al[b], f.bh[pg], acc[b][pg]);
-          }
-        };
-        Frags fa, fb;
-        load_frags(0, fa);
-        for (int tt = 0; tt < taps_here; tt += 2) {
-          if (tt + 1 < taps_here) load_frags(tt + 1, fb);
-          THA4_SCHED_FENCE();
-          mma_frags(fa);
-          if (tt + 1 < taps_here) {
-            if (tt + 2 < taps_here) load_frags(tt + 2, fa);
-            THA4_SCHED_FENCE();
-            mma_frags(fb);
-          }
-        }
-      } else
-#endif
+      // (Register double-buffering across the taps of a chunk - the fragments of tap tt + 1 requested under the MFMAs of tap tt, +38-64 VGPRs, no
+      // spill - was measured in round 3 and is NOT it: 161.2 -> 160.1 frames/s steady, 150.0 -> 149.2 cold, tools/runs_r03/gpu_r03_c49.sh.  The second
+      // wave of the SIMD already covers the LDS round trip of a tap.)
       for (int tt = 0; tt < taps_here; ++tt) {
         const int t = tc * a.taps_per_chunk + tt;
         const int toff = lane_pick(my_toff, t);

@@ -58,10 +58,6 @@ VARIANTS = {
     "l1w4_wait0": ["-DTHA4_L116_CFG=4,1,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "l1w8x2_wait0": ["-DTHA4_L116_CFG=4,2,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "plainsplit": ["-DTHA4_PLAIN_SPLIT"],          # hi/lo split as `lo = fp16(v - float(hi))` (8 instructions per pair instead of 3-4 with v_fma_mix)
-    # ---- full model: fragments of the next tap requested under the MFMAs of the current one (emulator-clean, NOT yet measured: first thing for round 4;
-    #      A/B with tools/time_full.py [--batch 8] and tools/compare_libs.py --full against the _wait0 twin) ----
-    "tapprefetch": ["-DTHA4_TILE_TAP_PREFETCH=1"],
-    "tapprefetch_wait0": ["-DTHA4_TILE_TAP_PREFETCH=1", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "hook": ["-DTHA4_L2_HOOK"],                      # with the level-2 code-object hook of the fault hunt (tools/hunt/check_co.py)
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
