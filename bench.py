@@ -327,6 +327,10 @@ def main():
     ap.add_argument("--settle-seconds", type=float, default=0.3,
                     help="untimed frames posed for this long BEFORE the W warm-up steps, so that a short run (--steps 20 --warmup 5) "
                          "is timed at the GPU's steady clocks like the stream it samples (0 = none)")
+    ap.add_argument("--stub-gloo", action="store_true",
+                    help="TEST HARNESS ONLY (tests/test_bench_launch_gloo.py): run the multi-rank driver logic - torchrun ranks, sharding, gather "
+                         "to rank 0, barriers, max-over-ranks timing, the JSON line - over gloo on CPU tensors with a stub that POSES NOTHING "
+                         "(constant frames).  Measures nothing: the line says \"data\": \"stub\" and carries no roofline / cpu_baseline.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -334,6 +338,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.stub_gloo:
+        return stub_gloo_main(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -385,6 +391,59 @@ def main():
             result["config"] = dict(workload=wl, **par)
             result.update(full_extras(args, work, dev, world, fps, B))
         print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _StubWork:
+    """--stub-gloo: stands in for StudentWork / FullWork and poses nothing - step i of rank r fills its B frames with 1000 r + i."""
+
+    def __init__(self, rank, B):
+        self.rank, self.B = rank, B
+
+    def step(self, i, out=None):
+        if out is None:
+            out = torch.empty(self.B, 4, 512, 512)
+        out.fill_(1000.0 * self.rank + i)
+        return out
+
+    def step_rgba8(self, i, out=None):
+        if out is None:
+            out = torch.empty(self.B, 512, 512, 4, dtype=torch.uint8)
+        out.fill_((7 * self.rank + i) % 251)
+        return out
+
+
+def stub_gloo_main(args, rank, world):
+    """The launch / sharding / exchange / timing / reporting path of `bench.py --gpus N` with gloo instead of RCCL and a stub instead
+    of a poser (test harness; no GPU in the build container, no multi-GPU node for the builder).  Same code from `measure` on."""
+    dev = torch.device("cpu")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo")
+    B = max(1, args.batch)
+    K = args.steps if args.steps is not None else 4
+    W = args.warmup if args.warmup is not None else 1
+    work = _StubWork(rank, B)
+    elapsed = measure(work, args, dev, rank, world, K, W, B, dist)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        gather = world > 1 and not args.no_gather
+        print(json.dumps({"metric": "STUB: driver logic only, nothing was posed", "value": round(K * B * world / elapsed, 2), "unit": "stub frames/s",
+                          "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub (tests/test_bench_launch_gloo.py)", "frames_per_gpu": K * B, "batch": B,
+                                     "parallelism": f"frame-parallel x{world}",
+                                     "gather": ("rgba8" if args.rgba8_gather else "fp32") if gather else False,
+                                     "gather_root_ring_bytes": getattr(work, "ring_bytes", None) if gather else None,
+                                     "delivered": getattr(work, "delivered", None) if gather else None}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

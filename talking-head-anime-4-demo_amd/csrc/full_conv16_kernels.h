@@ -41,6 +41,8 @@ namespace tha4 {
 constexpr int kTileWaves = 8;
 constexpr int kTileThreads = kTileWaves * 64;
 constexpr int kTileMaxItems = 5;     // staging items (pixel, g) per thread and K group: window <= 640 pixels
+constexpr int kTileWavesHalf = 4;    // the four-wave form (NW = 4, round 4): half the pixel tile, TWO workgroups per CU
+constexpr int kTileMaxItemsHalf = 6; // its staging items per thread: window <= 384 pixels (16 x 16 outputs + halo)
 
 // bytes of one lane-group plane of the window image; planes are skewed by 32 B so that the staging writes
 // (4 consecutive lanes = 4 planes of one pixel) hit distinct banks
@@ -137,23 +139,29 @@ THA4_DEV int fused_table_floats(const ConvArgs& a) {      // 2 x padded concaten
 // MSW = 2 (round 3): SIXTEEN waves on the same workgroup tile - the TMB output blocks are split over two halves of the workgroup
 // (wave w: pixel slot w & 7, block half w >> 3), so the window, the weight ring and every byte of traffic stay what they are while each
 // wave carries half the accumulators and a SIMD hosts four waves instead of two (what the student kernels gained 5-10 % from).
-template <int TMB, int PG, int INMODE, int MSW = 1>
-__global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs a) {
+// NW = 4 (round 4): FOUR pixel-slot waves per workgroup = half the pixel tile (64 PG positions), at most 80 KiB of LDS and the register
+// budget of two waves per SIMD, so that TWO workgroups share a CU: one workgroup's prologue (norm table, first fetch, first window),
+// staging phases and epilogue (stores, statistics) run under the other one's MFMAs instead of leaving the matrix pipe idle - the
+// lock-step of the 8-wave form has every wave of the CU in the same phase.  A workgroup in an odd slot of its CU (HW_ID.TG_ID) starts
+// `dephase_cycles` late, so that a single-round grid (batch 1) does not keep the two in phase.
+template <int TMB, int PG, int INMODE, int MSW = 1, int NW = kTileWaves>
+__global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2) conv_tile_kernel(ConvArgs a) {      // (threads, waves per SIMD)
   static_assert(MSW == 1 || (MSW == 2 && TMB % 2 == 0), "the block split needs an even block count");
+  static_assert(NW == kTileWaves || (NW == kTileWavesHalf && MSW == 1), "four or eight pixel-slot waves");
   constexpr bool kPool = INMODE == IN_POOL2;
-  constexpr int kWaves = kTileWaves * MSW, kThreads = kTileThreads * MSW;      // waves / threads of this instantiation
+  constexpr int kWaves = NW * MSW, kThreads = 64 * kWaves;                     // waves / threads of this instantiation
   constexpr int TMBW = TMB / MSW;                                              // output blocks per wave
-  constexpr int KI = MSW == 2 ? (kTileMaxItems + 1) / 2 : kTileMaxItems;       // staging items per thread
+  constexpr int KI = NW == kTileWavesHalf ? kTileMaxItemsHalf : MSW == 2 ? (kTileMaxItems + 1) / 2 : kTileMaxItems;       // staging items per thread
   THA4_DYN_LDS(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform_i32(tid >> 6);
-  const int pw = wave & (kTileWaves - 1), mh = wave / kTileWaves;      // pixel slot and block half of this wave
+  const int pw = wave & (NW - 1), mh = wave / NW;                      // pixel slot and block half of this wave
   const int p = lane & 15, g = lane >> 4, g4 = g * 4;
   const float m1 = split_minus_one();
 
   // ---- tile decomposition -------------------------------------------------------------------
-  const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (kTileWaves * PG * 16) >> twl;
+  const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (NW * PG * 16) >> twl;
   const int tiles_x = (a.tile_w + TWW - 1) >> twl;
   const int tiles_per_frame = tiles_x * ((a.tile_h + TWH - 1) / TWH);
   const int n = blockIdx.x / tiles_per_frame;
@@ -181,9 +189,9 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
   const int WB = a.win_buffers == 2 ? 8 * PLANE : 0;      // byte distance of the second window buffer (0: single-buffered)
   char* ring = smem + 8 * PLANE + WB;
   const int D = a.ring_slots;                                            // ring depth (2..4)
-  float* red = reinterpret_cast<float*>(ring + D * slot_bytes);          // [8 waves][TMB*16][2]
+  float* red = reinterpret_cast<float*>(ring + D * slot_bytes);          // [NW waves][TMB*16][2]
   // normalisation folded into this kernel (FusedNorm): per-channel scale | shift table behind `red`
-  float* tab_sc = red + kTileWaves * TMB * 16 * 2;
+  float* tab_sc = red + NW * TMB * 16 * 2;
   float* tab_sh = tab_sc + (fused_table_floats(a) >> 1);
   const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
 
@@ -279,6 +287,7 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
   f32x4 rawA[KI], rawB[KI];
   QuadCtx cA, cB;
   auto load_window = [&](int Q, const Offsets gofs) {
+    if (THA4_HOOK_TILE_WINDOW_BYPASS) return;
     cA = quad_ctx(2 * Q);
     cB = quad_ctx(2 * Q + 1);
 #pragma unroll
@@ -288,11 +297,18 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
     }
   };
   auto write_window = [&](const Offsets gofs, int wofs) {   // wofs: byte offset of the window buffer written
+    if (THA4_HOOK_TILE_WINDOW_BYPASS) return;
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       const int item = tid + k * kThreads;
       if (item >= nitems) continue;
       f32x4 va = rawA[k], vb = rawB[k];
+      if (THA4_HOOK_TILE_STAGE_VALU_BYPASS) {                // tuning builds only: the loaded bits as they are
+        const int off = sg * PLANE + (item >> 2) * 16;
+        *reinterpret_cast<f32x4*>(win_hi + wofs + off) = va;
+        *reinterpret_cast<f32x4*>(win_lo + wofs + off) = vb;
+        continue;
+      }
       const bool pad = gofs.v[k] < 0;                      // zero padding is applied AFTER normalisation + activation
       if (!kPool) {                                        // (wave-uniform conditions only: no per-lane branch; pooled samples were activated at load)
         if (cA.base) va = apply_act4(va, cA.sc, cA.sh, cA.act);
@@ -337,6 +353,7 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
 #define THA4_CSTAMP()
 #endif
   THA4_CSTAMP();                                           // 0: entry (after index set-up)
+  if (NW == kTileWavesHalf && a.dephase_cycles > 0) dephase_odd_slot(a.dephase_cycles);
   int slot = 0, chunk = q_begin * ntc;
   const int nchunks = q_end * ntc;
   const bool reduce_phase = a.phase == 2;
@@ -441,7 +458,7 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
 
   // ---- split-K: phase 1 publishes the partial fragments, phase 2 adds them in split order ----------------
   if (PG < 4 && a.phase != 0) {      // the planner never splits K with the largest tile (its registers are all spoken for)
-    const size_t frag = (size_t)kTileWaves * PG * 64;                         // f32x4 fragments per output block (8 pixel slots)
+    const size_t frag = (size_t)NW * PG * 64;                                 // f32x4 fragments per output block (NW pixel slots)
     // partial layout [split][frame][output block][tile][fragment]: indexed by the OUTPUT BLOCK, not by (m-tile, b), so
     // that phase 2 can run with one output block per workgroup (TMB = 1: 4x the workgroups, a quarter of the serial
     // load rounds each) on partials written by a TMB = 4 phase 1
@@ -493,6 +510,7 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       if (!inside[pg]) continue;                            // ragged tile: position outside the map
+      if (THA4_HOOK_TILE_EPILOGUE_BYPASS && acc[b][pg][0] != 1.2345e33f) continue;     // tuning builds only
       const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
       const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
       f32x4 v = acc[b][pg] * a.w16_inv_scale + bias;
@@ -538,7 +556,7 @@ __global__ void __launch_bounds__(kTileThreads * MSW) conv_tile_kernel(ConvArgs 
     __syncthreads();
     for (int i = tid; i < TMB * 16; i += kThreads) {
       float s = 0.f, q = 0.f;
-      for (int wv2 = 0; wv2 < kTileWaves; ++wv2) {
+      for (int wv2 = 0; wv2 < NW; ++wv2) {
         s += red[((wv2 * TMB) * 16 + i) * 2 + 0];
         q += red[((wv2 * TMB) * 16 + i) * 2 + 1];
       }

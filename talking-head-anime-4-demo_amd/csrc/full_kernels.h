@@ -98,6 +98,7 @@ struct ConvArgs {
   int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue
   FusedNorm fnorm;       // conv_tile_kernel / conv_small_kernel: normalisation of the tensor sources computed in the prologue
   int units_per_q;       // conv_small_kernel: tap ranges per K group (1, 2, 4 or 8: spreads few K groups over the 8 waves)
+  int dephase_cycles;    // conv_tile_kernel<..., NW = 4>: start delay of a workgroup in an odd slot of its CU (0: none)
 #ifdef THA4_PHASE_TIMING
   long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
 #endif

@@ -170,9 +170,12 @@ struct TileGeom {
   int win_buffers = 1;           // 2: the window is double-buffered (one barrier per K group less)
   size_t lds = 0;
 };
-inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB, int tw_log2, size_t extra_lds = 0) {
+// nw: pixel-slot waves of the workgroup - 8 (one workgroup per CU, up to 160 KiB of LDS) or 4 (conv_tile_kernel<..., NW = 4>: half the
+// tile, at most 80 KiB so that two workgroups share a CU)
+inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int TMB, int tw_log2, size_t extra_lds = 0, int nw = 8) {
   TileGeom t;
-  const int px = 8 * PG * 16;
+  const int px = nw * PG * 16;
+  const size_t lds_cap = nw == 8 ? 160 * 1024 : 80 * 1024;
   t.tw_log2 = tw_log2;
   const int tw = 1 << tw_log2;
   t.th = px / tw;
@@ -188,14 +191,14 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   t.win_h = (t.th - 1) * g.in_stride + (dy_hi - dy_lo) + 1;
   t.win_w = (tw - 1) * g.in_stride + (dx_hi - dx_lo) + 1;
   const int npx = t.win_h * t.win_w;
-  if (npx * 4 > 5 * 512) return t;                     // kTileMaxItems staging items per thread
+  if (npx * 4 > (nw == 8 ? 5 * 512 : 6 * 256)) return t;      // kTileMaxItems (kTileMaxItemsHalf) staging items per thread
   t.taps_per_chunk = 1;
   // One chunk barrier per streamed weight chunk: whole K groups (9 taps of a 3x3, 8 of the 16 of a 4x4) per chunk where two
   // ring slots of that size fit beside the window, else up to 4 taps / 32 KiB (measured: 155.9 -> 158.4 fps, batch 8 294.7 -> 297.3)
   const int taps_max = tune_env("THA4_TILE_TAPS_MAX") ? std::atoi(tune_env("THA4_TILE_TAPS_MAX")) : 9;            // tuning aid
   const int slot_max = tune_env("THA4_TILE_SLOT_MAX_KB") ? std::atoi(tune_env("THA4_TILE_SLOT_MAX_KB")) * 1024 : 72 * 1024;
   const size_t plane = (size_t)(npx * 16 + 127) / 128 * 128 + 32;
-  const size_t red = 8 * (size_t)TMB * 16 * 2 * sizeof(float);
+  const size_t red = (size_t)nw * TMB * 16 * 2 * sizeof(float);
   // the largest chunk that still leaves room for two ring slots; chunks need not divide the taps (9 = 5 + 4: two barriers
   // instead of three for the four-block tiles), but a chunk size is only taken if it lowers the chunk count
   const bool uneven = tune_env("THA4_TILE_EVEN_CHUNKS") == nullptr;     // tuning aid (measured: 157.15 -> 157.75 fps with 5 + 4)
@@ -203,6 +206,7 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   for (int d = 1; d <= g.ntaps; ++d) {
     const int chunks = (g.ntaps + d - 1) / d;
     if ((uneven || g.ntaps % d == 0) && d <= taps_max && (size_t)d * TMB * 2048 <= (size_t)slot_max && chunks < best_chunks &&
+        (nw == 8 || 8 * plane + 2 * (size_t)d * TMB * 2048 + red + extra_lds <= lds_cap) &&
         ((d <= 4 && (size_t)d * TMB * 2048 <= 32 * 1024) || 8 * plane + 2 * (size_t)d * TMB * 2048 + red + extra_lds <= 160 * 1024)) {
       t.taps_per_chunk = d;
       best_chunks = chunks;
@@ -212,13 +216,13 @@ inline TileGeom tile_geom(const ConvGeom& g, int tile_h, int tile_w, int PG, int
   // deeper while it costs no occupancy: never push a workgroup that fits twice on a CU (<= 80 KiB) over that line
   t.ring_slots = 2;
   // second window buffer where it fits beside two ring slots (PG <= 2 tiles)
-  t.win_buffers = (!tune_env("THA4_NO_DOUBLE_WINDOW") && 16 * plane + 2 * slot + red + extra_lds <= 160 * 1024) ? 2 : 1;
+  t.win_buffers = (!tune_env("THA4_NO_DOUBLE_WINDOW") && 16 * plane + 2 * slot + red + extra_lds <= lds_cap) ? 2 : 1;
   const size_t win = 8 * plane * t.win_buffers;
   const size_t base = win + 2 * slot + red + extra_lds;           // extra_lds: scale/shift table of a fused normalisation
-  const size_t cap = base <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
+  const size_t cap = base <= 80 * 1024 ? 80 * 1024 : lds_cap;
   while (t.ring_slots < 4 && win + (t.ring_slots + 1) * slot + red + extra_lds <= cap) ++t.ring_slots;
   t.lds = win + t.ring_slots * slot + red + extra_lds;
-  t.ok = t.lds <= 160 * 1024;
+  t.ok = t.lds <= lds_cap;
   return t;
 }
 

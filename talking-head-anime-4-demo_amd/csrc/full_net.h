@@ -24,6 +24,9 @@
 #ifndef THA4_TILE16_DEFAULT
 #define THA4_TILE16_DEFAULT 0      // conv_tile_kernel classes that run with sixteen waves (bit mask, see tile16_mask)
 #endif
+#ifndef THA4_TILE_NW4_DEFAULT
+#define THA4_TILE_NW4_DEFAULT 0     // conv_tile_kernel classes that run as four-wave workgroups, two per CU (bit mask, see nw4_mask)
+#endif
 #include "full_conv_point_kernels.h"
 #include "full_kernels.h"
 #include "full_layout.h"
@@ -178,7 +181,29 @@ class FullModel {
     return (tile16_mask() & bit) != 0;
   }
 #endif
-  static void dispatch_tile(int tmb, int pg, int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  // four-wave form (NW = 4, round 4): half the pixel tile, two workgroups per CU
+  template <int TMB, int PG>
+  static void launch_tile4(int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    if (inmode == IN_DIRECT) hipLaunchKernelGGL((conv_tile_kernel<TMB, PG, IN_DIRECT, 1, 4>), grid, dim3(256), lds, s, a);
+    else if (inmode == IN_UP2) hipLaunchKernelGGL((conv_tile_kernel<TMB, PG, IN_UP2, 1, 4>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_tile_kernel<TMB, PG, IN_POOL2, 1, 4>), grid, dim3(256), lds, s, a);
+  }
+  // classes that take the four-wave form: 1 <4,1>  2 <2,4>  4 <2,1>  8 <2,2>  16 <4,2>  32 <4,4>; THA4_TILE_NW4 is a tuning aid
+  static int nw4_mask() {
+    static const int m = tune_env("THA4_TILE_NW4") ? std::atoi(tune_env("THA4_TILE_NW4")) : THA4_TILE_NW4_DEFAULT;
+    return m;
+  }
+  static bool nw4_class(int tmb, int pg) {
+    const int bit = tmb == 4 && pg == 1 ? 1 : tmb == 2 && pg == 4 ? 2 : tmb == 2 && pg == 1 ? 4 : tmb == 2 && pg == 2 ? 8 : tmb == 4 && pg == 2 ? 16 :
+                    tmb == 4 && pg == 4 ? 32 : 0;
+    return (nw4_mask() & bit) != 0;
+  }
+  static void dispatch_tile(int tmb, int pg, int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, bool nw4 = false) {
+    if (nw4) {
+#define THA4_TCASE4(TM, PGV) if (tmb == TM && pg == PGV) return launch_tile4<TM, PGV>(inmode, a, grid, lds, s);
+      THA4_TCASE4(4, 4) THA4_TCASE4(4, 2) THA4_TCASE4(4, 1) THA4_TCASE4(2, 4) THA4_TCASE4(2, 2) THA4_TCASE4(2, 1)
+#undef THA4_TCASE4
+    }
 #ifdef THA4_TILE16_BUILD
     if (a.phase != 2 && tile16(tmb, pg)) {
 #define THA4_TCASE16(TM, PGV) if (tmb == TM && pg == PGV) return launch_tile16<TM, PGV>(inmode, a, grid, lds, s);
@@ -223,6 +248,12 @@ class FullModel {
     THA4_TALLOW(4, 4) THA4_TALLOW(4, 2) THA4_TALLOW(4, 1) THA4_TALLOW(2, 4) THA4_TALLOW(2, 2) THA4_TALLOW(2, 1)
     THA4_TALLOW(1, 4) THA4_TALLOW(1, 2) THA4_TALLOW(1, 1)
 #undef THA4_TALLOW
+#define THA4_TALLOW4(TM, PGV)                                                            \
+  set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_DIRECT, 1, 4>));        \
+  set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_UP2, 1, 4>));           \
+  set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_POOL2, 1, 4>));
+    THA4_TALLOW4(4, 4) THA4_TALLOW4(4, 2) THA4_TALLOW4(4, 1) THA4_TALLOW4(2, 4) THA4_TALLOW4(2, 2) THA4_TALLOW4(2, 1)
+#undef THA4_TALLOW4
 #ifdef THA4_TILE16_BUILD
 #define THA4_TALLOW16(TM, PGV)                                                        \
   set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_DIRECT, 2>));        \
@@ -331,6 +362,18 @@ class FullModel {
       }
       if (small) { tiled = false; tmb = 1; mtiles = nb; }
     }
+    // four-wave workgroups, two per CU (conv_tile_kernel<..., NW = 4>): same per-wave tile, half the workgroup tile.  Only without a
+    // K split (phase 2 reads the partials of an eight-wave phase 1) and where every parity class has a geometry within 80 KiB
+    bool nw4 = false;
+    int twl4 = 4;
+    if (tiled && plan.ksplit == 1 && nw4_class(tmb, plan.pg)) {
+      const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
+      float best_eff = 0.f;
+      for (int twl : {4, 3, 5}) {
+        const TileGeom t = tile_geom(g0, th, tw, plan.pg, tmb, twl, table_bytes, 4);
+        if (t.ok && t.efficiency > best_eff * 1.1f) { best_eff = t.efficiency; twl4 = twl; nw4 = true; }
+      }
+    }
     // fallbacks (1x1 convolutions): small maps (<= 32x32) one pixel group per workgroup with K split over its 4 waves
     // (conv_splitk_kernel), otherwise the exact-fp32 pixel-tiled kernel (conv_mfma_kernel)
     const bool splitk = !small && !tiled && !point && tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
@@ -341,16 +384,20 @@ class FullModel {
     else if (tiled) pg = plan.pg;
     else if (!splitk && tmb >= 2 && tile_px % 128 == 0 && (tile_px / 128) * mtiles * nclass >= 512) pg = 2;
     if (!small && !tiled && !point && tile_px % (splitk ? 16 : 64 * pg) != 0) { if (error.empty()) error = "conv tile grid is not a multiple of the pixel tile"; return FTensor(); }
-    const int tiles = small ? sp.tiles : point ? pp.tiles : tiled ? plan.geom.tiles : splitk ? tile_px / 16 : tile_px / (64 * pg);
+    int tiles = small ? sp.tiles : point ? pp.tiles : tiled ? plan.geom.tiles : splitk ? tile_px / 16 : tile_px / (64 * pg);
+    if (nw4) {
+      const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
+      tiles = tile_geom(g0, th, tw, pg, tmb, twl4, table_bytes, 4).tiles;
+    }
     const int ksplit = tiled ? plan.ksplit : 1;
     if (tiled && ksplit > 1) {
       partial_floats = std::max(partial_floats, (size_t)ksplit * mtiles * tiles * tmb * 8 * pg * 64 * 4);
     }
     const int conv_index = conv_counter++;
     if (std::getenv("THA4_DUMP_SCHEDULE"))
-      std::fprintf(stderr, "conv #%d kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d ksplit=%d twl=%d\n", conv_index, (int)kind, ih,
+      std::fprintf(stderr, "conv #%d kind=%d in=%dx%d mode=%d tile=%dx%d cin=%d(cb %d) cout=%d taps=%d splitk=%d tmb=%d pg=%d classes=%d wgs=%d tiled=%d ksplit=%d twl=%d nw=%d\n", conv_index, (int)kind, ih,
                    iw, in_mode, th, tw, cin, cbtot, cout, ntaps_k, (int)splitk, tmb, pg, nclass, tiles * mtiles * ksplit, small ? 2 : point ? 3 : (int)tiled, ksplit,
-                   small ? sp.tw_log2 : tiled ? plan.geom.tw_log2 : 0);
+                   small ? sp.tw_log2 : nw4 ? twl4 : tiled ? plan.geom.tw_log2 : 0, nw4 ? 4 : 8);
     FTensor out = new_tensor(nb, oh, ow);
     if (want_stats) {
       out.stats_tiles = tiles * nclass;
@@ -386,7 +433,7 @@ class FullModel {
         lds = point_lds_bytes(tmb, cbtot);
         a.w16_inv_scale = inv;
       } else if (tiled) {
-        const TileGeom tg = tile_geom(g, th, tw, pg, tmb, plan.geom.tw_log2, table_bytes);
+        const TileGeom tg = nw4 ? tile_geom(g, th, tw, pg, tmb, twl4, table_bytes, 4) : tile_geom(g, th, tw, pg, tmb, plan.geom.tw_log2, table_bytes);
         float inv = 1.f;
         const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb, &inv);
         w_off = add_param(p16.data(), p16.size());
@@ -394,7 +441,10 @@ class FullModel {
         a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
         a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots;
         a.win_buffers = tg.win_buffers;
-        if (!tg.ok) { if (error.empty()) error = "conv tile geometry differs between parity classes"; return FTensor(); }
+        if (!tg.ok || tg.tiles != tiles) { if (error.empty()) error = "conv tile geometry differs between parity classes"; return FTensor(); }
+        // single-round grids keep two co-resident workgroups in phase: the one in the odd slot starts late (tha4_platform.h dephase_odd_slot)
+        if (nw4 && (long)tiles * mtiles * max_batch <= 2 * 256)
+          a.dephase_cycles = tune_env("THA4_TILE_DEPHASE") ? std::atoi(tune_env("THA4_TILE_DEPHASE")) : 6000;
       } else {
         w_off = add_param(pack_conv_weight(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb));
         cq = std::max(1, 32 / (g.ntaps * tmb));
@@ -467,7 +517,7 @@ class FullModel {
             c.phase = 2;                       // one output block per workgroup: 4x the workgroups, a quarter of the load rounds each
             dispatch_tile(1, pg, in_mode, c, dim3(f.batch * tiles, mtiles * tmb, 1), lds, f.stream);
           } else {
-            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, 1), lds, f.stream);
+            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, 1), lds, f.stream, nw4);
           }
         } else {
           dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);

@@ -172,9 +172,7 @@ THA4_DEV void gemm16_stream(const char*& gw, char* ring, int& slot, const char* 
       const char* av = act + (size_t)(cg * CQ) * 2048 + w.lane * 16;
       mma_chunk<G, NB / HB, BPC, CQ, NBW>(wv, av, acc, h * BPC);
     }
-#ifndef THA4_ABLATE_BARRIER
-    __syncthreads();
-#endif
+    THA4_HOOK_CHUNK_BARRIER();
     slot = nslot;
   }
   }
@@ -300,14 +298,10 @@ THA4_DEV void first16_up_to(const float* zframe, int lowS, const float* wx, cons
       const int b = mbase + bb;
       const char* zb = reinterpret_cast<const char*>(zframe) + (size_t)b * npix * 16 * sizeof(float);      // wave-uniform
       const f32x4 vx = ldg4(wx + b * 16, g4 * 4u);
-#ifdef THA4_ABLATE_ZLOAD   // timing ablation only: results are wrong
-      const f32x4 a = vx, bq = vx, c = vx, d = vx;
-#else
-      const f32x4 a = *reinterpret_cast<const f32x4*>(zb + o00);
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(zb + o01);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(zb + o10);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(zb + o11);
-#endif
+      const f32x4 a = THA4_HOOK_ZLOAD(zb + o00, vx);
+      const f32x4 bq = THA4_HOOK_ZLOAD(zb + o01, vx);
+      const f32x4 c = THA4_HOOK_ZLOAD(zb + o10, vx);
+      const f32x4 d = THA4_HOOK_ZLOAD(zb + o11, vx);
       const f32x4 vy = ldg4(wy + b * 16, g4 * 4u);
       const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
       f32x4 v;
@@ -523,9 +517,7 @@ THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bia
     wv += body_source(img, face, g, y1, x1) * wse;
     const float blended = (1.0f - al) * wv + al * col;
     const size_t pix = (size_t)pix0[pg] + p;
-#if defined(THA4_HUNT_WAIT_BEFORE_STORES) && !defined(THA4_EMU)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // hazard hunt (tools/sin_cliff.py): no load outstanding when a store issues
-#endif
+    THA4_HOOK_BEFORE_STORES();
     if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
     if (d.out_rgba8) store_display(d, n, pix, g, p, blended);
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
@@ -688,9 +680,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   const int strip0 = xcd_tile(blockIdx.x, gridDim.x) * SPW;
 #pragma unroll 1
   for (int k = w.wave; k < SPW; k = wave_take_ticket(ticket, w.lane)) {
-#if defined(THA4_HUNT_WAIT_TOP) && !defined(THA4_EMU)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // hazard hunt: the previous strip's stores are complete before this strip's loads
-#endif
+    THA4_HOOK_STRIP_TOP();
     const int strip = strip0 + k;
     const int n = strip / STRIPS;
     int pix0[PG], X0[PG], Y[PG];

@@ -84,9 +84,7 @@ THA4_DEV void store_display(const StudentDev& d, int n, size_t pix, int g, int p
 // sin(r) = r + r^3 q(r^2) on [-pi/2, pi/2] (degree-9 minimax), sign flipped for odd k.
 // ---------------------------------------------------------------------------------------------
 THA4_DEV float sin_omega(float z) {
-#ifdef THA4_ABLATE_SIN   // timing ablation only (tools/sweep.py): results are wrong
-  return z;
-#endif
+  if (THA4_HOOK_SIN_BYPASS) return z;
   const float u = kOmega * z;
 #if defined(THA4_HW_SIN) && !defined(THA4_EMU)
   // v_sin_f32 variant (input in revolutions): same reference rounding of u, 2-term Cody-Waite by 2 pi,
@@ -119,9 +117,7 @@ THA4_DEV float sin_omega(float z) {
 // 2-term Cody-Waite (k * 3.140625 is exact for |k| < 2^16; total error <= |k| 6e-11), degree-9 polynomial:
 // 12 VALU ops: fma, sub, 2 fma, mul, 3 fma, mul, fma, shift, xor.
 THA4_DEV float sin_u(float u) {
-#ifdef THA4_ABLATE_SIN   // timing ablation only (tools/sweep.py): results are wrong
-  return u;
-#endif
+  if (THA4_HOOK_SIN_BYPASS) return u;
 #if THA4_SIN_TURNS
 #ifdef THA4_EMU
   return (float)sin(6.283185307179586476925 * (double)u);
@@ -202,9 +198,7 @@ THA4_DEV void fetch_pieces(const char* g, char* l, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < (PIECES + WAVES - 1) / WAVES; ++i) {
     const int pc = i * WAVES + wave;
-#ifndef THA4_ABLATE_FETCH
-    if (pc < PIECES) glds16(g + pc * 1024 + (unsigned)(lane * 16), l + pc * 1024);
-#endif
+    THA4_HOOK_FETCH(if (pc < PIECES) glds16(g + pc * 1024 + (unsigned)(lane * 16), l + pc * 1024));
   }
 }
 
@@ -279,9 +273,7 @@ THA4_DEV void gemm_stream(const char*& gw, char* ring, int& slot, const f32x4* a
         THA4_SCHED_FENCE();
       }
     }
-#ifndef THA4_ABLATE_BARRIER
-    __syncthreads();   // next slot landed (vmcnt(0)) and every wave is done reading this one
-#endif
+    THA4_HOOK_CHUNK_BARRIER();   // next slot landed (vmcnt(0)) and every wave is done reading this one
     slot = nslot;
   }
   gw += (size_t)NC * CHUNK;

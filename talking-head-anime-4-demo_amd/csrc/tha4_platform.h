@@ -23,13 +23,46 @@
 #define THA4_SCHED_FENCE()
 #endif
 
-// hazard hunt (tools/sin_cliff.py, never in a shipped build): drain one memory counter at every scheduling fence
-#if !defined(THA4_EMU) && defined(THA4_HUNT_FENCE_LGKM)
-#undef THA4_SCHED_FENCE
-#define THA4_SCHED_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#elif !defined(THA4_EMU) && defined(THA4_HUNT_FENCE_VM)
-#undef THA4_SCHED_FENCE
-#define THA4_SCHED_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// Timing ablations and hazard-hunt switches (every one of them produces WRONG results by construction) live in tha4_tuning.h and
+// exist in tuning builds only (-DTHA4_TUNING_BUILD, tools/sweep.py): the product build refuses them.  The kernels call the
+// THA4_HOOK_* macros below; without the tuning header each hook is the plain operation.
+#if defined(THA4_TUNING_BUILD)
+#include "tha4_tuning.h"
+#elif defined(THA4_ABLATE_MFMA) || defined(THA4_ABLATE_SIN) || defined(THA4_ABLATE_FETCH) || defined(THA4_ABLATE_BARRIER) ||       \
+    defined(THA4_ABLATE_ZLOAD) || defined(THA4_ABLATE_TILE_STAGE_VALU) || defined(THA4_ABLATE_TILE_WINDOW) ||                       \
+    defined(THA4_ABLATE_TILE_EPILOGUE) || defined(THA4_HUNT_FENCE_LGKM) || defined(THA4_HUNT_FENCE_VM) ||                            \
+    defined(THA4_HUNT_WAIT_BEFORE_STORES) || defined(THA4_HUNT_WAIT_TOP)
+#error "THA4_ABLATE_* / THA4_HUNT_* switches produce wrong results by construction: tuning builds only (-DTHA4_TUNING_BUILD, csrc/tha4_tuning.h)"
+#endif
+#ifndef THA4_HOOK_MFMA16H                  // the matrix instruction of the fp16 hi/lo contraction
+#define THA4_HOOK_MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+#ifndef THA4_HOOK_SIN_BYPASS               // 1: the SIREN sine returns its argument
+#define THA4_HOOK_SIN_BYPASS 0
+#endif
+#ifndef THA4_HOOK_FETCH                    // one weight piece global -> LDS
+#define THA4_HOOK_FETCH(stmt) stmt
+#endif
+#ifndef THA4_HOOK_CHUNK_BARRIER            // the per-chunk workgroup barrier of the streamed SIREN layers
+#define THA4_HOOK_CHUNK_BARRIER() __syncthreads()
+#endif
+#ifndef THA4_HOOK_ZLOAD                    // one z tap of the x2 upsample
+#define THA4_HOOK_ZLOAD(ptr, instead) (*reinterpret_cast<const f32x4*>(ptr))
+#endif
+#ifndef THA4_HOOK_BEFORE_STORES
+#define THA4_HOOK_BEFORE_STORES()
+#endif
+#ifndef THA4_HOOK_STRIP_TOP
+#define THA4_HOOK_STRIP_TOP()
+#endif
+#ifndef THA4_HOOK_TILE_STAGE_VALU_BYPASS   // 1: conv_tile_kernel writes the raw loaded bits into its window (no normalise / activate / split)
+#define THA4_HOOK_TILE_STAGE_VALU_BYPASS 0
+#endif
+#ifndef THA4_HOOK_TILE_WINDOW_BYPASS       // 1: conv_tile_kernel neither loads nor writes its window (weights + MFMA + barriers only)
+#define THA4_HOOK_TILE_WINDOW_BYPASS 0
+#endif
+#ifndef THA4_HOOK_TILE_EPILOGUE_BYPASS     // 1: conv_tile_kernel stores nothing
+#define THA4_HOOK_TILE_EPILOGUE_BYPASS 0
 #endif
 
 // wave-level ordering point for wave-PRIVATE LDS traffic (one lane writes, another lane of the same wave reads): the
@@ -100,11 +133,7 @@ THA4_DEV f32x4 mfma16(float a, float b, f32x4 c) {
 }
 // v_mfma_f32_16x16x32_f16: A[i][k] = lane 16*(k/8)+i element k%8, B[k][j] = lane 16*(k/8)+j element k%8
 THA4_DEV f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
-#ifdef THA4_ABLATE_MFMA   // timing ablation only (tools/sweep.py): results are wrong
-  c[0] += (float)a[0] * (float)b[0];
-  return c;
-#endif
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  return THA4_HOOK_MFMA16H(a, b, c);
 }
 THA4_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -141,6 +170,22 @@ THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {      // fibers run o
 THA4_DEV float lane_read(float v, int src_lane) { return emu::shfl(v, src_lane); }
 THA4_DEV int lane_pick(int v, int src_lane) { return (int)emu::shfl((float)v, src_lane); }       // |v| < 2^24: exact in fp32
 #endif
+
+// Two workgroups that share a CU run their stage -> barrier -> MFMA rhythm in phase when they start together (a single-round
+// grid), and then the matrix pipe idles in both staging phases.  A workgroup in an ODD slot of its CU (HW_REG_HW_ID.TG_ID, bits
+// 19:16: the workgroup's resource slot on the CU - co-resident workgroups hold different ones) waits `cycles` shader cycles before it
+// starts: the offset is preserved from then on (both run the same loop), so one stages while the other multiplies.
+THA4_DEV void dephase_odd_slot(int cycles) {
+#ifndef THA4_EMU
+  const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
+  if (tg & 1) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < (long long)cycles) __builtin_amdgcn_s_sleep(16);
+  }
+#else
+  (void)cycles;
+#endif
+}
 
 // fp16 hi/lo split of a PAIR of fp32 values: v = hi + lo with hi = fp16(v), lo = fp16(v - hi).  One v_cvt_pk_f16_f32 for both hi halves
 // and one v_fma_mix per lo half (the f16 -> f32 conversion of hi rides inside the FMA): 3-4 instructions per pair where the plain

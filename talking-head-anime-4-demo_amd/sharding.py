@@ -52,7 +52,10 @@ class FrameShardedStream:
         current, i.e. whatever it enqueues there is ordered after the arrival of the data and before the slot is
         overwritten ``ring_slots`` rounds later; a consumer that works on another stream must make that stream wait on
         an event it records in the callback and must be done before the slot comes round again.  ``run()`` then
-        returns None.  ``force_collective`` (tests) takes the gather path - side stream, ``dist.gather`` into views of the
+        returns None.  Without an exchange - one process, no process group, or ``gather=False`` - the consumer is served
+        just the same: every block this rank produces goes to ``on_chunk`` as it is finished (on the current stream; the
+        block is the frame function's own tensor), nothing is archived and ``run()`` returns None on every rank.
+        ``force_collective`` (tests) takes the gather path - side stream, ``dist.gather`` into views of the
         destination - even in a one-rank group: the only way a 1-GPU box executes RCCL at all (it refuses two ranks on one
         device)."""
         self.frame_fn = frame_fn
@@ -94,11 +97,12 @@ class FrameShardedStream:
         sizes = all_shard_sizes(self.total, self.world)
         rounds = max((s + self.chunk - 1) // self.chunk for s in sizes)
         streaming = self.gather and self.on_chunk is not None
+        local_streaming = (not self.gather) and self.on_chunk is not None      # no exchange: this rank's blocks go straight to the consumer
         ring = None
-        if streaming:
+        if streaming or local_streaming:
             if result is not None:
                 raise RuntimeError("a result buffer and on_chunk are exclusive: the stream is consumed, not archived")
-            if self.rank == 0:
+            if streaming and self.rank == 0:
                 ring = [self._empty(self.world * self.chunk) for _ in range(self.ring_slots)]
         elif result is None:
             result = self.allocate_result()
@@ -127,7 +131,10 @@ class FrameShardedStream:
                 raise RuntimeError(f"frame_fn returned {tuple(block.shape)} {block.dtype} for frames [{a},{b})")
             if not self.gather:
                 if block is not None:
-                    result[a - self.lo:b - self.lo] = block
+                    if local_streaming:
+                        self.on_chunk(a, b, block)
+                    else:
+                        result[a - self.lo:b - self.lo] = block
                 continue
             spans = [span(r, c) for r in range(self.world)]
             full_round = all(rb - ra == self.chunk for ra, rb in spans)

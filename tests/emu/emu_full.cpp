@@ -142,11 +142,14 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   std::vector<float> O((size_t)n * nb * opx * 16, 0.f);
   Mirror M;
   const bool splitk = pg == 0;
-  const bool tile16 = pg >= 40;             // conv_tile_kernel<tmb, pg - 40, ., 2>: sixteen waves, output blocks split over two wave halves
-  const bool point = pg >= 30 && !tile16;   // conv_point_kernel<tmb, pg - 30> (1x1, IN_DIRECT)
-  const bool small = pg >= 20 && !point && !tile16;    // conv_small_kernel<pg - 20> (tmb must be 1; `ksplit` carries units_per_q, 0 = planner's)
+  const bool tile4 = pg >= 50;              // conv_tile_kernel<tmb, pg - 50, ., 1, 4>: four-wave workgroups on half the pixel tile (two per CU)
+  const bool tile16 = pg >= 40 && !tile4;   // conv_tile_kernel<tmb, pg - 40, ., 2>: sixteen waves, output blocks split over two wave halves
+  const bool point = pg >= 30 && !tile16 && !tile4;   // conv_point_kernel<tmb, pg - 30> (1x1, IN_DIRECT)
+  const bool small = pg >= 20 && !point && !tile16 && !tile4;    // conv_small_kernel<pg - 20> (tmb must be 1; `ksplit` carries units_per_q, 0 = planner's)
   const bool tiled = pg >= 10 && !small && !point;    // conv_tile_kernel<tmb, pg - 10>
-  const int tpg = tile16 ? pg - 40 : pg - 10, spg = pg - 20, ppg = pg - 30;
+  const int tpg = tile4 ? pg - 50 : tile16 ? pg - 40 : pg - 10, spg = pg - 20, ppg = pg - 30;
+  const int tnw = tile4 ? 4 : 8;
+  if (tile4 && ksplit > 1) return -7;       // the four-wave form has no K split
   if (point && (kind != 0 || k != 1 || in_mode != IN_DIRECT || vec1)) return -6;
   const FusedSpec fused = g_fused;
   g_fused.set = false;
@@ -159,7 +162,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   }
   TileGeom tg0;
   if (tiled) {
-    tg0 = tile_geom(kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0)), th, tw, tpg, tmb, tw_log2, table_bytes);
+    tg0 = tile_geom(kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(0, 0)), th, tw, tpg, tmb, tw_log2, table_bytes, tnw);
     if (!tg0.ok) return -4;
   }
   const int tiles_per_class = point ? (th * tw + 64 * ppg - 1) / (64 * ppg) : small ? sp0.tiles : splitk ? th * tw / 16 : (tiled ? tg0.tiles : (th * tw / 16) / (4 * pg));
@@ -219,7 +222,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       a.units_per_q = ksplit > 0 ? ksplit : plan_small_conv(g, th, tw, nb, nq).units_per_q;
     }
     if (tiled) {
-      tg = tile_geom(g, th, tw, tpg, tmb, tw_log2, table_bytes);
+      tg = tile_geom(g, th, tw, tpg, tmb, tw_log2, table_bytes, tnw);
       if (!tg.ok) return -4;
       partial.assign((size_t)ksplit * n * mtiles * tg.tiles * tmb * 8 * tpg * 64 * 4, 0.f);
       a.partial = M.up(partial); a.ksplit = ksplit;
@@ -266,13 +269,21 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     RUN(1, 1) RUN(2, 1) RUN(4, 1) RUN(4, 2) RUN(2, 2)
 #undef RUN
 #define RUNT(TM, PGV)                                                                                       \
-  if (tiled && run_tmb == TM && tpg == PGV && (!tile16 || a.phase == 2)) {                                  \
+  if (tiled && !tile4 && run_tmb == TM && tpg == PGV && (!tile16 || a.phase == 2)) {                                  \
     if (in_mode == IN_DIRECT) THA4_RUN((conv_tile_kernel<TM, PGV, IN_DIRECT>), grid, kTileThreads, lds, a); \
     else if (in_mode == IN_UP2) THA4_RUN((conv_tile_kernel<TM, PGV, IN_UP2>), grid, kTileThreads, lds, a);  \
     else THA4_RUN((conv_tile_kernel<TM, PGV, IN_POOL2>), grid, kTileThreads, lds, a);                       \
   }
     RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 4) RUNT(1, 2) RUNT(1, 1)
 #undef RUNT
+#define RUNT4(TM, PGV)                                                                                         \
+  if (tiled && tile4 && run_tmb == TM && tpg == PGV) {                                                         \
+    if (in_mode == IN_DIRECT) THA4_RUN((conv_tile_kernel<TM, PGV, IN_DIRECT, 1, 4>), grid, 256, lds, a);       \
+    else if (in_mode == IN_UP2) THA4_RUN((conv_tile_kernel<TM, PGV, IN_UP2, 1, 4>), grid, 256, lds, a);        \
+    else THA4_RUN((conv_tile_kernel<TM, PGV, IN_POOL2, 1, 4>), grid, 256, lds, a);                             \
+  }
+    RUNT4(4, 4) RUNT4(4, 2) RUNT4(4, 1) RUNT4(2, 4) RUNT4(2, 2) RUNT4(2, 1)
+#undef RUNT4
 #define RUNT2(TM, PGV)                                                                                              \
   if (tiled && tile16 && a.phase != 2 && run_tmb == TM && tpg == PGV) {                                             \
     if (in_mode == IN_DIRECT) THA4_RUN((conv_tile_kernel<TM, PGV, IN_DIRECT, 2>), grid, kTileThreads * 2, lds, a);  \

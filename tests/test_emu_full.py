@@ -130,6 +130,17 @@ CASES = [
     (0, 3, 4, 41, 2, "silu", 16, 0, False, 32, 32, 64, True, False, False, True, (4, 1)),   # avg-pool 2x2 on load
     (0, 3, 2, 42, 0, "relu", 96, 27, True, 16, 16, 64, True, True, False, True, (4, 4)),    # split-K x4: phase 1 with 16 waves, phase 2 per block
     (0, 3, 2, 41, 0, "relu", 32, 0, False, 24, 24, 32, True, True, False, True, (3, 1)),    # ragged 24x24 map in 16x8 tiles
+    # conv_tile_kernel as FOUR-wave workgroups (pg = 50 + PG): half the pixel tile, <= 80 KiB of LDS, two workgroups per CU
+    (0, 3, 4, 54, 0, "silu", 40, 0, False, 32, 32, 64, True, True, False, True, (4, 1)),    # <4,4>: 16x16 tiles (18x18 window), phantom quad, residual
+    (0, 3, 2, 54, 0, "silu", 32, 16, False, 32, 32, 32, True, False, False, True, (5, 1)),  # <2,4>: 8x32 tiles, concat of two tensors
+    (0, 3, 4, 52, 0, "relu", 48, 0, False, 16, 32, 64, True, False, False, True, (4, 1)),   # <4,2>: 8x16 tiles
+    (0, 3, 2, 51, 0, "relu", 16, 12, True, 16, 16, 32, False, False, False, True, (3, 1)),  # <2,1>: 8x8 tiles, tensor ++ broadcast pose vector
+    (1, 4, 4, 51, 0, "relu", 16, 0, False, 32, 32, 64, False, False, False, True, (3, 1)),  # <4,1>: 4x4 stride 2 (18x18 window)
+    (2, 4, 2, 52, 0, "relu", 32, 0, False, 16, 16, 32, False, False, False, True, (4, 1)),  # <2,2>: convT 4x4 s2 (4 parity classes)
+    (0, 3, 2, 52, 1, "silu", 16, 0, False, 8, 16, 32, True, False, False, True, (4, 1)),    # nearest-up x2 on load
+    (0, 3, 4, 51, 2, "silu", 16, 0, False, 32, 32, 64, True, False, False, True, (4, 1)),   # avg-pool 2x2 on load
+    (0, 3, 2, 51, 0, "relu", 32, 0, False, 24, 24, 32, True, True, False, True, (3, 1)),    # ragged 24x24 map in 8x8 tiles
+    (0, 3, 4, 54, 0, "none", 4, 0, False, 48, 48, 64, True, False, False, False, (4, 1)),   # 4-channel image input, 48x48 (3x3 tiles of 16x16)
     # conv_small_kernel (pg = 20 + PG, tmb = 1): K split across the 8 waves of a workgroup, weights from L2 to registers
     # last field: (log2 tile width, units per K group; 0 = the planner's choice)
     (0, 3, 1, 21, 0, "relu", 96, 0, False, 16, 16, 32, True, True, False, True, (4, 0)),    # 3x3, 1x16 row tiles, 3 K groups -> tap split x4, residual
@@ -431,6 +442,7 @@ FUSED_CASES = [
     (12, 3, "silu", 64, 32, 32, 32, 32, 32, True, 4, (4, 1)),     # conv_tile_kernel<2,2> with the table in its prologue
     (11, 3, "relu", 48, 0, 16, 16, 32, 0, False, 2, (4, 2)),      # conv_tile_kernel K split (phase 1 builds the table, phase 2 skips it)
     (42, 3, "silu", 64, 32, 32, 32, 32, 32, True, 4, (4, 1)),     # conv_tile_kernel<2,2,.,2>: sixteen waves build the table (1024 threads)
+    (52, 3, "silu", 64, 32, 32, 32, 32, 32, True, 4, (4, 1)),     # conv_tile_kernel<2,2,.,1,4>: four waves (256 threads) build the table
     (32, 1, "silu", 96, 64, 16, 32, 32, 32, True, 4, (4, 0)),     # conv_point_kernel<2,2>: GroupNorm(32) over a concatenation + FiLM in its prologue
     (31, 1, "relu", 64, 0, 16, 16, 32, 0, False, 2, (4, 0)),      # conv_point_kernel<2,1>: InstanceNorm
 ]
@@ -460,7 +472,7 @@ def test_conv_with_fused_norm(lib, case):
     lib.emu_set_fused_norm(P(st0), tiles, P(st1), tiles * 2 if c1 else 0, cin, groups, C.c_float(1.0 / (h * w)), P(gamma), P(beta), P(f0), P(f1))
     tmb = 1 if 20 <= pg < 30 else 2
     out, stats = run_conv(lib, 0, k, tmb, pg, 0, act_in, x0, x1, False, None, None, weight, bias, None, None, 1, twl,
-                          extra if pg < 20 else (1 if pg >= 30 else 0))
+                          extra if pg < 20 or pg >= 50 else (1 if pg >= 30 else 0))
     assert np.abs(out - ref).max() < 5e-5, np.abs(out - ref).max()
     assert np.abs(stats[..., 0] - ref.sum(axis=(2, 3))).max() < 2e-3
 

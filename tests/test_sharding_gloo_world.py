@@ -1,0 +1,253 @@
+"""The N > 1 path at world sizes 3 and 8 on CPU (gloo): what the 8-GPU run of the driver relies on and no 1- or 2-rank test reaches -
+ragged tails over many ranks, `total < world` (most shards empty), the streaming root with the smallest ring (2 slots), one character
+instance per rank alternating by rank (BASELINE configs[3]), `bench.measure` at world 8, and `bench.py --gpus 8` launched exactly
+the way the driver launches it (`python -m torch.distributed.run ...`; the reference launches its own multi-process
+jobs the same way: src/tha4/shion/core/training/distrib/distributed_training_tasks.py:39-57) with gloo + a stub in place of RCCL +
+the poser (`--stub-gloo`: test harness, poses nothing)."""
+import argparse
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import tha4_amd  # noqa: F401
+from tha4_amd.sharding import FrameShardedStream, shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _frame(i, character=0):
+    g = torch.Generator().manual_seed(1000 + i + 100000 * character)
+    return torch.rand(2, 4, 4, generator=g)
+
+
+def _finish():
+    try:                                    # scaffolding only (results are already in the queue)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                       # noqa: BLE001
+        pass
+
+
+def _spawn(target, world, args, timeout=300):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=target, args=(r, world, os.path.join(d, "rendezvous")) + tuple(args) + (q,)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        for _ in range(world):
+            r = q.get(timeout=timeout)
+            res[r[0]] = r
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    return res
+
+
+def _init(rank, world, rendezvous):
+    os.environ["GLOO_SOCKET_IFNAME"] = os.environ.get("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
+
+
+def _gather_worker(rank, world, rendezvous, total, chunk, alternate, q):
+    _init(rank, world, rendezvous)
+    calls = []
+
+    def frame_fn(lo, hi):                    # one character instance per rank, alternating by rank (configs[3]) when `alternate`
+        calls.append((lo, hi))
+        return torch.stack([_frame(i, rank % 2 if alternate else 0) for i in range(lo, hi)])
+
+    s = FrameShardedStream(frame_fn, total, (2, 4, 4), torch.float32, torch.device("cpu"), chunk=chunk, gather=True)
+    out = s.run()
+    q.put((rank, s.local_range(), calls, None if out is None else out.clone()))
+    _finish()
+
+
+@pytest.mark.parametrize("world,total,chunk,alternate", [
+    (3, 11, 4, False),     # ragged: shards 4 / 4 / 3, one full round never happens (every round is a tail for somebody)
+    (3, 2, 4, False),      # total < world: rank 2 owns nothing and still takes part in the exchange
+    (3, 0, 4, False),      # an empty stream: no round at all
+    (8, 5, 2, False),      # total < world: three empty shards
+    (8, 67, 4, True),      # 8 ranks, shards of 9 / 8: two full rounds + a ragged tail; characters alternate by rank
+    (8, 64, 8, True),      # 8 ranks, exactly one full round
+    (8, 9, 1, False),      # chunk 1: rank 0 has two rounds, everybody else one
+])
+def test_gather_reassembles_stream_at_world_3_and_8(world, total, chunk, alternate):
+    res = _spawn(_gather_worker, world, (total, chunk, alternate))
+    full = res[0][3]
+    assert full.shape == (total, 2, 4, 4)
+    assert all(res[r][3] is None for r in range(1, world))
+    owner = {}
+    for r in range(world):
+        lo, hi = res[r][1]
+        assert (lo, hi) == shard_bounds(total, r, world)
+        done = [i for (a, b) in res[r][2] for i in range(a, b)]
+        assert done == list(range(lo, hi))                          # every frame once, in order, by the rank that owns it
+        assert all(b - a <= chunk for a, b in res[r][2])
+        for i in range(lo, hi):
+            owner[i] = r
+    assert sorted(owner) == list(range(total))
+    for i in range(total):                                          # frame i at row i, made by ITS rank's character instance
+        assert torch.equal(full[i], _frame(i, owner[i] % 2 if alternate else 0))
+
+
+def _stream_worker(rank, world, rendezvous, total, chunk, slots, q):
+    _init(rank, world, rendezvous)
+    got = []
+
+    def frame_fn(lo, hi):
+        return torch.stack([_frame(i, rank % 2) for i in range(lo, hi)])
+
+    def on_chunk(lo, hi, frames):
+        assert frames.shape == (hi - lo, 2, 4, 4)
+        got.append((lo, hi, frames.numpy().copy()))
+
+    s = FrameShardedStream(frame_fn, total, (2, 4, 4), torch.float32, torch.device("cpu"), chunk=chunk, gather=True,
+                           on_chunk=on_chunk, ring_slots=slots)
+    out = s.run()
+    q.put((rank, out is None, s.ring_bytes(), got))
+    _finish()
+
+
+@pytest.mark.parametrize("world,total,chunk,slots", [(3, 100, 4, 2), (8, 203, 4, 2), (8, 6, 4, 2), (8, 256, 8, 3)])
+def test_streaming_root_with_the_smallest_ring_at_world_3_and_8(world, total, chunk, slots):
+    res = _spawn(_stream_worker, world, (total, chunk, slots))
+    frame_bytes = 2 * 4 * 4 * 4
+    assert all(res[r][1] for r in range(world))                     # run() returns None on every rank
+    assert res[0][2] == slots * world * chunk * frame_bytes
+    assert all(res[r][3] == [] for r in range(1, world))            # only the root consumes
+    seen = {}
+    for lo, hi, frames in res[0][3]:
+        for i in range(lo, hi):
+            assert i not in seen
+            seen[i] = frames[i - lo]
+    assert sorted(seen) == list(range(total))
+    for r in range(world):
+        lo, hi = shard_bounds(total, r, world)
+        for i in range(lo, hi):
+            assert (seen[i] == _frame(i, r % 2).numpy()).all()
+
+
+def test_on_chunk_is_honoured_without_an_exchange():
+    """One process / no process group: the consumer still gets every block and nothing is archived (round-3 advisor finding:
+    the callback used to be ignored silently and run() allocated the whole stream)."""
+    got = []
+    s = FrameShardedStream(lambda lo, hi: torch.stack([_frame(i) for i in range(lo, hi)]), 7, (2, 4, 4), torch.float32,
+                           torch.device("cpu"), chunk=3, on_chunk=lambda lo, hi, fr: got.append((lo, hi, fr.clone())))
+    assert s.run() is None
+    assert [(a, b) for a, b, _ in got] == [(0, 3), (3, 6), (6, 7)]
+    for a, b, fr in got:
+        for i in range(a, b):
+            assert torch.equal(fr[i - a], _frame(i))
+    with pytest.raises(RuntimeError):
+        s.run(torch.empty(7, 2, 4, 4))                              # a result buffer and a consumer are exclusive here too
+
+
+def _local_stream_worker(rank, world, rendezvous, total, chunk, q):
+    _init(rank, world, rendezvous)
+    got = []
+    s = FrameShardedStream(lambda lo, hi: torch.stack([_frame(i) for i in range(lo, hi)]), total, (2, 4, 4), torch.float32,
+                           torch.device("cpu"), chunk=chunk, gather=False, on_chunk=lambda lo, hi, fr: got.append((lo, hi)))
+    out = s.run()
+    q.put((rank, out is None, got))
+    _finish()
+
+
+def test_on_chunk_without_gather_serves_each_rank_its_own_blocks():
+    res = _spawn(_local_stream_worker, 3, (10, 2))
+    for r in range(3):
+        lo, hi = shard_bounds(10, r, 3)
+        assert res[r][1]
+        assert [i for a, b in res[r][2] for i in range(a, b)] == list(range(lo, hi))
+
+
+class _StubWork:
+    def __init__(self, rank, B):
+        self.rank, self.B, self.calls = rank, B, []
+
+    def step(self, i, out=None):
+        self.calls.append(i)
+        if out is None:
+            out = torch.empty(self.B, 4, 512, 512)
+        out.fill_(1000.0 * self.rank + i)
+        return out
+
+
+def _measure_worker(rank, world, rendezvous, K, W, B, chunk, streaming, q):
+    sys.path.insert(0, ROOT)
+    import bench
+    _init(rank, world, rendezvous)
+    work = _StubWork(rank, B)
+    args = argparse.Namespace(no_gather=False, rgba8_gather=False, gather_chunk=chunk, settle_seconds=0.0)
+    if streaming:
+        elapsed = bench.measure(work, args, torch.device("cpu"), rank, world, K, W, B, dist)
+        q.put((rank, elapsed, work.calls, getattr(work, "delivered", None), None))
+    else:
+        elapsed, frames = bench.measure(work, args, torch.device("cpu"), rank, world, K, W, B, dist, return_frames=True)
+        rows = None if frames is None else frames[:, 0, 0, 0].clone()
+        q.put((rank, elapsed, work.calls, None, rows))
+    _finish()
+
+
+@pytest.mark.parametrize("world,K,W,B,chunk,streaming", [(8, 3, 1, 1, None, False), (8, 4, 1, 2, 4, True), (3, 5, 2, 1, 2, False)])
+def test_bench_measure_at_world_3_and_8(world, K, W, B, chunk, streaming):
+    res = _spawn(_measure_worker, world, (K, W, B, chunk, streaming), timeout=400)
+    for r in range(world):
+        _, elapsed, calls, _, _ = res[r]
+        assert elapsed > 0
+        assert [i for i in calls if i >= W] == list(range(W, W + K))
+    if streaming:
+        assert res[0][3] == world * K * B
+    else:
+        rows = res[0][4]
+        assert rows.shape[0] == world * K * B
+        for f in range(world * K * B):
+            r, j = divmod(f, K * B)
+            assert rows[f].item() == 1000.0 * r + W + j // B
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("extra", [[], ["--batch", "2", "--rgba8-gather"], ["--no-gather"]])
+def test_bench_py_gpus_8_launched_like_the_driver_under_gloo(extra):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8
+    --steps K --warmup W` end to end: rank / world from the environment, process group, rehearsal, timed sharded stream with the
+    streaming root, maximum over ranks, ONE JSON line from rank 0 - with gloo and a stub poser (`--stub-gloo`)."""
+    K, W = 4, 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(K), "--warmup", str(W),
+           "--settle-seconds", "0", "--stub-gloo"] + extra
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                          # ONE line, from rank 0
+    j = json.loads(lines[0])
+    B = 2 if "--batch" in extra else 1
+    assert j["n_gpus"] == 8 and j["steps"] == K and j["warmup"] == W and j["data"] == "stub" and j["scaling"] == "weak"
+    assert j["config"]["frames_per_gpu"] == K * B and j["config"]["parallelism"] == "frame-parallel x8"
+    assert abs(j["value"] - 8 * K * B / (j["ms_per_step"] * K / 1e3)) <= 0.02 * j["value"]        # whole-job rate from the max-over-ranks clock
+    if "--no-gather" in extra:
+        assert j["config"]["gather"] is False
+    else:
+        assert j["config"]["delivered"] == 8 * K * B                # the root's consumer saw every frame of every rank once
+        assert j["config"]["gather"] == ("rgba8" if "--rgba8-gather" in extra else "fp32")
+
+
+def test_bench_py_refuses_a_rank_count_that_differs_from_gpus():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub-gloo"], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "needs torch.distributed.run" in (r.stderr + r.stdout)

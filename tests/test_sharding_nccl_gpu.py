@@ -73,6 +73,27 @@ def test_two_rank_rccl_gather_real_poser(total, chunk):
     assert res == {0: True, 1: True}
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 3, reason="needs >= 3 GPUs in the lease (the 8-GPU node); tests/test_sharding_gloo_world.py covers world 3 / 8 on CPU")
+@pytest.mark.parametrize("total,chunk", [(19, 2), (5, 4)])
+def test_all_visible_gpus_rccl_gather_real_poser(total, chunk):
+    """Every GPU of the lease as one rank (up to 8): ragged shards, and with total = 5 on 8 GPUs three ranks own no frame at all."""
+    import torch.multiprocessing as mp
+    world = min(8, torch.cuda.device_count())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, chunk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == {r: True for r in range(world)}
+
+
 def _solo_worker(port, q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -15,7 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "talking-head-anime-4-demo_amd", "csrc")
 OUT = os.path.join(ROOT, "build_variants")
 
-NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DTHA4_NO_PACKED_FP32=1"]     # = tha4_amd._build.DEVICE_FLAGS
+import importlib.util                                  # the product's own device flags (no packed fp32): ONE definition, tha4_amd/_build.py
+_spec = importlib.util.spec_from_file_location("_tha4_build", os.path.join(ROOT, "talking-head-anime-4-demo_amd", "_build.py"))
+_bld = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bld)
+NOPK = list(_bld.DEVICE_FLAGS)
+TUNE = ["-DTHA4_TUNING_BUILD"]                          # ablations / hazard-hunt switches live in csrc/tha4_tuning.h: tuning builds only
 VARIANTS = {
     "default": [],
     "wait0": ["-mllvm", "-amdgpu-waitcnt-forcezero=1"],                              # the shipped source with every memory wait forced to zero (tools/compare_libs.py)
@@ -43,6 +48,10 @@ VARIANTS = {
     "ab_zload": ["-DTHA4_ABLATE_ZLOAD"], "ab_mfma_sin": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN"],
     "ab_fetch_barrier": ["-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER"],
     "ab_all": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER", "-DTHA4_ABLATE_ZLOAD"],
+    # ---- conv_tile_kernel ablations (round 4; results are wrong): what pre-staged operands / async window fills could buy at most ----
+    "abt_valu": ["-DTHA4_ABLATE_TILE_STAGE_VALU"], "abt_window": ["-DTHA4_ABLATE_TILE_WINDOW"], "abt_epi": ["-DTHA4_ABLATE_TILE_EPILOGUE"],
+    "abt_window_epi": ["-DTHA4_ABLATE_TILE_WINDOW", "-DTHA4_ABLATE_TILE_EPILOGUE"],
+    "abt_all": ["-DTHA4_ABLATE_TILE_WINDOW", "-DTHA4_ABLATE_TILE_EPILOGUE", "-DTHA4_ABLATE_MFMA"],
     # ---- level 1 with independent workgroups sharing a CU (half chunks of 12 KiB: 72 KiB of LDS per 64-pixel workgroup -> two per CU) ----
     "l1w4": ["-DTHA4_L116_CFG=4,1,1,1,1,2"],       # 4 waves / workgroup: each SIMD hosts one wave of each of two workgroups
     "l1w8x2": ["-DTHA4_L116_CFG=4,2,1,1,1,2"],     # 8 waves / workgroup (rows split over two waves): four waves per SIMD
@@ -71,6 +80,8 @@ def build():
     for name, flags in VARIANTS.items():            # all variants at once: one hipcc process each
         out = os.path.join(OUT, f"libtha4_{name}.so")
         base = [] if "-DTHA4_PACKED_FP32_BUILD" in flags else NOPK      # variants are relative to the shipped flags (no packed fp32)
+        if any("THA4_ABLATE_" in f or "THA4_HUNT_" in f for f in flags):
+            base = base + TUNE
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, "-I",
                os.path.join(ROOT, "include")] + base + flags + [os.path.join(CSRC, "tha4_capi.hip"), "-o", out]
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
