@@ -86,6 +86,25 @@ def newest_profile(pattern):
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
+def rocprof_kernel_avgs(pattern, names):
+    """Average launch durations (ms) from the newest committed `rocprofv3 --kernel-trace --stats` summary under profiles/, for the
+    kernels whose name contains one of `names` ({label: substring}) - quoted NEXT to the in-bench HIP-event times, which carry the
+    event overhead (their sum exceeds the step)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None
+    import csv
+    out = {}
+    try:
+        for row in csv.DictReader(open(files[-1])):
+            for label, sub in names.items():
+                if sub in row.get("Name", ""):
+                    out[label] = round(float(row["AverageNs"]) / 1e6, 5)
+    except (OSError, KeyError, ValueError):
+        return None
+    return {"file": os.path.relpath(files[-1], ROOT), "avg_ms": out} if out else None
+
+
 def kernel_traffic_bytes(prof, name):
     k = (prof or {}).get("kernels", {}).get(name)
     if not k:
@@ -114,11 +133,12 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(run_frame, what, budget_s, max_frames):
-    """The CPU path timed beside the GPU path: the oracle's torch-functional restatement of the
-    reference (the same ATen ops the reference dispatches), fp32, `torch.set_num_threads(k)` for k in {1, 8, 32, all
+def cpu_baseline(run_frame, what, budget_s, max_frames, kind="port"):
+    """The CPU path timed beside the GPU path, fp32, `torch.set_num_threads(k)` for k in {1, 8, 32, all
     physical cores}; the BEST k is the reported baseline (too many threads is slower for these small convolutions).
-    Bounded sample: ~budget_s of CPU work in total."""
+    `kind` = "reference": the UNMODIFIED reference (oracle/reference_runner.py, wherever /root/reference exists - the build
+    container); "port": the oracle's torch-functional restatement (the same ATen ops the reference dispatches; what the GPU box,
+    which has no /root/reference, can run).  Bounded sample: ~budget_s of CPU work in total."""
     phys = physical_cores()
     ks = sorted({k for k in (1, 8, 32, phys) if k <= max(phys, 1)})
     prev = torch.get_num_threads()
@@ -139,7 +159,7 @@ def cpu_baseline(run_frame, what, budget_s, max_frames):
     finally:
         torch.set_num_threads(prev)
     best = max(by, key=lambda k: by[k]["fps"])
-    return {"value": by[best]["fps"], "unit": "frames/s", "cores": best, "kind": "port",
+    return {"value": by[best]["fps"], "unit": "frames/s", "cores": best, "kind": kind,
             "sample": f"{what}; {by[best]['frames']} frames at the best thread count ({sum(v['seconds'] for v in by.values()):.0f} s of CPU work over thread counts {ks})",
             "ms_per_frame": by[best]["ms_per_frame"], "by_threads": {str(k): v for k, v in by.items()},
             "cpu_model": cpu_model_string(), "physical_cores": phys, "logical_cpus": os.cpu_count()}
@@ -215,10 +235,11 @@ def timed_steps(work, lo, hi):
     return out
 
 
-def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False):
+def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fresh=True):
     """Settle, W warm-up steps, then EXACTLY K timed steps between barriers (N > 1: with the gather of the finished frames to
     rank 0 inside the timed region, after an untimed rehearsal of the exchange).  Returns this rank's elapsed seconds (and, for
-    the tests, what rank 0 gathered).  Device-agnostic: tests/test_bench_stream_gloo.py runs it on CPU tensors over gloo."""
+    the tests, what rank 0 gathered).  `fresh=False` (the `repeats` of the JSON line) times the same K steps again without
+    settle / warm-up / rehearsal.  Device-agnostic: tests/test_bench_stream_gloo.py runs it on CPU tensors over gloo."""
     cuda = dev.type == "cuda"
     gather = world > 1 and not args.no_gather
     frames = None
@@ -233,15 +254,16 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False):
 
     settle_steps = 0
     with torch.no_grad():
-        if args.settle_seconds > 0:                       # same frames as the warm-up steps, not counted anywhere
+        if fresh and args.settle_seconds > 0:             # same frames as the warm-up steps, not counted anywhere
             t_end = time.perf_counter() + args.settle_seconds
             while time.perf_counter() < t_end:
                 timed_steps(work, 0, max(1, min(W, 8)))
                 settle_steps += max(1, min(W, 8))
                 if cuda:
                     torch.cuda.synchronize(dev)
-        work.settle_steps = settle_steps
-        timed_steps(work, 0, W)
+        if fresh:
+            work.settle_steps = settle_steps
+            timed_steps(work, 0, W)
         if gather:
             want_chunk = args.gather_chunk if args.gather_chunk is not None else min(32, max(1, K * B // 5))
             chunk = max(B, want_chunk // B * B)
@@ -266,7 +288,8 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False):
                     step(0, out=blk[f:f + B])
                 return blk
 
-            FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
+            if fresh:
+                FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
             if return_frames:              # tests: archive the whole (short) stream on rank 0
                 stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
                 gathered = stream.allocate_result()       # allocated outside the timed region
@@ -327,6 +350,8 @@ def main():
     ap.add_argument("--settle-seconds", type=float, default=0.3,
                     help="untimed frames posed for this long BEFORE the W warm-up steps, so that a short run (--steps 20 --warmup 5) "
                          "is timed at the GPU's steady clocks like the stream it samples (0 = none)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="time the same K steps this many more times after the region that gives `value`; the line reports median / min / max")
     ap.add_argument("--stub-gloo", action="store_true",
                     help="TEST HARNESS ONLY (tests/test_bench_launch_gloo.py): run the multi-rank driver logic - torchrun ranks, sharding, gather "
                          "to rank 0, barriers, max-over-ranks timing, the JSON line - over gloo on CPU tensors with a stub that POSES NOTHING "
@@ -363,6 +388,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # `value` is the region above; the SAME K steps are timed `--repeats` more times so that a short region (20 steps of the student
+    # stream = 2.5 ms) carries its own spread.  Same barriers, maximum over ranks per repeat.
+    rep_fps = []
+    for _ in range(max(0, args.repeats)):
+        e = measure(work, args, dev, rank, world, K, W, B, dist, fresh=False)
+        if world > 1:
+            t = torch.tensor([e], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        rep_fps.append(K * B * world / e)
 
     if rank == 0:
         fps = K * B * world / elapsed
@@ -371,7 +406,10 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE, "per_gpu_fps": round(fps / world, 2), "settle_seconds": args.settle_seconds,
-            "settle_frames": getattr(work, "settle_steps", 0) * B}
+            "settle_frames": getattr(work, "settle_steps", 0) * B,
+            "repeats": ({"n": len(rep_fps), "what": f"the same {K} timed steps again, after `value` (frames/s of each region)",
+                         "median": round(float(np.median(rep_fps)), 2), "min": round(min(rep_fps), 2), "max": round(max(rep_fps), 2),
+                         "all": [round(v, 2) for v in rep_fps]} if rep_fps else None)}
         par = {"frames_per_gpu": K * B, "batch": B, "parallelism": f"frame-parallel x{world}",
                "gather": ("rgba8 (display epilogue fused into the composing kernel)" if args.rgba8_gather else "fp32") if gather else False}
         if gather:
@@ -481,6 +519,10 @@ def student_extras(args, work, dev, world, fps, K, W, B):
                 "traffic_unit": f"bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 PMC passes in {prof_file}",
                 "traffic_per_frame": (sum(kernel_traffic_bytes(prof, n) or 0 for n in prof.get("kernels", {})) if (B == 1 and prof) else None),
                 "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                "kernel_ms_what": "HIP events on the launch stream inside the C ABI (they add ~3-4 us per kernel: a conservative frac)",
+                "kernel_ms_rocprof": rocprof_kernel_avgs("r*_student_b1_kernel_stats.csv" if B == 1 else "r*_student_b32_kernel_stats.csv",
+                                                         {"front (level0 + face, one launch)": "front16_kernel", "level1": "level1_16_kernel",
+                                                          "level2": "level2_16p_kernel"}),
                 "frame_event_ms": round(whole / nprof, 4),
                 "whole_frame_achieved_tflops": round(fps / world * GFLOP_FRAME / 1e3, 3),
                 "whole_frame_frac": round(fps / world * GFLOP_FRAME / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
@@ -552,12 +594,19 @@ def student_extras(args, work, dev, world, fps, K, W, B):
                                  "unfused_fps": round(unfused, 2),
                                  "unfused_what": "pose (fp32 frame) -> tha4_display_rgba8 as a second kernel -> the same D2H (round 2's path)"}
     if world == 1 and args.cpu_seconds > 0:
-        from oracle import student_oracle as so          # cpu_baseline leg only (oracle/ is test infrastructure)
+        from oracle import reference_runner as rr        # cpu_baseline leg only (oracle/ is test infrastructure)
+        from oracle import student_oracle as so
         w, image_np, poses_cpu = work.w, work.image_np, work.poses_cpu
-        out["cpu_baseline"] = cpu_baseline(lambda i: so.student_forward_torch(w, image_np, poses_cpu[i % poses_cpu.shape[0]].numpy(), "float32"),
-                                           f"{work.character} student stream, oracle.student_forward_torch fp32", args.cpu_seconds, 48)
-        out["cpu_baseline"]["port_fidelity"] = ("the oracle dispatches the same ATen ops as the reference and equals the unmodified reference bit for bit on "
-                                                "every committed fixture (tests/test_oracle_golden.py; /root/reference does not exist on the GPU box)")
+        if rr.available():                               # the unmodified reference itself (build container; never on the GPU box)
+            ref_run, _ = rr.student_runner(work.character)
+            out["cpu_baseline"] = cpu_baseline(lambda i: ref_run(poses_cpu[i % poses_cpu.shape[0]].numpy()),
+                                               f"{work.character} student stream, the unmodified reference (tha4.poser.modes.mode_14 on CPU, fp32)",
+                                               args.cpu_seconds, 48, kind="reference")
+        else:
+            out["cpu_baseline"] = cpu_baseline(lambda i: so.student_forward_torch(w, image_np, poses_cpu[i % poses_cpu.shape[0]].numpy(), "float32"),
+                                               f"{work.character} student stream, oracle.student_forward_torch fp32", args.cpu_seconds, 48)
+            out["cpu_baseline"]["port_fidelity"] = ("the oracle dispatches the same ATen ops as the reference and equals the unmodified reference bit for bit on "
+                                                    "every committed fixture (tests/test_oracle_golden.py; /root/reference does not exist on the GPU box)")
     if single and args.full_frames > 0:
         try:      # secondary: configs[2] in the same process (the headline must not depend on it)
             poser.free()
@@ -640,11 +689,18 @@ def full_extras(args, work, dev, world, fps, B):
         out["steady_and_cold"] = measure_full_b1(other, dev, max(10, min(50, args.steps or 50)))
     if world == 1 and args.cpu_seconds > 0:
         from oracle import full_oracle as fo             # cpu_baseline leg only
+        from oracle import reference_runner as rr
         w = synthetic.synth_full_weights()
         poses = make_poses(4, seed=77).numpy()
         img = work.image_np
-        out["cpu_baseline"] = cpu_baseline(lambda i: fo.full_forward_torch(w, img, poses[i % 4], "float32"),
-                                           "cold frames of the full model, oracle.full_forward_torch fp32, synthetic weights", args.cpu_seconds, 12)
+        if rr.available():                               # the unmodified reference modules with the synthetic state_dicts (build container only)
+            ref_run = rr.full_runner(w)
+            out["cpu_baseline"] = cpu_baseline(lambda i: ref_run(img, poses[i % 4]),
+                                               "cold frames of the full model, the unmodified reference (GeneralPoser02 + mode_07 protocol on CPU, fp32), "
+                                               "synthetic weights", args.cpu_seconds, 12, kind="reference")
+        else:
+            out["cpu_baseline"] = cpu_baseline(lambda i: fo.full_forward_torch(w, img, poses[i % 4], "float32"),
+                                               "cold frames of the full model, oracle.full_forward_torch fp32, synthetic weights", args.cpu_seconds, 12)
     return out
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THA4_ABI_VERSION 3
+#define THA4_ABI_VERSION 4
 
 typedef enum tha4_status {
   THA4_OK = 0,
@@ -194,9 +194,21 @@ int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image
 /* Same with the number of networks: 5 = mode_07; 3 = the reference's mode_12 (src/tha4/poser/modes/mode_12.py:169-202,
  * the teacher of the face-morpher distillation, siren_face_morpher_00_trainer.py:23-26): eyebrow_decomposer ->
  * eyebrow_morphing_combiner -> face_morpher only (weights->tensors[3], [4] are ignored).  Such a handle produces
- * outputs 11..32 of the list below (mode_12's list = face_morpher 8 + combiner 8 + decomposer 6, mode_12.py:92-97). */
+ * outputs 11..32 of the list below (mode_12's list = face_morpher 8 + combiner 8 + decomposer 6, mode_12.py:92-97).
+ *
+ * flags (ABI v4):
+ *   THA4_FULL_EXACT_FP32  plan EVERY convolution on the exact-fp32 kernels (v_mfma_f32_16x16x4_f32 on fp32 operands: fp32's own
+ *                         range, no fp16 hi/lo staging) and every normalisation through the finalize kernel.  The default plan
+ *                         (0) multiplies fp16 hi/lo operand halves (22 significant bits, |operand| <= 65504 after normalise +
+ *                         activate; tha4_full_numeric_status reports a violation): ~2.5-3x faster, within 1e-3 of this plan on
+ *                         every tested parameter set.  This is the plan to re-create the handle with when THA4_ERR_NUMERIC_RANGE
+ *                         is reported for weights / inputs that are legitimate in fp32 (the reference computes in plain fp32,
+ *                         mode_07.py:137-315 loads whatever the .pt files hold). */
+#define THA4_FULL_EXACT_FP32 1u
 int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
-                        int num_networks, tha4_full** out);
+                        int num_networks, uint32_t flags, tha4_full** out);
+/* The flags the handle was created with. */
+int tha4_full_flags(const tha4_full* h);
 
 /* Replaces: GeneralPoser02.get_posing_outputs -> FiveStepPoserComputationProtocol (mode_07.py:54-134).
  *   outputs_dev[i]  device pointer for output i of the reference's 33-entry list (order mode_07.py:126-132:

@@ -142,8 +142,11 @@ THA4_DEV int fused_table_floats(const ConvArgs& a) {      // 2 x padded concaten
 // NW = 4 (round 4): FOUR pixel-slot waves per workgroup = half the pixel tile (64 PG positions), at most 80 KiB of LDS and the register
 // budget of two waves per SIMD, so that TWO workgroups share a CU: one workgroup's prologue (norm table, first fetch, first window),
 // staging phases and epilogue (stores, statistics) run under the other one's MFMAs instead of leaving the matrix pipe idle - the
-// lock-step of the 8-wave form has every wave of the CU in the same phase.  A workgroup in an odd slot of its CU (HW_ID.TG_ID) starts
-// `dephase_cycles` late, so that a single-round grid (batch 1) does not keep the two in phase.
+// lock-step of the 8-wave form has every wave of the CU in the same phase.  It needs the staging phase at raised issue priority
+// (THA4_PHASE_PRIO: a VALU wave only hides under a partner's MFMAs at s_setprio 1, profiles/r03_machine_model.md) and pays on grids of
+// several rounds, where the workgroups of a CU drift out of phase by themselves: measured +4-7 % at batch 8 for the <4,4> / <4,2> /
+// <2,4> classes, nothing at batch 1 where the two workgroups of a CU start and end together - a start delay of the one in the odd
+// slot (HW_ID.TG_ID, 3k-40k cycles) measured neutral to negative and is not in the code (profiles/r04_full_conv_tile_reading.md).
 template <int TMB, int PG, int INMODE, int MSW = 1, int NW = kTileWaves>
 __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2) conv_tile_kernel(ConvArgs a) {      // (threads, waves per SIMD)
   static_assert(MSW == 1 || (MSW == 2 && TMB % 2 == 0), "the block split needs an even block count");
@@ -353,7 +356,6 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
 #define THA4_CSTAMP()
 #endif
   THA4_CSTAMP();                                           // 0: entry (after index set-up)
-  if (NW == kTileWavesHalf && a.dephase_cycles > 0) dephase_odd_slot(a.dephase_cycles);
   int slot = 0, chunk = q_begin * ntc;
   const int nchunks = q_end * ntc;
   const bool reduce_phase = a.phase == 2;
@@ -497,6 +499,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
       }
   }
 
+  THA4_CSTAMP();                                           // K loop (and split-K reduction) done
   // ---- epilogue: 1/scale, bias, residual, activation, store, deterministic per-tile statistics ----
   const int out_px = a.out_h * a.out_w;
   float ssum[TMBW][4], ssq[TMBW][4];
@@ -537,17 +540,15 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
       for (int j = 0; j < 4; ++j) { ssum[b][j] += v[j]; ssq[b][j] = fmaf(v[j], v[j], ssq[b][j]); }
     }
   }
+  THA4_CSTAMP();                                           // output stores issued
   if (a.stats) {
 #pragma unroll
     for (int b = 0; b < TMBW; ++b)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s = ssum[b][j], q = ssq[b][j];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
-          s += lane_read(s, lane ^ m);
-          q += lane_read(q, lane ^ m);
-        }
+        s = row16_sum(s, lane);
+        q = row16_sum(q, lane);
         if (p == 0) {
           red[((pw * TMB + mh * TMBW + b) * 16 + g4 + j) * 2 + 0] = s;
           red[((pw * TMB + mh * TMBW + b) * 16 + g4 + j) * 2 + 1] = q;
@@ -565,6 +566,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
       dst[1] = q;
     }
   }
+  THA4_CSTAMP();                                           // statistics written: end of the kernel
 }
 
 }  // namespace tha4

@@ -231,11 +231,8 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s = ssum[b][j], q = ssq[b][j];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
-          s += lane_read(s, lane ^ m);
-          q += lane_read(q, lane ^ m);
-        }
+        s = row16_sum(s, lane);
+        q = row16_sum(q, lane);
         if (p == 0) {
           red[((wave * TMB + b) * 16 + g4 + j) * 2 + 0] = s;
           red[((wave * TMB + b) * 16 + g4 + j) * 2 + 1] = q;

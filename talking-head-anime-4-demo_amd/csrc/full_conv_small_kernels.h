@@ -379,11 +379,8 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float s = ssum[j], q = ssq[j];
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) {
-        s += lane_read(s, lane ^ m);
-        q += lane_read(q, lane ^ m);
-      }
+      s = row16_sum(s, lane);
+      q = row16_sum(q, lane);
       if (p == 0) {
         float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
         dst[0] = s;

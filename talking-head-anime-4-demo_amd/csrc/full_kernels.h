@@ -98,7 +98,6 @@ struct ConvArgs {
   int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue
   FusedNorm fnorm;       // conv_tile_kernel / conv_small_kernel: normalisation of the tensor sources computed in the prologue
   int units_per_q;       // conv_small_kernel: tap ranges per K group (1, 2, 4 or 8: spreads few K groups over the 8 waves)
-  int dephase_cycles;    // conv_tile_kernel<..., NW = 4>: start delay of a workgroup in an odd slot of its CU (0: none)
 #ifdef THA4_PHASE_TIMING
   long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
 #endif
@@ -383,11 +382,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s = ssum[b][j], q = ssq[b][j];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
-          s += lane_read(s, lane ^ m);
-          q += lane_read(q, lane ^ m);
-        }
+        s = row16_sum(s, lane);
+        q = row16_sum(q, lane);
         if (p == 0) {
           red[((wave * TMB + b) * 16 + g4 + j) * 2 + 0] = s;
           red[((wave * TMB + b) * 16 + g4 + j) * 2 + 1] = q;
@@ -541,11 +537,8 @@ __global__ void __launch_bounds__(256) conv_splitk_kernel(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float su = v[j], sq = v[j] * v[j];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
-          su += lane_read(su, lane ^ m);
-          sq += lane_read(sq, lane ^ m);
-        }
+        su = row16_sum(su, lane);
+        sq = row16_sum(sq, lane);
         if (p == 0) {
           float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
           dst[0] = su;

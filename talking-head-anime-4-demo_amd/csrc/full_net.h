@@ -25,7 +25,7 @@
 #define THA4_TILE16_DEFAULT 0      // conv_tile_kernel classes that run with sixteen waves (bit mask, see tile16_mask)
 #endif
 #ifndef THA4_TILE_NW4_DEFAULT
-#define THA4_TILE_NW4_DEFAULT 0     // conv_tile_kernel classes that run as four-wave workgroups, two per CU (bit mask, see nw4_mask)
+#define THA4_TILE_NW4_DEFAULT 50    // conv_tile_kernel classes that run as four-wave workgroups, two per CU (bit mask, see nw4_mask): <4,4> <4,2> <2,4>
 #endif
 #include "full_conv_point_kernels.h"
 #include "full_kernels.h"
@@ -68,6 +68,10 @@ class FullModel {
   std::string error;
   int max_batch = 1;
   int sel_index = 2;       // eyebrow_morphed_image_index (mode_07.py:275)
+  // THA4_FULL_EXACT_FP32 (round 4): every convolution on the exact-fp32 kernels (conv_mfma_kernel / conv_splitk_kernel:
+  // v_mfma_f32_16x16x4_f32 on fp32 operands, no fp16 hi/lo staging and therefore no 65504 operand limit), every normalisation
+  // through norm_finalize_kernel.  The plan a caller falls back to when the numeric-range guard of the default plan trips.
+  bool exact_fp32 = false;
 
   // ---- arenas -------------------------------------------------------------------------------
   std::vector<char> host_params;     // packed parameters, uploaded once
@@ -313,7 +317,7 @@ class FullModel {
     for (auto& sx : srcs)
       if (!sx.vector) { ctab += sx.t.cb * 16; if (sx.pend.fused) fpend = &sx.pend; }
     const size_t table_bytes = fpend ? (size_t)2 * ctab * sizeof(float) : 0;
-    if ((kind != K_SAME1 || tune_env("THA4_TILE_1X1")) && !tune_env("THA4_NO_TILE_CONV")) {
+    if ((kind != K_SAME1 || tune_env("THA4_TILE_1X1")) && !tune_env("THA4_NO_TILE_CONV") && !exact_fp32) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
       plan = plan_tile_conv(g0, th, tw, tmb, mtiles, nq, 256, max_batch);
       if (plan.ok && table_bytes && !tile_geom(g0, th, tw, plan.pg, tmb, plan.geom.tw_log2, table_bytes).ok) plan.ok = false;
@@ -331,7 +335,7 @@ class FullModel {
     const int max1x1 = tune_env("THA4_SMALL_1X1_MAX_PX") ? std::atoi(tune_env("THA4_SMALL_1X1_MAX_PX")) : 32 * 32;
     bool point = false;
     PointPlan pp;
-    if (kind == K_SAME1 && in_mode == IN_DIRECT && tile_px > max1x1 && !tiled && !tune_env("THA4_NO_POINT_CONV") &&
+    if (kind == K_SAME1 && in_mode == IN_DIRECT && tile_px > max1x1 && !tiled && !tune_env("THA4_NO_POINT_CONV") && !exact_fp32 &&
         (!residual || res_mode == IN_DIRECT) && point_act_supported(act_in)) {
       bool tensors = true;
       for (auto& sx : srcs) tensors = tensors && !sx.vector;
@@ -343,7 +347,7 @@ class FullModel {
     // the waves of one workgroup, ONE launch
     bool small = false;
     SmallPlan sp;
-    if (!point) {
+    if (!point && !exact_fp32) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
       // where it wins (per-layer breakdown in profiles/r02_full_b1_reading.md): 3x3 / 1x1 / transposed-conv classes on maps
       // the tile plan would split over two launches, not the 16-tap stride-2 convolutions (their 108-pixel window per 16
@@ -369,10 +373,15 @@ class FullModel {
     if (tiled && plan.ksplit == 1 && nw4_class(tmb, plan.pg)) {
       const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
       float best_eff = 0.f;
+      int tiles4 = 0;
       for (int twl : {4, 3, 5}) {
         const TileGeom t = tile_geom(g0, th, tw, plan.pg, tmb, twl, table_bytes, 4);
-        if (t.ok && t.efficiency > best_eff * 1.1f) { best_eff = t.efficiency; twl4 = twl; nw4 = true; }
+        if (t.ok && t.efficiency > best_eff * 1.1f) { best_eff = t.efficiency; twl4 = twl; nw4 = true; tiles4 = t.tiles; }
       }
+      // only grids of more than one round (512 co-resident four-wave workgroups): on a single round the two workgroups of a CU start
+      // and end together and nothing overlaps (measured: batch 1 +-0, batch 8 +4-7 %)
+      const long min_wgs = tune_env("THA4_TILE_NW4_MIN_WGS") ? std::atol(tune_env("THA4_TILE_NW4_MIN_WGS")) : 2 * 512;
+      if (nw4 && (long)tiles4 * mtiles * max_batch < min_wgs) nw4 = false;
     }
     // fallbacks (1x1 convolutions): small maps (<= 32x32) one pixel group per workgroup with K split over its 4 waves
     // (conv_splitk_kernel), otherwise the exact-fp32 pixel-tiled kernel (conv_mfma_kernel)
@@ -442,9 +451,6 @@ class FullModel {
         a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots;
         a.win_buffers = tg.win_buffers;
         if (!tg.ok || tg.tiles != tiles) { if (error.empty()) error = "conv tile geometry differs between parity classes"; return FTensor(); }
-        // single-round grids keep two co-resident workgroups in phase: the one in the odd slot starts late (tha4_platform.h dephase_odd_slot)
-        if (nw4 && (long)tiles * mtiles * max_batch <= 2 * 256)
-          a.dephase_cycles = tune_env("THA4_TILE_DEPHASE") ? std::atoi(tune_env("THA4_TILE_DEPHASE")) : 6000;
       } else {
         w_off = add_param(pack_conv_weight(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb));
         cq = std::max(1, 32 / (g.ntaps * tmb));
@@ -541,7 +547,8 @@ class FullModel {
     // (a batched call multiplies the consumers' workgroups, each of which would redo the reduction, while one finalize launch
     // serves all frames: fusing pays for max_batch <= 2 only - measured, profiles/r02_full_b1_reading.md)
     const int fuse_batch = tune_env("THA4_FUSED_NORM_MAX_BATCH") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_BATCH")) : 2;
-    if (total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !tune_env("THA4_NO_SMALL_CONV") && !tune_env("THA4_NO_TILE_CONV")) {
+    if (total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !tune_env("THA4_NO_SMALL_CONV") && !tune_env("THA4_NO_TILE_CONV") &&
+        !exact_fp32) {
       Pending p;
       p.fused = true;
       for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].stats_off; p.tiles[i] = srcs[i].stats_tiles; }
@@ -854,8 +861,9 @@ class FullModel {
   // num_nets = 5: mode_07 (all 33 outputs); num_nets = 3: mode_12 (mode_12.py:42-97: eyebrow_decomposer ->
   // eyebrow_morphing_combiner -> face_morpher only; outputs 11..32 of the list below exist, 0..10 are never written)
   int num_networks = 5;
-  bool build(const WeightMap nets[5], int max_batch_, int sel, int num_nets = 5) {
+  bool build(const WeightMap nets[5], int max_batch_, int sel, int num_nets = 5, bool exact = false) {
     max_batch = max_batch_;
+    exact_fp32 = exact;
     sel_index = sel;
     num_networks = num_nets;
     static const int och[33] = {4, 1, 4, 2, 4, 4, 4, 1, 4, 2, 4, 4, 1, 4, 4, 1, 4, 4, 2, 4, 1, 4, 4, 1, 4, 4, 2, 4, 1, 4, 4, 1, 4};

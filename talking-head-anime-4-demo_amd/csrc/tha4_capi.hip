@@ -459,24 +459,31 @@ struct tha4_full {
 
 int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
                      tha4_full** out) {
-  return tha4_full_create_ex(weights, eyebrow_morphed_image_index, device, max_batch, 5, out);
+  return tha4_full_create_ex(weights, eyebrow_morphed_image_index, device, max_batch, 5, 0u, out);
 }
 
 int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
-                        int num_networks, tha4_full** out) {
+                        int num_networks, uint32_t flags, tha4_full** out) {
   if (!weights || !out) return fail(THA4_ERR_INVALID_ARGUMENT, "weights/out must not be NULL");
+  if (flags & ~(uint32_t)THA4_FULL_EXACT_FP32) return fail(THA4_ERR_INVALID_ARGUMENT, "unknown flag bits");
   if (num_networks != 3 && num_networks != 5) return fail(THA4_ERR_INVALID_ARGUMENT, "num_networks must be 5 (mode_07) or 3 (mode_12)");
   *out = nullptr;
   if (max_batch < 1 || max_batch > 256) return fail(THA4_ERR_INVALID_ARGUMENT, "max_batch must be in [1, 256]");
   if (eyebrow_morphed_image_index != 0 && eyebrow_morphed_image_index != 2)
     return fail(THA4_ERR_INVALID_ARGUMENT, "eyebrow_morphed_image_index must be 0 or 2");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(THA4_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= ndev) return fail(THA4_ERR_NO_DEVICE, "device index out of range");
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(THA4_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library only contains gfx950 code");
+  const bool have_dev = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+  // diagnostics only: with THA4_DUMP_SCHEDULE set and no device (the build container) the launch plan is still built and printed
+  // - planning is host code - before the call fails with THA4_ERR_NO_DEVICE like it always does without a GPU
+  const bool plan_only = !have_dev && std::getenv("THA4_DUMP_SCHEDULE") != nullptr;
+  if (!have_dev && !plan_only) return fail(THA4_ERR_NO_DEVICE, "no HIP device visible");
+  if (have_dev) {
+    if (device < 0 || device >= ndev) return fail(THA4_ERR_NO_DEVICE, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(THA4_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library only contains gfx950 code");
+  }
   WeightMap nets[5];
   for (int n = 0; n < num_networks; ++n) {
     if (!weights->tensors[n] || weights->counts[n] <= 0) return fail(THA4_ERR_INVALID_ARGUMENT, "empty state_dict");
@@ -491,10 +498,14 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
   }
   auto* h = new tha4_full();
   h->device = device;
-  if (!h->model.build(nets, max_batch, eyebrow_morphed_image_index, num_networks)) {
+  if (!h->model.build(nets, max_batch, eyebrow_morphed_image_index, num_networks, (flags & THA4_FULL_EXACT_FP32) != 0)) {
     std::string msg = std::string(num_networks == 5 ? "not a mode_07 model: " : "not a mode_12 model: ") + h->model.error;
     delete h;
     return fail(THA4_ERR_INVALID_ARGUMENT, msg);
+  }
+  if (plan_only) {
+    delete h;
+    return fail(THA4_ERR_NO_DEVICE, "no HIP device visible (the launch plan was printed: THA4_DUMP_SCHEDULE)");
   }
   DeviceGuard guard(device);
   FullModel& m = h->model;
@@ -549,6 +560,8 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
   // is the synchronous check).  Reported once, then cleared so that the caller can go on with sane inputs
   if (*reinterpret_cast<volatile int*>(h->fault)) {
     *reinterpret_cast<volatile int*>(h->fault) = 0;
+    // the faulted call may be the one that filled the persistent eyebrow-decomposer outputs: they are not reused by anybody
+    h->decomposer_valid = false;
     return fail(THA4_ERR_NUMERIC_RANGE, kNumericFaultMessage);
   }
   DeviceGuard guard(h->device);
@@ -564,10 +577,11 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
   for (int i = 0; i < 33; ++i) f.out[i] = outputs_dev[i] ? outputs_dev[i] : m.Wk(m.scratch_out[i]);
   for (int i = 0; i < 6; ++i) want_dec[i] = outputs_dev[27 + i] != nullptr;
   const bool reuse = reuse_decomposer && h->decomposer_valid && h->last_batch == batch;
+  h->decomposer_valid = false;              // valid again only once every launch of this call has been accepted
   m.run(f, !reuse, want_dec);
+  HIP_TRY(hipGetLastError());
   h->decomposer_valid = true;
   h->last_batch = batch;
-  HIP_TRY(hipGetLastError());
   return THA4_OK;
 }
 
@@ -579,6 +593,7 @@ int tha4_full_numeric_status(tha4_full* h, int synchronize) {
   }
   if (*reinterpret_cast<volatile int*>(h->fault)) {
     *reinterpret_cast<volatile int*>(h->fault) = 0;
+    h->decomposer_valid = false;
     return fail(THA4_ERR_NUMERIC_RANGE, kNumericFaultMessage);
   }
   return THA4_OK;
@@ -605,6 +620,7 @@ void tha4_full_destroy(tha4_full* h) {
 
 int tha4_full_max_batch(const tha4_full* h) { return h ? h->model.max_batch : THA4_ERR_INVALID_ARGUMENT; }
 int tha4_full_num_networks(const tha4_full* h) { return h ? h->model.num_networks : THA4_ERR_INVALID_ARGUMENT; }
+int tha4_full_flags(const tha4_full* h) { return h ? (h->model.exact_fp32 ? THA4_FULL_EXACT_FP32 : 0) : THA4_ERR_INVALID_ARGUMENT; }
 
 int tha4_display_rgba8(const float* frames_dev, int batch, int height, int width, const float* background_rgb,
                        uint8_t* out_dev, void* stream) {

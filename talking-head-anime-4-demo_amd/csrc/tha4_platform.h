@@ -106,7 +106,10 @@
 // a wave issuing back-to-back MFMAs starves its partner's VALU instructions and the two phases take the SUM of their times,
 // with the VALU-phase wave at s_setprio 1 they overlap (cross-wave 16x16x32: 1059 -> 766 us for 494 us of MFMA + 565 us of FMA).
 // THA4_PRIO_VALU() opens a VALU-heavy phase (sine / staging epilogues), THA4_PRIO_MFMA() a matrix phase.
-#if !defined(THA4_EMU) && defined(THA4_PHASE_PRIO) && THA4_PHASE_PRIO
+#ifndef THA4_PHASE_PRIO
+#define THA4_PHASE_PRIO 1      // round 4: on (it is what makes the two workgroups per CU of conv_tile_kernel<..., NW = 4> overlap; neutral elsewhere)
+#endif
+#if !defined(THA4_EMU) && THA4_PHASE_PRIO
 #define THA4_PRIO_VALU() __builtin_amdgcn_s_setprio(1)
 #define THA4_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
 #else
@@ -144,6 +147,21 @@ THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 THA4_DEV float lane_read(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15 = the 16 pixels a lane group holds of one channel), left in every lane of
+// the row: four v_add_f32 with a row_ror DPP operand (rotations by 8, 4, 2, 1 - a fixed, direction-independent order).  Round 4:
+// the per-channel statistics of the convolution epilogues spent 8 ds_bpermute_b32 per value (128 LDS round trips per workgroup
+// tile); DPP needs no LDS at all.
+template <int N>
+THA4_DEV float row16_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+THA4_DEV float row16_sum(float v, int) {
+  v += row16_ror<8>(v);
+  v += row16_ror<4>(v);
+  v += row16_ror<2>(v);
+  v += row16_ror<1>(v);
+  return v;
+}
 // value held by lane `src_lane` (wave-uniform index) as a scalar: v_readlane_b32 - a per-tap table kept in one VGPR
 // (lane t holds entry t) replaces a scalar memory load + s_waitcnt lgkmcnt(0) inside the MFMA loops
 THA4_DEV int lane_pick(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
@@ -168,24 +186,12 @@ THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {      // fibers run o
   return (int)emu::shfl(v, 0);                                   // tickets are small integers: exact in fp32
 }
 THA4_DEV float lane_read(float v, int src_lane) { return emu::shfl(v, src_lane); }
+THA4_DEV float row16_sum(float v, int lane) {                   // the device's order: rotations by 8, 4, 2, 1 inside the 16-lane row
+  for (int m = 8; m >= 1; m >>= 1) v += emu::shfl(v, (lane & ~15) | ((lane + m) & 15));
+  return v;
+}
 THA4_DEV int lane_pick(int v, int src_lane) { return (int)emu::shfl((float)v, src_lane); }       // |v| < 2^24: exact in fp32
 #endif
-
-// Two workgroups that share a CU run their stage -> barrier -> MFMA rhythm in phase when they start together (a single-round
-// grid), and then the matrix pipe idles in both staging phases.  A workgroup in an ODD slot of its CU (HW_REG_HW_ID.TG_ID, bits
-// 19:16: the workgroup's resource slot on the CU - co-resident workgroups hold different ones) waits `cycles` shader cycles before it
-// starts: the offset is preserved from then on (both run the same loop), so one stages while the other multiplies.
-THA4_DEV void dephase_odd_slot(int cycles) {
-#ifndef THA4_EMU
-  const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
-  if (tg & 1) {
-    const long long t0 = clock64();
-    while (clock64() - t0 < (long long)cycles) __builtin_amdgcn_s_sleep(16);
-  }
-#else
-  (void)cycles;
-#endif
-}
 
 // fp16 hi/lo split of a PAIR of fp32 values: v = hi + lo with hi = fp16(v), lo = fp16(v - hi).  One v_cvt_pk_f16_f32 for both hi halves
 // and one v_fma_mix per lo half (the f16 -> f32 conversion of hi rides inside the FMA): 3-4 instructions per pair where the plain

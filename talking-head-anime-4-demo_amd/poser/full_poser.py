@@ -41,8 +41,13 @@ class HipFullPoser(Poser):
                  eyebrow_morphed_image_index: int = 2,
                  default_output_index: int = 0,
                  max_batch: int = 1,
-                 dtype: torch.dtype = torch.float):
+                 dtype: torch.dtype = torch.float,
+                 exact_fp32: bool = False):
         self.state_dict_loaders = state_dict_loaders
+        #: THA4_FULL_EXACT_FP32: every convolution on the exact-fp32 kernels (fp32's own operand range; ~2.5-3x slower).  The plan to
+        #: fall back to when `check_numeric_range()` / `pose()` report THA4_ERR_NUMERIC_RANGE for weights that are fine in fp32:
+        #: `poser.set_exact_fp32(True)` re-plans the handle on the next call.
+        self.exact_fp32 = bool(exact_fp32)
         self.device = torch.device(device)
         self.pose_parameters = pose_parameters
         self.eyebrow_morphed_image_index = eyebrow_morphed_image_index
@@ -110,6 +115,14 @@ class HipFullPoser(Poser):
         if self._handle is not None:
             _capi.check(self._lib, self._lib.tha4_full_numeric_status(self._handle, 1), "tha4_full_numeric_status")
 
+    def set_exact_fp32(self, on: bool = True) -> "HipFullPoser":
+        """Switch between the default plan (fp16 hi/lo operand halves, |operand| <= 65504) and the exact-fp32 plan; the native handle
+        is re-created lazily by the next call.  Results of the two plans agree within the parity gate, not bitwise."""
+        if bool(on) != self.exact_fp32:
+            self.exact_fp32 = bool(on)
+            self._destroy_handle()
+        return self
+
     def free(self):
         self._destroy_handle()
         self._state_dicts = None
@@ -175,7 +188,7 @@ class HipFullPoser(Poser):
         weights, keep = _capi.build_full_weights(self._state_dicts)
         handle = C.c_void_p()
         st = self._lib.tha4_full_create_ex(C.byref(weights), self.eyebrow_morphed_image_index, dev, self._max_batch,
-                                           self.num_networks, C.byref(handle))
+                                           self.num_networks, _capi.FULL_EXACT_FP32 if self.exact_fp32 else 0, C.byref(handle))
         _capi.check(self._lib, st, "tha4_full_create_ex")
         del keep
         self._handle = handle
@@ -220,8 +233,10 @@ class HipFullPoser(Poser):
         if self.content_cache and not image_changed and not reuse and self._cache_copy is not None \
                 and self._cache_copy_batch == b and self._cache_copy.shape == image.shape:
             reuse = bool((image - self._cache_copy).abs().max().item() == 0)      # the reference's test, with its sync
-        if self.content_cache and not reuse:
-            self._cache_copy, self._cache_copy_batch = image.clone(), b           # private copy: immune to in-place edits
+        # the private copy behind the content rule is replaced only AFTER the call below has succeeded: a failed call (e.g.
+        # THA4_ERR_NUMERIC_RANGE returns without enqueueing anything) must not leave a copy that makes the NEXT call with the same
+        # content claim a decomposer result that was never computed (round-3 advisor finding)
+        new_copy = image.clone() if (self.content_cache and not reuse) else None      # private copy: immune to in-place edits
         target = torch.device("cuda", dev)
         outs = {}
         ptrs = (C.c_void_p * _capi.FULL_NUM_OUTPUTS)()
@@ -240,8 +255,12 @@ class HipFullPoser(Poser):
             stream = torch.cuda.current_stream(dev).cuda_stream
             st = self._lib.tha4_full_pose_ex(self._handle, image.data_ptr(), stride, pose.data_ptr(), b, ptrs, int(reuse),
                                              disp_ref, C.c_void_p(stream))
+        if st != 0:                                         # nothing of this call may be reused: forget every cache rule's state
+            self._cache_key, self._cache_image, self._cache_copy = None, None, None
         _capi.check(self._lib, st, "tha4_full_pose_ex")
         del disp_keep
+        if new_copy is not None:
+            self._cache_copy, self._cache_copy_batch = new_copy, b
         self._cache_key = key
         self._cache_image = keep if key is not None else None
         if display is not None:

@@ -142,7 +142,8 @@ def test_no_kernel_spills(built):
     import re
     from tha4_amd import _build
     lines = open(_build.RESOURCES).read().splitlines()
-    assert sum("conv_tile_kernel" in l for l in lines) == 27 and sum("tha42v2" in l for l in lines) >= 5
+    assert sum("conv_tile_kernel" in l for l in lines) == 45      # 27 eight-wave + 18 four-wave (NW = 4) instantiations
+    assert sum("tha42v2" in l for l in lines) >= 5
 
     def num(l, key):
         return int(re.search(key + r"=(\d+)", l).group(1))
@@ -168,7 +169,8 @@ def test_mode_12_surface_and_defaults():
 def test_new_entry_points_validate_arguments(built):
     lib = _capi.load_library()
     assert lib.tha4_student_set_weights(None, None) == -1
-    assert lib.tha4_full_create_ex(None, 2, 0, 1, 3, None) == -1
+    assert lib.tha4_full_create_ex(None, 2, 0, 1, 3, 0, None) == -1
+    assert lib.tha4_full_flags(None) == -1
     assert lib.tha4_full_num_networks(None) == -1
     # stateless image entry points refuse host pointers instead of launching on them
     import ctypes as C

@@ -455,3 +455,141 @@ def test_content_equivalent_decomposer_cache(weights, full_io, golden_io):
     assert torch.equal(p.pose(img, pose), cold_a) and calls[-1] == 0
     p._lib = lib
     p.free()
+
+
+def test_failed_call_does_not_poison_the_decomposer_cache(weights, full_io, golden_io):
+    """Round-3 advisor finding: with `content_cache` on, the private copy of the last image used to be replaced BEFORE the native
+    call had succeeded - a refused call (THA4_ERR_NUMERIC_RANGE enqueues nothing) then made the next call with the same content
+    claim a decomposer result that was never computed.  Now no cache rule keeps anything of a failed call, and the native side
+    drops its own validity bit when it reports a fault."""
+    from oracle.student_oracle import synthetic_image
+    from tha4_amd import _capi
+    dev = torch.device("cuda:0")
+    p = mode_07.create_poser_from_state_dicts(dev, weights, max_batch=1)
+    p.content_cache = True
+    pose = torch.from_numpy(full_io["poses"][1]).to(dev)
+    a_np, b_np = golden_io["image_f32"], synthetic_image(seed=321)
+    p.pose(torch.from_numpy(a_np).to(dev), pose, image_changed=True)
+    want_b = p.pose(torch.from_numpy(b_np).to(dev), pose, image_changed=True).clone()
+    p.pose(torch.from_numpy(a_np).to(dev), pose)                      # the decomposer buffers hold image a again
+    lib, calls, fail_next = p._lib, [], [True]
+    real = lib.tha4_full_pose_ex
+
+    class Spy:                                            # refuses ONE call the way a sticky numeric fault does: status < 0, nothing enqueued
+        def __call__(self, *args):
+            if fail_next[0]:
+                fail_next[0] = False
+                return _capi.ERR_NUMERIC_RANGE
+            calls.append(int(args[6]))
+            return real(*args)
+    p._lib = type("L", (), {"tha4_full_pose_ex": Spy(), "tha4_last_error": lib.tha4_last_error, "tha4_full_destroy": lib.tha4_full_destroy,
+                            "tha4_full_create_ex": lib.tha4_full_create_ex, "tha4_full_numeric_status": lib.tha4_full_numeric_status})()
+    with pytest.raises(_capi.Tha4Error):
+        p.pose(torch.from_numpy(b_np).to(dev), pose)                  # image b: refused
+    got = p.pose(torch.from_numpy(b_np.copy()).to(dev), pose)         # same content again: must NOT reuse (b was never decomposed)
+    assert calls == [0], calls
+    assert torch.equal(got, want_b)
+    assert torch.equal(p.pose(torch.from_numpy(b_np.copy()).to(dev), pose), want_b) and calls[-1] == 1      # and from now on it hits
+    p._lib = lib
+    p.free()
+    # native side: a reported fault invalidates the handle's own decomposer state (reuse_decomposer = 1 is then ignored once)
+    import copy
+    bad = copy.deepcopy(weights)
+    bad["eyebrow_decomposer"]["body.downsample_blocks.0.1.weight"] = bad["eyebrow_decomposer"]["body.downsample_blocks.0.1.weight"] * 2e5
+    q = mode_07.create_poser_from_state_dicts(dev, bad, max_batch=1)
+    img = torch.from_numpy(a_np).to(dev)
+    q.pose(img, pose)                                                  # faults inside the decomposer; returns OK (no sync)
+    with pytest.raises(_capi.Tha4Error, match="numeric fault"):
+        q.check_numeric_range()
+    q.free()
+
+
+# ---- round 4: the exact-fp32 plan (THA4_FULL_EXACT_FP32) and the .pt-file route of the full model on the device --------------------
+def test_exact_fp32_plan_vs_reference_fixture_and_split_plan(weights, poser1, full_io, golden_io):
+    """`mode_07.create_poser_from_state_dicts(..., exact_fp32=True)` -> tha4_full_create_ex(flags = THA4_FULL_EXACT_FP32): every
+    convolution on v_mfma_f32_16x16x4_f32 with fp32 operands.  All 33 outputs against the unmodified reference's fixture (same gate
+    as the default plan), and the distance between the two plans is written down."""
+    dev = torch.device("cuda:0")
+    p = mode_07.create_poser_from_state_dicts(dev, weights, max_batch=1, exact_fp32=True)
+    p.get_modules()
+    assert p._lib.tha4_full_flags(p._handle) == 1 and poser1._lib.tha4_full_flags(poser1._handle) == 0
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    report, apart = [], 0.0
+    for i in range(2):
+        pose = torch.from_numpy(full_io["poses"][i]).to(dev)
+        outs = p.get_posing_outputs(image, pose, image_changed=(i == 0))
+        split = poser1.get_posing_outputs(image, pose, image_changed=(i == 0))
+        for k in range(33):
+            got = outs[k][0].cpu().numpy()
+            assert np.isfinite(got).all(), fo.OUTPUT_NAMES[k]
+            err = float(np.abs(got[:, SUB, SUB] - full_io[f"ref32_sub_out{k}"][i]).max())
+            d = float((outs[k] - split[k]).abs().max())
+            apart = max(apart, d)
+            report.append((i, fo.OUTPUT_NAMES[k], err, d))
+    p.check_numeric_range()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/full_exact_plan_report.txt", "w") as fh:
+        fh.write("exact-fp32 plan (THA4_FULL_EXACT_FP32): |hip - reference fp32 fixture|   |exact plan - default (fp16 hi/lo) plan|\n")
+        fh.write("\n".join(f"pose {i} {n:20s} {e:.3e}   {d:.3e}" for i, n, e, d in report) + "\n")
+    print(f"PARITY exact plan: worst vs reference {max(r[2] for r in report):.3e}; exact vs split plan {apart:.3e}")
+    bad = [r for r in report if r[2] > TOL]
+    assert not bad, bad
+    assert apart <= 2e-3                                    # two correct fp32-class evaluations of the same frame
+    p.free()
+
+
+def test_guard_trips_then_exact_plan_serves_the_same_weights(weights, full_io, golden_io):
+    """What a caller does when the default plan reports THA4_ERR_NUMERIC_RANGE for weights that are legitimate in fp32 (the
+    reference computes in plain fp32): switch the poser to the exact plan.  An InstanceNorm gain x 2e5 in the face morpher's first
+    block drives its ReLU output beyond the fp16 hi/lo operand range (the guard test above); the exact plan poses the same weights
+    with finite outputs that match the oracle's fp32 evaluation of THOSE weights."""
+    import copy
+    from tha4_amd import _capi
+    dev = torch.device("cuda:0")
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    pose_np = full_io["poses"][0]
+    pose = torch.from_numpy(pose_np).to(dev)
+    bad = copy.deepcopy(weights)
+    bad["face_morpher"]["downsample_blocks.0.1.weight"] = bad["face_morpher"]["downsample_blocks.0.1.weight"] * 2e5
+    p = mode_07.create_poser_from_state_dicts(dev, bad, max_batch=1)
+    p.pose(image, pose)
+    with pytest.raises(_capi.Tha4Error, match="numeric fault"):
+        p.check_numeric_range()
+    p.set_exact_fp32(True)                                   # re-plans lazily; same weights
+    outs = p.get_posing_outputs(image, pose, image_changed=True)
+    p.check_numeric_range()                                  # no fault on this plan
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    ref = fo.full_forward_torch(bad, golden_io["image_f32"], pose_np[None], "float32")
+    ref64 = fo.full_forward_torch(bad, golden_io["image_f32"], pose_np[None], "float64")
+    worst = 0.0
+    for k in (0, 5, 6, 11):                                  # posed frame, pasted face, body morpher, face morpher
+        noise = float((ref[k].double() - ref64[k]).abs().max())
+        err = float((outs[k].cpu().double() - ref64[k]).abs().max())
+        worst = max(worst, err)
+        assert err <= _tol(fo.OUTPUT_NAMES[k], noise), (fo.OUTPUT_NAMES[k], err, noise)
+    print(f"PARITY exact plan on out-of-range weights: worst |hip - ref64| {worst:.3e}")
+    p.free()
+
+
+def test_mode_07_create_poser_from_pt_files_on_device(weights, poser1, full_io, golden_io, tmp_path):
+    """The reference's own entry point, literally: `mode_07.create_poser(device, module_file_names={...five .pt files...})`
+    (mode_07.py:272-315) with `torch.save`d state_dicts in the reference layout (OrderedDict of tensors, the keys
+    `load_state_dict(strict=True)` accepts: tests/golden/make_golden_full.py).  Bitwise equal to the in-memory route."""
+    from collections import OrderedDict
+    dev = torch.device("cuda:0")
+    files = {}
+    for net in mode_07.Network:
+        path = str(tmp_path / f"{net.name}.pt")
+        torch.save(OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in weights[net.name].items()), path)
+        files[net.name] = path
+    p = mode_07.create_poser(dev, module_file_names=files)
+    assert p.get_output_length() == 33 and p.get_num_parameters() == 45 and p.get_image_size() == 512
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    pose = torch.from_numpy(full_io["poses"][0]).to(dev)
+    got = p.get_posing_outputs(image, pose)
+    want = poser1.get_posing_outputs(image, pose, image_changed=True)
+    assert len(got) == 33 and all(torch.equal(a, b) for a, b in zip(got, want))
+    assert np.abs(got[0][0].cpu().numpy() - full_io["ref32_full_out0"][0]).max() <= TOL
+    with pytest.raises(FileNotFoundError):
+        mode_07.create_poser(dev, module_file_names={**files, "upscaler": str(tmp_path / "missing.pt")}).pose(image, pose)
+    p.free()

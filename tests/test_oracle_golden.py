@@ -93,3 +93,45 @@ def test_random_pose_ranges():
     assert (p[:, :37] >= 0).all() and (p[:, :37] < 1).all()
     assert (p[:, 37:44] >= -1).all() and (p[:, 37:44] < 1).all() and (p[:, 37:44] < 0).any()
     assert (p[:, 44] >= 0).all()
+
+
+@pytest.mark.parametrize("character", ["lambda_00", "lambda_01"])
+def test_oracle_matches_the_pinned_sweep_and_edge_poses(character, char_weights, char_io):
+    """The round-4 fixtures (tests/golden/make_golden_sweep.py): the four edge poses of the GPU suite's test_edge_poses and poses of
+    the 64-pose sweep that round 3 had NOT pinned for lambda_01 (indices >= 16) - the oracle equals the unmodified reference on
+    them too (stride-8 pixel subsets)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"student_{character}_sweep.npz"))
+    assert z["ref32_sub8_out0"].shape[0] == 64 and z["ref32_sub8_edge_out0"].shape[0] == 4
+    w, image = char_weights[character], char_io[character]["image_f32"]
+    out = so.student_forward_torch(w, image, z["edge_poses"], "float32")[0].numpy()
+    assert np.abs(out[:, :, 3::8, 3::8] - z["ref32_sub8_edge_out0"]).max() <= TOL32[0]
+    idx = [17, 40, 63]
+    out = so.student_forward_torch(w, image, z["poses"][idx], "float32")[0].numpy()
+    assert np.abs(out[:, :, 3::8, 3::8] - z["ref32_sub8_out0"][idx]).max() <= TOL32[0]
+
+
+def test_local_affine_grid_table_against_the_fixture_build():
+    """The kernels take the LOCAL torch build's fp32 `affine_grid` axes (`match_aten_positions=True`: they track "the reference on
+    this machine"); the committed reference frames were made with the torch build recorded in the sweep fixture.  A different
+    local table moves up to ~1e-4 of the 1e-3 budget (test_exact_positions_shift_output_by_1e4): never silently - this test WARNS
+    with both versions and the number of differing entries (and fails only if an axis is outside what fp32 linspace rounding can
+    produce, i.e. more than 1 ulp from the exact dyadic grid)."""
+    import os
+    import warnings
+    import torch
+    import torch.nn.functional as F
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "student_lambda_00_sweep.npz"))
+    ident = torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]])
+    differing = {}
+    for sz in (128, 256, 512):
+        local = F.affine_grid(ident, [1, 1, sz, sz], align_corners=False)[0, 0, :, 0].numpy()
+        exact = ((2 * np.arange(sz) + 1) / sz - 1).astype(np.float64)
+        assert np.abs(local.astype(np.float64) - exact).max() <= np.spacing(np.float32(1.0)), f"affine_grid axis {sz} is not an fp32 rounding of the dyadic grid"
+        n = int((local != z[f"aten_axis{sz}"]).sum())
+        if n:
+            differing[sz] = n
+    if differing:
+        warnings.warn(f"local torch {torch.__version__} produces a different fp32 affine_grid table than the fixtures' torch "
+                      f"{str(z['torch_version'])}: differing entries {differing} - the kernels follow the LOCAL table, the committed reference "
+                      f"frames the fixture's (up to ~1e-4 of the 1e-3 budget)", RuntimeWarning)

@@ -187,6 +187,11 @@ def test_edge_poses(poser, dev, golden_io, golden_weights):
     ref = so.student_forward_torch(golden_weights, golden_io["image_f32"], edge, "float32")[0].numpy()
     assert np.isfinite(out).all()
     assert np.abs(out - ref).max() <= TOL_OUT0
+    # ... and against the UNMODIFIED reference's frames for the same four poses (tests/golden/make_golden_sweep.py, stride-8 subsets)
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "student_lambda_00_sweep.npz"))
+    assert np.array_equal(z["edge_poses"], edge)
+    assert np.abs(out[:, :, 3::8, 3::8] - z["ref32_sub8_edge_out0"]).max() <= TOL_OUT0
 
 
 def test_random_weights_and_synthetic_image(dev):

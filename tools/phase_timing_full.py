@@ -15,7 +15,11 @@ CSRC = os.path.join(ROOT, "talking-head-anime-4-demo_amd", "csrc")
 lib = os.path.join(ROOT, "build_variants", "libtha4_phase.so")
 if "build" in sys.argv:
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTHA4_PHASE_TIMING", *(["-DTHA4_PHASE_WINDOW"] if "--window" in sys.argv else []), "-I", CSRC, "-I",
+    from importlib import util as _u
+    _sp = _u.spec_from_file_location("_tha4_build", os.path.join(ROOT, "talking-head-anime-4-demo_amd", "_build.py"))
+    _b = _u.module_from_spec(_sp)
+    _sp.loader.exec_module(_b)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTHA4_PHASE_TIMING", *_b.DEVICE_FLAGS, *(["-DTHA4_PHASE_WINDOW"] if "--window" in sys.argv else []), "-I", CSRC, "-I",
                     os.path.join(ROOT, "include"), os.path.join(CSRC, "tha4_capi.hip"), "-o", lib], check=True)
     sys.exit(0)
 
@@ -46,7 +50,8 @@ sched = [l for l in tmp.read().decode().splitlines() if l.startswith("conv #")]
 del os.environ["THA4_DUMP_SCHEDULE"]
 
 targets = ["tile=64x64 cin=256(cb 16) cout=256", "tile=16x16 cin=512(cb 32) cout=512", "tile=256x256 cin=128(cb 8) cout=128",
-           "tile=128x128 cin=128(cb 8) cout=128", "tile=32x32 cin=256(cb 16) cout=256", "tile=16x16 cin=256(cb 16) cout=256"]
+           "tile=128x128 cin=128(cb 8) cout=128", "tile=32x32 cin=256(cb 16) cout=256", "tile=16x16 cin=256(cb 16) cout=256",
+           "tile=128x128 cin=256(cb 16) cout=256", "tile=256x256 cin=64(cb 4) cout=64", "tile=512x512 cin=32(cb 2) cout=32"]
 if "--small" in sys.argv:
     targets = [t for t in targets if "16x16" in t or "32x32" in t]
 L = p._lib
@@ -71,7 +76,8 @@ for tgt in targets:
     first = t[:, :, 0].copy()
     d = np.diff(t[:, :, :n], axis=-1)
     print(f"== {line[:170]}")
-    print(f"   stamps per wave: {n}; wave span entry -> last stamp: {(t[:, :, n - 1] - t[:, :, 0]).mean():.0f} cycles")
+    print(f"   stamps per wave: {n}; wave span entry -> last stamp: {(t[:, :, n - 1] - t[:, :, 0]).mean():.0f} cycles; "
+          f"first entry -> last stamp over the grid: {t[:, :, n - 1].max() - t[:, :, 0].min():.0f}; entry spread {t[:, :, 0].max() - t[:, :, 0].min():.0f}")
     print("   mean cycles between consecutive stamps: " + " ".join(f"{x:.0f}" for x in d.mean(axis=(0, 1))))
     if "tiled=2" in line:       # conv_small_kernel: waves have different stamp counts (wave 0 runs the epilogue): per-wave rows of workgroup 0 and the spread of entry times
         for wv in (0, 1, 7):
