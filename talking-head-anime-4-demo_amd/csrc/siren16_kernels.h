@@ -8,13 +8,17 @@
 // weights would be off by 0.25 / 1.6.  Per 32-channel K group the matrix pipe spends 3 x 16 cycles
 // instead of 8 x 32 (v_mfma_f32_16x16x4_f32): 5.3x fewer MFMA cycles, which moves the bound to the VALU - and VALU
 // work does NOT hide under MFMAs on this chip (tools/microbench/valu_rate.hip) - so everything per-value is trimmed:
-//   * weights are packed as W' = c S W with c = 30 for sine layers (and for the z hand-off layers, whose consumer is a
-//     sine) and S a per-layer power of two that lifts the lo halves of small weights out of the fp16 subnormal range;
-//     the epilogue is ONE fma  u = acc / S + 30 b  and sin(u) needs no 30x multiply;
+//   * weights are packed as W' = c S W with c = omega_0 / (2 pi) = 4.7746 for sine layers (and for the z hand-off layers,
+//     whose consumer is a sine) - the sine takes its argument in TURNS (round 3, THA4_SIN_TURNS) - and S a per-layer power of
+//     two that lifts the lo halves of small weights out of the fp16 subnormal range; the epilogue is ONE fma
+//     t = acc / S + c b  and the sine needs no multiply;
 //   * activations are in [-1, 1]: their lo halves are stored unscaled (abs error <= 2^-25, MFMA keeps fp16
-//     subnormals), so the split is cvt + one mixed-precision fma per value and one accumulator serves all 3 MFMAs;
-//   * sin(u): k = rint(u/pi) by the 1.5*2^23 magic add (its low mantissa bit is the parity of k), 2-term Cody-Waite,
-//     degree-9 odd polynomial: 12 VALU ops instead of 15.
+//     subnormals), so the split of a PAIR of values is one v_cvt_pk_f16_f32 + one v_fma_mix per value (split_pair,
+//     tha4_platform.h) and one accumulator serves all 3 MFMAs;
+//   * sin(2 pi t) is ONE v_sin_f32 (sin_u, siren_kernels.h: the instruction reduces its argument itself, valid for
+//     |t| <= 256 turns - checked for every layer when the weights are packed, siren_layout.h - 3.8e-7 max abs error).
+//     (-DTHA4_SIN_TURNS=0 rebuilds round 2's pipeline: c = 30, radians, magic-add rint + 2-term Cody-Waite + degree-9
+//     polynomial, 12 VALU ops per sine.)
 // Everything else (fused level chains, streamed fragment-linear weights, z hand-off, warp epilogue) is the design of
 // siren_kernels.h.
 //

@@ -120,6 +120,7 @@ THA4_DEV float sin_u(float u) {
   if (THA4_HOOK_SIN_BYPASS) return u;
 #if THA4_SIN_TURNS
 #ifdef THA4_EMU
+  if (!(fabsf(u) <= 256.0f)) return 0.0f;          // the instruction's domain: 0 beyond 256 turns (and for NaN / inf inputs the device returns NaN; not modelled)
   return (float)sin(6.283185307179586476925 * (double)u);
 #else
   return __builtin_amdgcn_sinf(u);

@@ -9,6 +9,7 @@
 //
 // Everything here is plain C++ (no HIP types) so the CPU unit tests can use it as well.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -206,6 +207,29 @@ inline std::string pack_student(const StudentWeightsView& v, StudentPacked& p) {
   append(p.w_l2, v.body_last, 0, kC2, 1, kNB2);
   append_bias(p.b_l2, v.body_last, 1);
   return "";
+}
+
+// Upper bound, in TURNS, of |omega_0 (W x + b)| / (2 pi) over every sine layer of the student for inputs inside their ranges -
+// hidden activations are sine outputs (|x| <= 1), positions |x|, |y| < 1, pose parameters |p| <= 1 (pose_parameters.py:4-36), the
+// upsampled features of levels 1 / 2 are convex combinations of sine outputs - i.e. max over rows of c (sum_j |W_ij| + |b_i|).
+// The default kernels evaluate the sine with ONE v_sin_f32 on the argument in turns, which returns 0 beyond 256 turns where the
+// reference's torch.sin accepts any argument: tha4_student_create / _set_weights refuse weights whose bound reaches the limit
+// (the shipped students stay below 7 turns) and point at THA4_STUDENT_EXACT_FP32, whose radian pipeline reduces |u| < 12868 rad.
+constexpr double kSineTurnsLimit = 256.0;
+inline double sine_argument_bound_turns(const StudentWeightsView& v) {
+  const double c = 30.0 / 6.283185307179586476925;
+  double worst = 0.0;
+  auto layer = [&](const LinearView& l) {
+    for (int o = 0; o < l.out_ch; ++o) {
+      double s = std::fabs((double)l.bias[o]);
+      for (int i = 0; i < l.in_ch; ++i) s += std::fabs((double)l.weight[(size_t)o * l.in_ch + i]);
+      if (!(s * c <= worst)) worst = s * c;             // (a NaN weight makes the bound NaN: reported as over the limit)
+    }
+  };
+  for (int i = 0; i < 8; ++i) layer(v.face_sine[i]);
+  for (int l = 0; l < 3; ++l)
+    for (int j = 0; j < 3; ++j) layer(v.body_sine[l][j]);
+  return worst;
 }
 
 // exact affine_grid(identity, align_corners=False) axis: x_j = (2j+1)/S - 1 (dyadic, exact in fp32)

@@ -165,6 +165,15 @@ std::string build_student_blob(const tha4_student_weights* weights, bool exact, 
   StudentPacked p;
   std::string err = pack_student(to_view(weights), p);
   if (!err.empty()) return err;
+  if (!exact && THA4_SIN_TURNS) {           // domain of the one-instruction sine (siren_layout.h sine_argument_bound_turns)
+    const double bound = sine_argument_bound_turns(to_view(weights));
+    if (!(bound < kSineTurnsLimit)) {
+      char msg[256];
+      std::snprintf(msg, sizeof msg, "a sine layer's argument can reach %.3g turns (limit %.0f: the default kernels' v_sin_f32 returns 0 beyond it); "
+                    "create the poser with THA4_STUDENT_EXACT_FP32 (exact_fp32=True) for these weights", bound, kSineTurnsLimit);
+      return msg;
+    }
+  }
   const FirstLayerPack* fl[4] = {&p.f_face, &p.f_l0, &p.f_l1, &p.f_l2};
   if (exact) {
     o.wf = bb.add(p.w_face); o.w0 = bb.add(p.w_l0); o.w1 = bb.add(p.w_l1); o.w2 = bb.add(p.w_l2);
@@ -224,7 +233,7 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   BlobBuilder bb;
   StudentBlobOffsets o;
   const std::string err = build_student_blob(weights, exact, pos128, pos256, pos512, bb, o);
-  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, "not a mode_14 student: " + err);
+  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, (err.rfind("a sine layer", 0) == 0 ? "student weights outside the default kernels' range: " : "not a mode_14 student: ") + err);
 
   DeviceGuard guard(device);
   auto* h = new tha4_student();
@@ -395,7 +404,7 @@ int tha4_student_set_weights(tha4_student* h, const tha4_student_weights* weight
   BlobBuilder bb;
   StudentBlobOffsets o;
   const std::string err = build_student_blob(weights, h->exact_fp32, h->pos128, h->pos256, h->pos512, bb, o);
-  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, "not a mode_14 student: " + err);
+  if (!err.empty()) return fail(THA4_ERR_INVALID_ARGUMENT, (err.rfind("a sine layer", 0) == 0 ? "student weights outside the default kernels' range: " : "not a mode_14 student: ") + err);
   if (bb.host.size() != h->blob_bytes) return fail(THA4_ERR_INVALID_ARGUMENT, "internal: packed size differs from the handle's blob");
   DeviceGuard guard(h->device);
   // rare operation: wait for every pose call in flight (whatever stream it is on), then overwrite the blob in place -

@@ -175,6 +175,9 @@ void emu_student_block_pixels_gen(int kernel, int block, int gen, int* first, in
 }
 void emu_student_block_pixels(int kernel, int block, int* first, int* count) { emu_student_block_pixels_gen(kernel, block, 1, first, count); }
 
+// upper bound of the sine arguments in turns for a flat weight set (siren_layout.h): what tha4_student_create checks against 256
+double emu_sine_argument_bound_turns(const tha4_student_weights* w) { return sine_argument_bound_turns(to_view(w)); }
+double emu_sine_turns_limit() { return kSineTurnsLimit; }
 float emu_sin_omega(float z) { return sin_omega(z); }
 float emu_sin_u(float u) { return sin_u(u); }
 float emu_sine_scale16() { return kSineScale16; }      // what generation 2 folds into biases / z hand-off: omega_0 / 2 pi (turns) or omega_0

@@ -107,3 +107,51 @@ def test_level2_kernel_blocks(ctx, golden_weights, golden_io):
                            ("out_grid", 4, 2)):
             got = emu.buf(name).reshape(c, -1)[:, px]
             assert np.abs(got - ref[k].reshape(c, -1)[:, px]).max() < tol[name], (b, name)
+
+
+def test_sine_argument_bound_and_domain(built, golden_weights, char_weights):
+    """Round-3 advisor finding: the default kernels' sine is ONE v_sin_f32 on an argument in turns, which returns 0 beyond 256 turns
+    where the reference's torch.sin accepts anything.  (a) The host-side bound tha4_student_create / _set_weights enforce
+    (siren_layout.h sine_argument_bound_turns: max over rows of c (sum |W| + |b|)) is far below the limit for both shipped
+    students and above it for weights scaled by 100; it really is an upper bound of what the oracle's layers see.  (b) The emulator
+    models the instruction's domain (0 beyond 256 turns) instead of an ideal sine."""
+    import ctypes as C
+    import os
+    from tha4_amd import _capi
+    from tha4_amd.weights import split_flat_weights
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libtha4_emu.so"))
+    lib.emu_sine_argument_bound_turns.restype = C.c_double
+    lib.emu_sine_argument_bound_turns.argtypes = [C.c_void_p]
+    lib.emu_sine_turns_limit.restype = C.c_double
+    lib.emu_sin_u.restype = C.c_float
+    lib.emu_sin_u.argtypes = [C.c_float]
+    limit = lib.emu_sine_turns_limit()
+    assert limit == 256.0
+
+    def bound(flat):
+        ws, keep = _capi.build_student_weights(*split_flat_weights(flat))
+        return lib.emu_sine_argument_bound_turns(C.byref(ws))
+    for name in ("lambda_00", "lambda_01"):
+        b = bound(char_weights[name])
+        assert 1.0 < b < 64.0, (name, b)                 # the shipped students: a wide margin to 256 turns
+    big = {k: (v * 100.0 if k.endswith("sine_layers.3.linear.weight") else v) for k, v in golden_weights.items()}
+    assert bound(big) > limit
+    # it IS an upper bound: the largest |30 (W x + b)| / 2 pi the fp64 oracle meets in the face morpher's hidden layers for a pose
+    pose = so.random_poses(1, seed=5)[0]
+    x = None
+    worst = 0.0
+    c = 30.0 / (2.0 * np.pi)
+    ax = so.position_axis(128)
+    pos = np.stack([np.broadcast_to(ax[None, :], (128, 128)), np.broadcast_to(ax[:, None], (128, 128))])       # channel 0 = x, 1 = y
+    inp = np.concatenate([pos, np.broadcast_to(pose[:39, None, None].astype(np.float64), (39, 128, 128))], 0).reshape(41, -1)
+    x = inp
+    for i in range(8):
+        W = golden_weights[f"face.siren.sine_layers.{i}.linear.weight"].astype(np.float64)
+        b = golden_weights[f"face.siren.sine_layers.{i}.linear.bias"].astype(np.float64)
+        u = W @ x + b[:, None]
+        worst = max(worst, float(np.abs(u).max()) * c)
+        x = np.sin(30.0 * u)
+    assert worst <= bound(golden_weights)
+    # (b) the instruction's domain in the emulator
+    assert lib.emu_sin_u(C.c_float(300.25)) == 0.0 and lib.emu_sin_u(C.c_float(-256.5)) == 0.0
+    assert abs(lib.emu_sin_u(C.c_float(255.25)) - 1.0) < 1e-6
