@@ -10,6 +10,10 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(CSRC, "libtha4_hip.so")
 RESOURCES = os.path.join(CSRC, "libtha4_hip.resources.txt")
+# The same source compiled with every memory wait forced to zero (-mllvm -amdgpu-waitcnt-forcezero=1): identical arithmetic, so a byte
+# that differs from the shipped library is a memory-ordering / hazard fault in one of them (how round 3 found the faulty level-2
+# geometry).  TEST ARTEFACT: only tests/test_twin_gpu.py and tools/compare_libs.py load it, through THA4_HIP_LIB.
+TWIN = os.path.join(CSRC, "libtha4_hip_wait0.so")
 SOURCES = ["tha4_capi.hip"]
 # No packed-fp32 VALU instructions (v_pk_mul / v_pk_fma / v_pk_add_f32) in any kernel of the library: the compiler's packed arithmetic is
 # what made level2_16p_kernel<8,.,2> produce run-to-run varying pixels on gfx950 once the sine shrank to one instruction
@@ -50,6 +54,18 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     with open(RESOURCES, "w") as f:          # per-kernel VGPR / scratch / LDS report (tests/test_api_surface.py gates on it)
         f.write(parse_resource_remarks(r.stderr))
     return LIB
+
+
+def build_forced_wait_twin(force: bool = False) -> str:
+    deps = [os.path.join(CSRC, f) for f in SOURCES + _headers()] + [os.path.join(INCLUDE, "tha4_hip.h"), os.path.abspath(__file__)]
+    if not force and not _stale(TWIN, deps):
+        return TWIN
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-waitcnt-forcezero=1"] + DEVICE_FLAGS + \
+          ["-I", CSRC, "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", TWIN]
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed (forced-wait twin):\n" + r.stderr[-4000:])
+    return TWIN
 
 
 def parse_resource_remarks(stderr: str) -> str:

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 PMC1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"
 cd /tmp
 # ---- student, batch 32 ----
-SB="python $R/bench.py --batch 32 --characters lambda_00 --steps 24 --warmup 4 --cpu-seconds 0 --profile-frames 2 --settle-seconds 0"
+SB="python $R/bench.py --batch 32 --characters lambda_00 --steps 24 --warmup 4 --cpu-seconds 0 --profile-frames 2 --settle-seconds 0 --repeats 0"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pb32_stats -- $SB > $R/gpurun_out/pb32_stats.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc $PMC1 --output-format csv -d $R/gpurun_out/pb32_pmc1 -- $SB > $R/gpurun_out/pb32_pmc1.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pb32_fetch -- $SB > $R/gpurun_out/pb32_fetch.log 2>&1
@@ -31,5 +31,5 @@ cp $(ls gpurun_out/pfb8_stats/*/*kernel_stats.csv | head -1) gpurun_out/pfb8_ker
 grep "full model batch" gpurun_out/pfb8_stats.log > gpurun_out/pfb8_time_profiled.log
 rm -rf gpurun_out/pb32_stats gpurun_out/pb32_pmc1 gpurun_out/pb32_fetch gpurun_out/pb32_write gpurun_out/pfb8_stats gpurun_out/pfb8_pmc1 gpurun_out/pfb8_fetch gpurun_out/pfb8_write
 python tools/time_full.py --batch 8 --frames 20 > gpurun_out/pfb8_time.log 2>&1
-python bench.py --batch 32 --characters lambda_00 --steps 64 --warmup 8 --cpu-seconds 0 --profile-frames 20 > gpurun_out/pb32_bench.json 2>/dev/null
+python bench.py --batch 32 --characters lambda_00 --steps 64 --warmup 8 --cpu-seconds 0 --profile-frames 20 --repeats 0 > gpurun_out/pb32_bench.json 2>/dev/null
 tail -1 gpurun_out/pfb8_time.log; head -c 400 gpurun_out/pb32_bench.json; head -c 500 gpurun_out/student_b32_traffic.json; head -c 500 gpurun_out/full_b8_traffic.json
