@@ -462,6 +462,7 @@ struct tha4_full {
   FullModel model;
   bool decomposer_valid = false;
   int last_batch = 0;
+  int fault_policy = THA4_FAULT_REFUSE_NEXT;
   StreamOrder order;
   int* fault = nullptr;        // pinned host memory, device-visible: the kernels' sticky numeric-fault flag
 };
@@ -567,7 +568,7 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
     return fail(THA4_ERR_INVALID_ARGUMENT, "image_batch_stride must be 0 (shared) or >= 4*512*512");
   // sticky numeric-fault flag of EARLIER calls (no synchronisation: whatever has become visible by now; tha4_full_numeric_status
   // is the synchronous check).  Reported once, then cleared so that the caller can go on with sane inputs
-  if (*reinterpret_cast<volatile int*>(h->fault)) {
+  if (h->fault_policy == THA4_FAULT_REFUSE_NEXT && *reinterpret_cast<volatile int*>(h->fault)) {
     *reinterpret_cast<volatile int*>(h->fault) = 0;
     // the faulted call may be the one that filled the persistent eyebrow-decomposer outputs: they are not reused by anybody
     h->decomposer_valid = false;
@@ -591,6 +592,13 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
   HIP_TRY(hipGetLastError());
   h->decomposer_valid = true;
   h->last_batch = batch;
+  return THA4_OK;
+}
+
+int tha4_full_set_fault_policy(tha4_full* h, int policy) {
+  if (!h) return fail(THA4_ERR_INVALID_ARGUMENT, "handle must not be NULL");
+  if (policy != THA4_FAULT_REFUSE_NEXT && policy != THA4_FAULT_STATUS_ONLY) return fail(THA4_ERR_INVALID_ARGUMENT, "unknown fault policy");
+  h->fault_policy = policy;
   return THA4_OK;
 }
 

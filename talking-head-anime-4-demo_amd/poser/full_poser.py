@@ -162,6 +162,11 @@ class HipFullPoser(Poser):
     #: reproducibility, e.g. the sharded stream), "allow" re-creates quietly.
     regrow_policy = "warn"
 
+    #: how a numeric fault of an earlier call is delivered (tha4_full_set_fault_policy): "refuse_next" (default) - the next pose()
+    #: raises once and is not enqueued; "status_only" - pose() never refuses, `check_numeric_range()` is the only report (real-time
+    #: callers that poll it and cannot lose a frame).  pose() never synchronises: its outputs are unchecked until the check is called.
+    fault_policy = "refuse_next"
+
     #: the reference's content rule for the eyebrow-decomposer cache (mode_07.py:56-61), behind the identity / version rules:
     #: costs one device->host synchronisation per call whose identity key misses, like the reference pays on every call
     content_cache = False
@@ -192,6 +197,9 @@ class HipFullPoser(Poser):
         _capi.check(self._lib, st, "tha4_full_create_ex")
         del keep
         self._handle = handle
+        if self.fault_policy not in ("refuse_next", "status_only"):
+            raise _capi.Tha4Error(f"unknown fault_policy {self.fault_policy!r}")
+        _capi.check(self._lib, self._lib.tha4_full_set_fault_policy(handle, 1 if self.fault_policy == "status_only" else 0), "tha4_full_set_fault_policy")
 
     def _run(self, image: Tensor, pose: Tensor, wanted: List[int], image_changed: bool,
              image_version: Optional[int] = None, display=None):

@@ -171,6 +171,7 @@ def test_new_entry_points_validate_arguments(built):
     assert lib.tha4_student_set_weights(None, None) == -1
     assert lib.tha4_full_create_ex(None, 2, 0, 1, 3, 0, None) == -1
     assert lib.tha4_full_flags(None) == -1
+    assert lib.tha4_full_set_fault_policy(None, 0) == -1
     assert lib.tha4_full_num_networks(None) == -1
     # stateless image entry points refuse host pointers instead of launching on them
     import ctypes as C

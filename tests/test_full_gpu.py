@@ -404,6 +404,15 @@ def test_numeric_range_guard_and_regrow_policy(weights, golden_io, full_io):
     with pytest.raises(_capi.Tha4Error, match="numeric fault"):      # the next call reports the earlier call's fault
         p.pose(image, pose)
     p.free()
+    # fault_policy = "status_only": pose() never refuses a frame; the synchronous check is the only report
+    p = mode_07.create_poser_from_state_dicts(dev, bad, max_batch=1)
+    p.fault_policy = "status_only"
+    for _ in range(3):
+        p.pose(image, pose)
+        torch.cuda.synchronize()
+    with pytest.raises(_capi.Tha4Error, match="numeric fault"):
+        p.check_numeric_range()
+    p.free()
     # the same gain at 1e3 (staged values of O(1e3..1e4)) is inside the range: no flag, finite outputs
     ok = copy.deepcopy(weights)
     ok["face_morpher"]["downsample_blocks.0.1.weight"] = ok["face_morpher"]["downsample_blocks.0.1.weight"] * 1e3
