@@ -229,6 +229,7 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
  * host-visible memory.  tha4_full_pose returns THA4_ERR_NUMERIC_RANGE once, WITHOUT enqueueing work, when it finds the flag
  * set by an earlier call (it never synchronises, so the call that faulted itself returns THA4_OK); this function is the
  * synchronous check: synchronize != 0 waits for the handle's device first.  Both report-and-clear. */
+int tha4_full_numeric_status(tha4_full* h, int synchronize);
 /* How a numeric fault of an EARLIER call is delivered (ABI v4).  THA4_FAULT_REFUSE_NEXT (default): the next tha4_full_pose
  * returns THA4_ERR_NUMERIC_RANGE once without enqueueing that call (a caller that never polls still learns of the fault, at the
  * price of one refused frame).  THA4_FAULT_STATUS_ONLY: tha4_full_pose never refuses; the fault is reported through
@@ -237,7 +238,6 @@ int tha4_full_pose(tha4_full* h, const float* image_dev, int64_t image_batch_str
 #define THA4_FAULT_REFUSE_NEXT 0
 #define THA4_FAULT_STATUS_ONLY 1
 int tha4_full_set_fault_policy(tha4_full* h, int policy);
-int tha4_full_numeric_status(tha4_full* h, int synchronize);
 
 /* tha4_full_pose with the display epilogue of output 0 (the upscaler's merged frame) fused into the kernel that composes
  * it; `display` may be NULL (= tha4_full_pose).  With display->rgba8_dev set, outputs_dev may be all-NULL. */
