@@ -378,9 +378,10 @@ class FullModel {
         const TileGeom t = tile_geom(g0, th, tw, plan.pg, tmb, twl, table_bytes, 4);
         if (t.ok && t.efficiency > best_eff * 1.1f) { best_eff = t.efficiency; twl4 = twl; nw4 = true; tiles4 = t.tiles; }
       }
-      // only grids of more than one round (512 co-resident four-wave workgroups): on a single round the two workgroups of a CU start
-      // and end together and nothing overlaps (measured: batch 1 +-0, batch 8 +4-7 %)
-      const long min_wgs = tune_env("THA4_TILE_NW4_MIN_WGS") ? std::atol(tune_env("THA4_TILE_NW4_MIN_WGS")) : 2 * 512;
+      // grids that fill the chip with co-resident pairs: at least one full round (512 four-wave workgroups) on a handle built for one
+      // frame (+1.3 % steady on two of three same-box rounds, profiles/r04_raw/c12_ab.txt), two rounds otherwise (batch 8: +4-7 % with
+      // two rounds, -0.5 % when single-round grids join in)
+      const long min_wgs = tune_env("THA4_TILE_NW4_MIN_WGS") ? std::atol(tune_env("THA4_TILE_NW4_MIN_WGS")) : (max_batch == 1 ? 512 : 2 * 512);
       if (nw4 && (long)tiles4 * mtiles * max_batch < min_wgs) nw4 = false;
     }
     // fallbacks (1x1 convolutions): small maps (<= 32x32) one pixel group per workgroup with K split over its 4 waves
