@@ -167,8 +167,11 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (NW * PG * 16) >> twl;
   const int tiles_x = (a.tile_w + TWW - 1) >> twl;
   const int tiles_per_frame = tiles_x * ((a.tile_h + TWH - 1) / TWH);
-  const int n = blockIdx.x / tiles_per_frame;
-  const int tile = blockIdx.x % tiles_per_frame;
+  int cls = 0, bx = (int)blockIdx.x;                        // merged transposed convolution: the parity class is the slowest part of blockIdx.x
+  if (a.nclass > 1) { cls = bx / (a.batch * tiles_per_frame); bx -= cls * (a.batch * tiles_per_frame); }
+  const ConvClass cg = conv_class(a, cls, tiles_per_frame);
+  const int n = bx / tiles_per_frame;
+  const int tile = bx % tiles_per_frame;
   const int tile_y0 = (tile / tiles_x) * TWH, tile_x0 = (tile % tiles_x) << twl;
   const int mtile = blockIdx.y;
   const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (kPool ? a.in_h / 2 : a.in_h);
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   const int in_px = a.in_h * a.in_w;
   const int WW = a.win_w, NPX = a.win_h * a.win_w;
   const int PLANE = tile_plane_bytes(NPX);
-  const int vy0 = tile_y0 * a.in_stride + a.win_dy0, vx0 = tile_x0 * a.in_stride + a.win_dx0;
+  const int vy0 = tile_y0 * a.in_stride + cg.win_dy0, vx0 = tile_x0 * a.in_stride + cg.win_dx0;
 
   int cbtot = 0;
   for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   // normalisation folded into this kernel (FusedNorm): per-channel scale | shift table behind `red`
   float* tab_sc = red + NW * TMB * 16 * 2;
   float* tab_sh = tab_sc + (fused_table_floats(a) >> 1);
-  const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
+  const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)cls * a.w16_class_bytes + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
 
   // ---- per-lane output pixels ------------------------------------------------------------------
   int ly[PG], lx[PG], boff[PG];
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   // LDS offset of tap t inside the window, kept in lane t of one VGPR: the MFMA loop picks it with v_readlane instead of two
   // scalar loads from the argument block and an s_waitcnt lgkmcnt(0) (which also drains the LDS reads in flight) per tap
   const int tl = lane & (kMaxTaps - 1);
-  const int my_toff = ((a.tap_dy[tl] - a.win_dy0) * WW + (a.tap_dx[tl] - a.win_dx0)) * 16;
+  const int my_toff = ((conv_tap_dy(a, cls, tl) - cg.win_dy0) * WW + (conv_tap_dx(a, cls, tl) - cg.win_dx0)) * 16;
 
 #if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
   long long* stamps = (a.dbg && a.phase != 2 && blockIdx.z == 0) ? a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * 64 : nullptr;
@@ -466,7 +469,8 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
     // load rounds each) on partials written by a TMB = 4 phase 1
     const size_t stride_split = (size_t)a.batch * a.nb * tiles_per_frame * frag;      // wave-uniform strides (f32x4 units)
     const size_t stride_block = (size_t)tiles_per_frame * frag;
-    f32x4* part = reinterpret_cast<f32x4*>(a.partial) + (((size_t)n * a.nb + (size_t)mtile * TMB + mh * TMBW) * tiles_per_frame + tile) * frag +
+    f32x4* part = reinterpret_cast<f32x4*>(a.partial) + (size_t)cls * a.ksplit * stride_split +      // (merged classes: one partial image per class)
+                  (((size_t)n * a.nb + (size_t)mtile * TMB + mh * TMBW) * tiles_per_frame + tile) * frag +
                   (size_t)(pw * PG) * 64 + lane;        // this lane's fragment of this wave's first output block, split 0, pixel group 0
     if (a.phase == 1) {
 #pragma unroll
@@ -514,7 +518,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
     for (int pg = 0; pg < PG; ++pg) {
       if (!inside[pg]) continue;                            // ragged tile: position outside the map
       if (THA4_HOOK_TILE_EPILOGUE_BYPASS && acc[b][pg][0] != 1.2345e33f) continue;     // tuning builds only
-      const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
+      const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
       const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
       f32x4 v = acc[b][pg] * a.w16_inv_scale + bias;
       if (a.residual) {
@@ -561,7 +565,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
         s += red[((wv2 * TMB) * 16 + i) * 2 + 0];
         q += red[((wv2 * TMB) * 16 + i) * 2 + 1];
       }
-      float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + mtile * TMB) * 16 + i) * 2;
+      float* dst = a.stats + ((((size_t)n * a.stats_tiles + cg.stats_tile0 + tile) * a.nb + mtile * TMB) * 16 + i) * 2;
       dst[0] = s;
       dst[1] = q;
     }

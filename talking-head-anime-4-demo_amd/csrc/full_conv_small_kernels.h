@@ -53,14 +53,17 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   // all pixel tiles of one output block share that block's weights, so they are mapped to ONE XCD (block bo -> XCD
   // bo % 8) and every weight is fetched from HBM / MALL once per frame instead of once per XCD
   const int G = a.batch * tiles_per_frame;                 // workgroups per output block
+  int cls = 0, bx = (int)blockIdx.x;                        // merged transposed convolution: the parity class is the slowest grid dimension
+  if (a.nclass > 1) { cls = bx / (G * a.nb); bx -= cls * (G * a.nb); }
+  const ConvClass cg = conv_class(a, cls, tiles_per_frame);
   int bo, tl;
   if ((a.nb & 7) == 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bx & 7, slot = bx >> 3;
     bo = xcd + 8 * (slot / G);
     tl = slot % G;
   } else {
-    bo = blockIdx.x / G;
-    tl = blockIdx.x % G;
+    bo = bx / G;
+    tl = bx % G;
   }
   const int n = tl / tiles_per_frame;
   const int tile = tl % tiles_per_frame;
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   const int in_px = a.in_h * a.in_w;
   const int WW = a.win_w, NPX = a.win_h * a.win_w;
   const int PLANE = tile_plane_bytes(NPX);
-  const int vy0 = tile_y0 * a.in_stride + a.win_dy0, vx0 = tile_x0 * a.in_stride + a.win_dx0;
+  const int vy0 = tile_y0 * a.in_stride + cg.win_dy0, vx0 = tile_x0 * a.in_stride + cg.win_dx0;
 
   int cbtot = 0;
   for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
@@ -86,7 +89,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   char* wins = smem + ((tabf * 4 + 127) & ~127);
   char* win_hi = wins + wave * 8 * PLANE;
   char* win_lo = win_hi + 4 * PLANE;
-  const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)bo * NQ * a.ntaps * 2048 + lane * 16;
+  const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)cls * a.w16_class_bytes + (size_t)bo * NQ * a.ntaps * 2048 + lane * 16;
 
   // ---- per-lane output pixels ------------------------------------------------------------------
   int ly[PG], lx[PG], boff[PG];
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) acc[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int tapl = lane & (kMaxTaps - 1);                  // tap offsets in lane t of one VGPR (see conv_tile_kernel)
-  const int my_toff = ((a.tap_dy[tapl] - a.win_dy0) * WW + (a.tap_dx[tapl] - a.win_dx0)) * 16;
+  const int my_toff = ((conv_tap_dy(a, cls, tapl) - cg.win_dy0) * WW + (conv_tap_dx(a, cls, tapl) - cg.win_dx0)) * 16;
   auto mac_chunk = [&](int t0, int t1, const WChunk& w) {
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   const int out_px = a.out_h * a.out_w;
   constexpr bool kPrefetchRes = !(PG == 4 && kPool);       // (the one instantiation without a spare register keeps the load in the epilogue)
   auto load_residual = [&](int pg) -> f32x4 {
-    const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
+    const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
     if (a.res_mode == IN_DIRECT)
       return *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4);
     if (a.res_mode == IN_UP2) {                            // ResBlock x_resample = Upsample (unet.py:46): nearest
@@ -363,7 +366,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
 #pragma unroll
     for (int w2i = 1; w2i < kSmallWaves; ++w2i) s = s + red[(w2i * PG + pg) * 64 + lane];
     if (!inside[pg]) continue;                             // ragged tile: position outside the map
-    const int oy = (tile_y0 + ly[pg]) * a.out_sy + a.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + a.out_ox;
+    const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
     const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
     f32x4 v = s * a.w16_inv_scale + bias;
     if (a.residual) v = v + (kPrefetchRes ? resv[kPrefetchRes ? pg : 0] : load_residual(pg));
@@ -382,7 +385,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
       s = row16_sum(s, lane);
       q = row16_sum(q, lane);
       if (p == 0) {
-        float* dst = a.stats + ((((size_t)n * a.stats_tiles + a.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
+        float* dst = a.stats + ((((size_t)n * a.stats_tiles + cg.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
         dst[0] = s;
         dst[1] = q;
       }

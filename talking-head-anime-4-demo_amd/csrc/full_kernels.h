@@ -98,10 +98,34 @@ struct ConvArgs {
   int phase;             // 0: whole convolution; 1: partial products of K split blockIdx.z only; 2: reduce partials + epilogue
   FusedNorm fnorm;       // conv_tile_kernel / conv_small_kernel: normalisation of the tensor sources computed in the prologue
   int units_per_q;       // conv_small_kernel: tap ranges per K group (1, 2, 4 or 8: spreads few K groups over the 8 waves)
+  // conv_tile_kernel / conv_small_kernel: the four output-parity classes of a ConvTranspose2d(4, stride 2, padding 1) in ONE launch
+  // (round 4).  nclass = 4: the class is the slowest part of blockIdx.x; its taps, window origin, output offsets and statistics tiles
+  // follow from the class id (conv_class below = full_layout.h geom_convT4_s2), its weights are `w16_class_bytes` further on.  nclass <= 1:
+  // one class, geometry from the fields above.
+  int nclass;
+  long long w16_class_bytes;
 #ifdef THA4_PHASE_TIMING
   long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
 #endif
 };
+
+// Geometry of one launch class.  Merged transposed convolution (nclass = 4): class (py, px), tap t = 2a + b reads input (i + dd[py][a],
+// j + dd[px][b]) with dd = {{0, -1}, {1, 0}} and writes output (2i + py, 2j + px) - geom_convT4_s2 (full_layout.h, conv.py:164-177).
+struct ConvClass { int win_dy0, win_dx0, out_oy, out_ox, stats_tile0; };
+THA4_DEV int convt_delta(int parity, int ab) { return parity ? (ab ? 0 : 1) : (ab ? -1 : 0); }
+THA4_DEV ConvClass conv_class(const ConvArgs& a, int cls, int tiles_per_class) {
+  ConvClass c;
+  c.win_dy0 = a.win_dy0; c.win_dx0 = a.win_dx0; c.out_oy = a.out_oy; c.out_ox = a.out_ox; c.stats_tile0 = a.stats_tile0;
+  if (a.nclass == 4) {
+    const int py = cls >> 1, px = cls & 1;
+    c.win_dy0 = py ? 0 : -1; c.win_dx0 = px ? 0 : -1;
+    c.out_oy = py; c.out_ox = px;
+    c.stats_tile0 = cls * tiles_per_class;
+  }
+  return c;
+}
+THA4_DEV int conv_tap_dy(const ConvArgs& a, int cls, int t) { return a.nclass == 4 ? convt_delta(cls >> 1, (t >> 1) & 1) : a.tap_dy[t]; }
+THA4_DEV int conv_tap_dx(const ConvArgs& a, int cls, int t) { return a.nclass == 4 ? convt_delta(cls & 1, t & 1) : a.tap_dx[t]; }
 
 // 1 / (1 + e^-v) on the hardware transcendentals: v_exp_f32 (2^x, ~1 ulp) and v_rcp_f32 (1 ulp) - libm's expf plus an
 // IEEE division cost ~40 VALU instructions per element, which made the SiLU operand staging of the U-Net convolutions

@@ -401,7 +401,7 @@ class FullModel {
     }
     const int ksplit = tiled ? plan.ksplit : 1;
     if (tiled && ksplit > 1) {
-      partial_floats = std::max(partial_floats, (size_t)ksplit * mtiles * tiles * tmb * 8 * pg * 64 * 4);
+      partial_floats = std::max(partial_floats, (size_t)ksplit * mtiles * tiles * tmb * 8 * pg * 64 * 4 * (nclass == 4 ? 4 : 1));     // merged classes: one image each
     }
     const int conv_index = conv_counter++;
     if (std::getenv("THA4_DUMP_SCHEDULE"))
@@ -421,17 +421,45 @@ class FullModel {
     }
     size_t act_off = kNone;
     if (act_out) { std::vector<int> a(nb * 16, 0); for (int i = 0; i < cout; ++i) a[i] = (*act_out)[i]; act_off = add_param_i(a); }
-    for (int cls = 0; cls < nclass; ++cls) {
+    // The four output-parity classes of a transposed convolution run as ONE launch of conv_tile_kernel / conv_small_kernel (round 4: the
+    // class is the slowest grid dimension, its geometry follows from the class id in the kernel, the four weight images are contiguous):
+    // 4 launches -> 1, 8 -> 2 with a K split.  The exact-fp32 kernels keep one launch per class.
+    const bool merge_classes = nclass == 4 && (small || tiled) && !tune_env("THA4_NO_CLASS_MERGE");
+    const int launch_classes = merge_classes ? 1 : nclass, grid_classes = merge_classes ? 4 : 1;
+    auto pack16_classes = [&](const ConvGeom& g0c, int tmb_pack, float* inv, size_t* class_bytes) {
+      std::vector<char> all = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g0c, segs, tmb_pack, inv);
+      *class_bytes = all.size();
+      if (merge_classes)
+        for (int c2 = 1; c2 < 4; ++c2) {
+          float inv2 = 1.f;
+          const std::vector<char> more = pack_conv_weight16(weight.data, cout, cin, k, k, true, geom_convT4_s2(c2 >> 1, c2 & 1), segs, tmb_pack, &inv2);
+          if (more.size() != *class_bytes || inv2 != *inv) { if (error.empty()) error = "internal: parity classes of a transposed convolution pack differently"; }
+          all.insert(all.end(), more.begin(), more.end());
+        }
+      return all;
+    };
+    for (int cls = 0; cls < launch_classes; ++cls) {
       ConvGeom g = kind == K_SAME3 ? geom_conv_same(3) : kind == K_SAME1 ? geom_conv_same(1)
                  : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1);
       size_t w_off = 0, lds = 0;
       int cq = 1;
       ConvArgs a{};
+      a.nclass = grid_classes;
       if (small) {
         const SmallPlan sg = small_geom(g, th, tw, sp.pg, sp.tw_log2);
         if (!sg.ok || sg.tiles != sp.tiles) { if (error.empty()) error = "small conv geometry differs between parity classes"; return FTensor(); }
+        if (merge_classes)
+          for (int c2 = 1; c2 < 4; ++c2) {
+            const SmallPlan s2 = small_geom(geom_convT4_s2(c2 >> 1, c2 & 1), th, tw, sp.pg, sp.tw_log2);
+            if (!s2.ok || s2.tiles != sg.tiles || s2.win_h != sg.win_h || s2.win_w != sg.win_w || s2.lds != sg.lds) {
+              if (error.empty()) error = "small conv geometry differs between parity classes";
+              return FTensor();
+            }
+          }
         float inv = 1.f;
-        const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, 1, &inv);
+        size_t class_bytes = 0;
+        const std::vector<char> p16 = pack16_classes(g, 1, &inv, &class_bytes);
+        a.w16_class_bytes = (long long)class_bytes;
         w_off = add_param(p16.data(), p16.size());
         lds = ((table_bytes + 127) & ~(size_t)127) + sg.lds;
         a.w16_inv_scale = inv; a.wg_tw_log2 = sg.tw_log2; a.win_h = sg.win_h; a.win_w = sg.win_w;
@@ -444,8 +472,20 @@ class FullModel {
         a.w16_inv_scale = inv;
       } else if (tiled) {
         const TileGeom tg = nw4 ? tile_geom(g, th, tw, pg, tmb, twl4, table_bytes, 4) : tile_geom(g, th, tw, pg, tmb, plan.geom.tw_log2, table_bytes);
+        if (merge_classes)
+          for (int c2 = 1; c2 < 4; ++c2) {
+            const ConvGeom g2 = geom_convT4_s2(c2 >> 1, c2 & 1);
+            const TileGeom t2 = nw4 ? tile_geom(g2, th, tw, pg, tmb, twl4, table_bytes, 4) : tile_geom(g2, th, tw, pg, tmb, plan.geom.tw_log2, table_bytes);
+            if (!t2.ok || t2.tiles != tg.tiles || t2.win_h != tg.win_h || t2.win_w != tg.win_w || t2.taps_per_chunk != tg.taps_per_chunk ||
+                t2.ring_slots != tg.ring_slots || t2.win_buffers != tg.win_buffers || t2.lds != tg.lds) {
+              if (error.empty()) error = "conv tile geometry differs between parity classes";
+              return FTensor();
+            }
+          }
         float inv = 1.f;
-        const std::vector<char> p16 = pack_conv_weight16(weight.data, cout, cin, k, k, kind == K_CONVT, g, segs, tmb, &inv);
+        size_t class_bytes = 0;
+        const std::vector<char> p16 = pack16_classes(g, tmb, &inv, &class_bytes);
+        a.w16_class_bytes = (long long)class_bytes;
         w_off = add_param(p16.data(), p16.size());
         lds = tg.lds;
         a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
@@ -509,7 +549,7 @@ class FullModel {
         c.stats = outc.stats_tiles ? Wk(outc.stats_off) : nullptr;
         c.batch = f.batch;
         if (small) {
-          dispatch_small(pg, in_mode, c, dim3(f.batch * tiles * nb, 1, 1), lds, f.stream);
+          dispatch_small(pg, in_mode, c, dim3(f.batch * tiles * nb * grid_classes, 1, 1), lds, f.stream);
         } else if (point) {
           dispatch_point(tmb, pg, c, dim3(f.batch * tiles * mtiles, 1, 1), lds, f.stream);
         } else if (splitk) {
@@ -520,11 +560,11 @@ class FullModel {
         } else if (tiled) {
           if (ksplit > 1) {
             c.phase = 1;
-            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, ksplit), lds, f.stream);
+            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles * grid_classes, mtiles, ksplit), lds, f.stream);
             c.phase = 2;                       // one output block per workgroup: 4x the workgroups, a quarter of the load rounds each
-            dispatch_tile(1, pg, in_mode, c, dim3(f.batch * tiles, mtiles * tmb, 1), lds, f.stream);
+            dispatch_tile(1, pg, in_mode, c, dim3(f.batch * tiles * grid_classes, mtiles * tmb, 1), lds, f.stream);
           } else {
-            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles, 1), lds, f.stream, nw4);
+            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles * grid_classes, mtiles, 1), lds, f.stream, nw4);
           }
         } else {
           dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);

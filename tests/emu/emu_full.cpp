@@ -176,7 +176,21 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   if (c1 > 0) segs.push_back({c0, c1});
   const int mtiles = (nb + tmb - 1) / tmb;
   if (mtiles * tmb != nb) return -3;
-  for (int cls = 0; cls < nclass; ++cls) {
+  // transposed convolution on conv_tile_kernel / conv_small_kernel: the four parity classes in ONE launch, like FullModel::conv issues them
+  const bool merge_classes = nclass == 4 && (small || tiled);
+  const int launch_classes = merge_classes ? 1 : nclass, grid_classes = merge_classes ? 4 : 1;
+  auto pack16_classes = [&](const ConvGeom& g0c, int tmb_pack, float* inv, size_t* class_bytes) {
+    std::vector<char> all = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g0c, segs, tmb_pack, inv);
+    *class_bytes = all.size();
+    if (merge_classes)
+      for (int c2 = 1; c2 < 4; ++c2) {
+        float inv2 = 1.f;
+        const std::vector<char> more = pack_conv_weight16(weight, cout, cin, 4, 4, true, geom_convT4_s2(c2 >> 1, c2 & 1), segs, tmb_pack, &inv2);
+        all.insert(all.end(), more.begin(), more.end());
+      }
+    return all;
+  };
+  for (int cls = 0; cls < launch_classes; ++cls) {
     ConvGeom g = kind == 0 ? geom_conv_same(k) : (kind == 1 ? geom_conv4_s2() : geom_convT4_s2(cls >> 1, cls & 1));
     std::vector<float> P = pack_conv_weight(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb);
     ConvArgs a{};
@@ -207,6 +221,8 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     a.act_out = act_out ? dA : nullptr; a.out = dO; a.stats = dST;
     a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
     a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
+    a.nclass = grid_classes;
+    size_t class_bytes = 0;
     std::vector<char> P16;
     std::vector<float> partial;
     TileGeom tg;
@@ -215,7 +231,8 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       sg = small_geom(g, th, tw, spg, tw_log2);
       if (!sg.ok) return -4;
       float inv = 1.f;
-      P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, 1, &inv);
+      P16 = pack16_classes(g, 1, &inv, &class_bytes);
+      a.w16_class_bytes = (long long)class_bytes;
       a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = sg.tw_log2; a.win_h = sg.win_h; a.win_w = sg.win_w;
       a.win_dy0 = sg.dy0; a.win_dx0 = sg.dx0;
       const int nq = (cb0 + cb1 + 1) / 2;
@@ -224,10 +241,11 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     if (tiled) {
       tg = tile_geom(g, th, tw, tpg, tmb, tw_log2, table_bytes, tnw);
       if (!tg.ok) return -4;
-      partial.assign((size_t)ksplit * n * mtiles * tg.tiles * tmb * 8 * tpg * 64 * 4, 0.f);
+      partial.assign((size_t)ksplit * n * mtiles * tg.tiles * tmb * 8 * tpg * 64 * 4 * grid_classes, 0.f);
       a.partial = M.up(partial); a.ksplit = ksplit;
       float inv = 1.f;
-      P16 = pack_conv_weight16(weight, cout, cin, kind == 0 ? k : 4, kind == 0 ? k : 4, kind == 2, g, segs, tmb, &inv);
+      P16 = pack16_classes(g, tmb, &inv, &class_bytes);
+      a.w16_class_bytes = (long long)class_bytes;
       a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
       a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots; a.win_buffers = tg.win_buffers;
     }
@@ -245,7 +263,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     const size_t lds = small ? ((table_bytes + 127) & ~(size_t)127) + sg.lds : tiled ? tg.lds : splitk ? (size_t)4 * tmb * 1024 : 2 * (size_t)chunk_quads * g.ntaps * tmb * 1024 + 4 * tmb * 16 * 2 * sizeof(float);
     const int phases = tiled && ksplit > 1 ? 2 : 1;
     if (small) {
-      const dim3 sgrid(n * tiles_per_class * nb, 1, 1);
+      const dim3 sgrid(n * tiles_per_class * nb * grid_classes, 1, 1);
 #define RUNS(PGV)                                                                                            \
   if (spg == PGV) {                                                                                          \
     if (in_mode == IN_DIRECT) THA4_RUN((conv_small_kernel<PGV, IN_DIRECT>), sgrid, kSmallThreads, lds, a);   \
@@ -259,7 +277,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     for (int ph = 0; ph < phases; ++ph) {
     a.phase = phases == 1 ? 0 : ph + 1;
     const int run_tmb = a.phase == 2 ? 1 : tmb;          // phase 2 runs one output block per workgroup
-    dim3 grid(n * tiles_per_class, a.phase == 2 ? nb : mtiles, a.phase == 1 ? ksplit : 1);
+    dim3 grid(n * tiles_per_class * (tiled ? grid_classes : 1), a.phase == 2 ? nb : mtiles, a.phase == 1 ? ksplit : 1);
 #define RUN(TM, PGV)                                                                                        \
   if (!tiled && !splitk && tmb == TM && pg == PGV) {                                                        \
     if (in_mode == IN_DIRECT) THA4_RUN((conv_mfma_kernel<TM, PGV, IN_DIRECT>), grid, 256, lds, a);          \
