@@ -505,41 +505,87 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
 
   THA4_CSTAMP();                                           // K loop (and split-K reduction) done
   // ---- epilogue: 1/scale, bias, residual, activation, store, deterministic per-tile statistics ----
+  // Three passes (round 4): every residual load of the tile goes out first, then the values are finished in the accumulators, then ALL
+  // stores are issued back to back.  The one-fragment-at-a-time form (rounds 1-3) put a load - residual, activation codes - between
+  // consecutive stores, and on gfx9 a load's s_waitcnt vmcnt also waits for every older STORE: the 16 fragments of a <4,4> tile went out as
+  // 16 dependent store round trips (32.8 k cycles between the last MFMA and the last store in the in-kernel stamps).  Same arithmetic
+  // per element, same order of the statistics' additions: bit-identical outputs.
   const int out_px = a.out_h * a.out_w;
   float ssum[TMBW][4], ssq[TMBW][4];
+  size_t offs[TMBW][PG];
 #pragma unroll
   for (int b = 0; b < TMBW; ++b) {
     const int bo = mtile * TMB + mh * TMBW + b;
-    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
+      offs[b][pg] = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
+    }
+  }
+  if (a.residual) {                                        // pass 1: residual values of every fragment requested together
+    f32x4 res[TMBW][PG];
+#pragma unroll
+    for (int b = 0; b < TMBW; ++b) {
+      const int bo = mtile * TMB + mh * TMBW + b;
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        res[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!inside[pg]) continue;                          // ragged tile: position outside the map
+        const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
+        if (a.res_mode == IN_DIRECT) {
+          res[b][pg] = *reinterpret_cast<const f32x4*>(a.residual + offs[b][pg]);
+        } else if (a.res_mode == IN_UP2) {      // ResBlock x_resample = Upsample (unet.py:46): nearest
+          const int rw = a.out_w >> 1, rpx = out_px >> 2;
+          res[b][pg] = *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
+        } else {                                // x_resample = Downsample = AvgPool2d(2,2) (unet.py:58)
+          const int rw = a.out_w * 2;
+          const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
+          res[b][pg] = ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
+                        (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < TMBW; ++b) {
+      const int bo = mtile * TMB + mh * TMBW + b;
+      f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[b][pg] = (acc[b][pg] * a.w16_inv_scale + bias) + res[b][pg];
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < TMBW; ++b) {
+      const int bo = mtile * TMB + mh * TMBW + b;
+      f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[b][pg] = acc[b][pg] * a.w16_inv_scale + bias;
+    }
+  }
+  if (a.act_out) {                                         // head blocks only: per-channel output activations (codes depend on the block, not on the pixel)
+#pragma unroll
+    for (int b = 0; b < TMBW; ++b) {
+      const int bo = mtile * TMB + mh * TMBW + b;
+      int codes[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) codes[j] = a.act_out[bo * 16 + g4 + j];
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b][pg][j] = apply_act(acc[b][pg][j], codes[j]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < TMBW; ++b) {                         // pass 3: stores back to back + the statistics of the positions inside the map
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ssum[b][j] = 0.f; ssq[b][j] = 0.f; }
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       if (!inside[pg]) continue;                            // ragged tile: position outside the map
       if (THA4_HOOK_TILE_EPILOGUE_BYPASS && acc[b][pg][0] != 1.2345e33f) continue;     // tuning builds only
-      const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
-      const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
-      f32x4 v = acc[b][pg] * a.w16_inv_scale + bias;
-      if (a.residual) {
-        if (a.res_mode == IN_DIRECT) {
-          v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
-        } else if (a.res_mode == IN_UP2) {      // ResBlock x_resample = Upsample (unet.py:46): nearest
-          const int rw = a.out_w >> 1, rpx = out_px >> 2;
-          v = v + *reinterpret_cast<const f32x4*>(a.residual + (((size_t)n * a.nb + bo) * rpx + (size_t)(oy >> 1) * rw + (ox >> 1)) * 16 + g4);
-        } else {                                // x_resample = Downsample = AvgPool2d(2,2) (unet.py:58)
-          const int rw = a.out_w * 2;
-          const float* r0 = a.residual + (((size_t)n * a.nb + bo) * ((size_t)out_px * 4) + (size_t)(2 * oy) * rw + 2 * ox) * 16 + g4;
-          const f32x4 r = ((*reinterpret_cast<const f32x4*>(r0) + *reinterpret_cast<const f32x4*>(r0 + 16)) +
-                           (*reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16) + *reinterpret_cast<const f32x4*>(r0 + (size_t)rw * 16 + 16))) * 0.25f;
-          v = v + r;
-        }
-      }
-      if (a.act_out) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
-      }
-      *reinterpret_cast<f32x4*>(a.out + off) = v;
+      const f32x4 v = acc[b][pg];
+      *reinterpret_cast<f32x4*>(a.out + offs[b][pg]) = v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ssum[b][j] += v[j]; ssq[b][j] = fmaf(v[j], v[j], ssq[b][j]); }
     }
