@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
           red[((pw * TMB + mh * TMBW + b) * 16 + g4 + j) * 2 + 1] = q;
         }
       }
-    __syncthreads();
+    THA4_BARRIER_LDS();        // LDS only: the output stores above stay in flight (a full __syncthreads would wait for every store's acknowledgement)
     for (int i = tid; i < TMB * 16; i += kThreads) {
       float s = 0.f, q = 0.f;
       for (int wv2 = 0; wv2 < NW; ++wv2) {

@@ -202,25 +202,49 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: 1/scale, bias, residual, activation, store, deterministic per-tile moments ----------------------------
+  // three passes like conv_tile_kernel's epilogue (round 4): residual loads together, values, then the stores back to back - a load between
+  // two stores makes its s_waitcnt vmcnt wait for the older store as well (gfx9 counts both in vmcnt)
   float ssum[TMB][4], ssq[TMB][4];
+  size_t offs[TMB][PG];
+  f32x4 res[TMB][PG];
+#pragma unroll
+  for (int b = 0; b < TMB; ++b)
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      offs[b][pg] = (((size_t)n * a.nb + mtile * TMB + b) * px + pix[pg]) * 16 + g4;
+      res[b][pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.residual && inside[pg]) res[b][pg] = *reinterpret_cast<const f32x4*>(a.residual + offs[b][pg]);
+    }
 #pragma unroll
   for (int b = 0; b < TMB; ++b) {
     const int bo = mtile * TMB + b;
     f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+    int codes[4] = {0, 0, 0, 0};
+    if (a.act_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) codes[j] = a.act_out[bo * 16 + g4 + j];
+    }
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      f32x4 v = acc[b][pg] * a.w16_inv_scale + bias;
+      if (a.residual) v = v + res[b][pg];
+      if (a.act_out) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], codes[j]);
+      }
+      acc[b][pg] = v;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < TMB; ++b) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ssum[b][j] = 0.f; ssq[b][j] = 0.f; }
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       if (!inside[pg]) continue;                           // ragged last tile
-      const size_t off = (((size_t)n * a.nb + bo) * px + pix[pg]) * 16 + g4;
-      f32x4 v = acc[b][pg] * a.w16_inv_scale + bias;
-      if (a.residual) v = v + *reinterpret_cast<const f32x4*>(a.residual + off);
-      if (a.act_out) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
-      }
-      *reinterpret_cast<f32x4*>(a.out + off) = v;
+      const f32x4 v = acc[b][pg];
+      *reinterpret_cast<f32x4*>(a.out + offs[b][pg]) = v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ssum[b][j] += v[j]; ssq[b][j] = fmaf(v[j], v[j], ssq[b][j]); }
     }
@@ -238,7 +262,7 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
           red[((wave * TMB + b) * 16 + g4 + j) * 2 + 1] = q;
         }
       }
-    __syncthreads();
+    THA4_BARRIER_LDS();        // LDS only: the output stores above stay in flight (a full __syncthreads would wait for every store's acknowledgement)
     for (int i = tid; i < TMB * 16; i += kPointThreads) {
       float s = 0.f, q = 0.f;
       for (int w2 = 0; w2 < kPointWaves; ++w2) {
