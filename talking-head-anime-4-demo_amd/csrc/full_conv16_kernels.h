@@ -149,6 +149,7 @@ THA4_DEV int fused_table_floats(const ConvArgs& a) {      // 2 x padded concaten
 // slot (HW_ID.TG_ID, 3k-40k cycles) measured neutral to negative and is not in the code (profiles/r04_full_conv_tile_reading.md).
 template <int TMB, int PG, int INMODE, int MSW = 1, int NW = kTileWaves>
 __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2) conv_tile_kernel(ConvArgs a) {      // (threads, waves per SIMD)
+  warm_kernarg<(int)sizeof(ConvArgs)>();
   static_assert(MSW == 1 || (MSW == 2 && TMB % 2 == 0), "the block split needs an even block count");
   static_assert(NW == kTileWaves || (NW == kTileWavesHalf && MSW == 1), "four or eight pixel-slot waves");
   constexpr bool kPool = INMODE == IN_POOL2;

@@ -35,6 +35,7 @@ inline bool point_act_supported(int act) { return act == ACT_NONE || act == ACT_
 
 template <int TMB, int PG>
 __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
+  warm_kernarg<(int)sizeof(ConvArgs)>();
   constexpr int D = kPointD;
   constexpr int SLOT = D * TMB * 2048;
   constexpr int GL = SLOT / 1024 / kPointWaves;            // global_load_lds instructions per wave and chunk

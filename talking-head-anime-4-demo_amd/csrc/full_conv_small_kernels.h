@@ -29,6 +29,7 @@ constexpr int kSmallTapChunk = 3;     // taps per register-resident weight chunk
 
 template <int PG, int INMODE>
 __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
+  warm_kernarg<(int)sizeof(ConvArgs)>();
   constexpr bool kPool = INMODE == IN_POOL2;
   constexpr int KI = kSmallMaxItems, TC = kSmallTapChunk;
   THA4_DYN_LDS(smem);

@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(64) pose_pad_kernel(const float* pose, float* 
 
 // stage 1 input: image[:, :, 64:192, 192:320] -> C16 (4 real channels)                                (mode_07.py:74)
 __global__ void __launch_bounds__(256) crop_eyebrow_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 128, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= S * S) return;
   const int y = idx / S, x = idx % S;
@@ -102,6 +103,7 @@ __global__ void __launch_bounds__(256) crop_eyebrow_kernel(ImgArgs a) {
 // out: 0 eyebrow_layer, 1 eb_alpha, 2 eb_colour, 3 background_layer, 4 bg_alpha, 5 bg_colour  (all [B][C][128][128])
 // c16_out: combiner input = cat([background_layer, eyebrow_layer])                      (eyebrow_morphing_combiner_00.py:48)
 __global__ void __launch_bounds__(256) decomposer_tail_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 128, P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
@@ -133,6 +135,7 @@ __global__ void __launch_bounds__(256) decomposer_tail_kernel(ImgArgs a) {
 // in0 = eyebrow_layer (dec out 0), in1 = background_layer (dec out 3), both [B][4][128][128].
 // out: 0 eyebrow_image, 1 combine_alpha, 2 eyebrow_image_no_combine_alpha, 3 morphed, 4 alpha, 5 colour, 6 warped, 7 grid
 __global__ void __launch_bounds__(256) combiner_tail_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 128, P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
@@ -168,6 +171,7 @@ __global__ void __launch_bounds__(256) combiner_tail_kernel(ImgArgs a) {
 // stage 3 input (mode_07.py:85-90): image[:, :, 32:224, 160:352] with [32:160, 32:160] <- combiner output `sel`.
 // in0 = that combiner output [B][4][128][128].  out[0] = face input NCHW [B][4][192][192]; c16_out = same in C16.
 __global__ void __launch_bounds__(256) face_input_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 192, P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
@@ -189,6 +193,7 @@ __global__ void __launch_bounds__(256) face_input_kernel(ImgArgs a) {
 // in0 = face input NCHW [B][4][192][192].
 // out: 0 output_image, 1 eye_alpha, 2 eye_colour, 3 iris_mouth_image_1, 4 iris_alpha, 5 iris_colour, 6 iris_mouth_image_0, 7 grid
 __global__ void __launch_bounds__(256) face_tail_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 192, P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
@@ -219,6 +224,7 @@ __global__ void __launch_bounds__(256) face_tail_kernel(ImgArgs a) {
 // mode_07.py:93-103: face_morphed_full = image with [32:224, 160:352] <- face output (in0, [B][4][192][192]);
 // out[0] = face_morphed_full NCHW [B][4][512][512]
 __global__ void __launch_bounds__(256) paste_face_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 512, P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
@@ -235,6 +241,7 @@ __global__ void __launch_bounds__(256) paste_face_kernel(ImgArgs a) {
 // face_morphed_half = bilinear 512 -> 256, align_corners=False (= mean of the 2x2 window).  in0 = full NCHW.
 // out[0] = half NCHW [B][4][256][256], c16_out = half in C16 (body morpher input).
 __global__ void __launch_bounds__(256) half_image_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 256, P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
@@ -257,6 +264,7 @@ __global__ void __launch_bounds__(256) half_image_kernel(ImgArgs a) {
 // out: 0 merged, 1 alpha, 2 warped, 3 grid, 4 direct
 template <int S>
 __global__ void __launch_bounds__(256) unet_tail_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
@@ -295,6 +303,7 @@ __global__ void __launch_bounds__(256) unet_tail_kernel(ImgArgs a) {
 // in1 = body merged [B][4][256][256], in2 = body grid [B][2][256][256].
 // c16_out channels: 0-3 rest | 4-7 bilinear-up(merged) | 8-11 warp(rest, up(grid)) | 12-13 up(grid) | 14-15 zero
 __global__ void __launch_bounds__(256) upscaler_input_kernel(ImgArgs a) {
+  warm_kernarg<(int)sizeof(ImgArgs)>();
   const int S = 512, P = S * S, idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;

@@ -202,6 +202,7 @@ struct RawFrag {
 // (over the batch), blockIdx.y = output-channel tile.
 template <int TMB, int PG, int INMODE>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+  warm_kernarg<(int)sizeof(ConvArgs)>();
   constexpr int NV = INMODE == IN_POOL2 ? 4 : 1;
   using Raw = RawFrag<NV>;
   THA4_DYN_LDS(smem);
@@ -438,6 +439,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int TMB, int INMODE>
 __global__ void __launch_bounds__(256) conv_splitk_kernel(ConvArgs a) {
+  warm_kernarg<(int)sizeof(ConvArgs)>();
   constexpr int NV = INMODE == IN_POOL2 ? 4 : 1;
   THA4_DYN_LDS(smem);
   const int lane = threadIdx.x & 63;
@@ -623,6 +625,7 @@ THA4_DEV void instance_norm_from_moments(const FusedInstanceNorm& f, int n, int 
 }
 
 __global__ void __launch_bounds__(256) affine_add_kernel(AffineAddArgs k) {
+  warm_kernarg<(int)sizeof(AffineAddArgs)>();
   THA4_DYN_LDS(smem);                                      // 256 B: fused path: scale_a | shift_a | scale_b | shift_b of this workgroup's channel block
   float (*tab)[16] = reinterpret_cast<float (*)[16]>(smem);
   const size_t quads = (size_t)k.cb * k.px * 4;
@@ -707,6 +710,7 @@ inline int norm_channels_per_block(int ctot, int channels, int groups) {
   return cpb < ctot ? cpb : ctot;
 }
 __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a) {
+  warm_kernarg<(int)sizeof(NormArgs)>();
   THA4_DYN_LDS(smem);
   const int n = blockIdx.x;
   const int c0 = a.cb[0] * 16;
@@ -809,6 +813,7 @@ struct GemvArgs {
 };
 
 __global__ void __launch_bounds__(256) gemv_kernel(GemvArgs a) {
+  warm_kernarg<(int)sizeof(GemvArgs)>();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n = blockIdx.y;
@@ -849,6 +854,7 @@ constexpr int kAttnMaxKeys = 256 / kAttnSlices;  // keys per slice held in regis
 // against its query, takes the slice maximum, accumulates exp-weighted values, and the 8 slices of a query are merged
 // with lane shuffles (max first, then one rescale per slice) - a fixed order.
 __global__ void __launch_bounds__(256) attention_kernel(AttnArgs a) {
+  warm_kernarg<(int)sizeof(AttnArgs)>();
   THA4_DYN_LDS(smem);
   constexpr int CH = kAttnHeadDim, Q4 = CH / 4;
   const int L = a.tokens;

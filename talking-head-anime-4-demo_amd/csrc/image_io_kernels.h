@@ -59,6 +59,7 @@ struct DisplayArgs {
 };
 
 __global__ void __launch_bounds__(256) display_rgba8_kernel(DisplayArgs a) {
+  warm_kernarg<(int)sizeof(DisplayArgs)>();
   const int i = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (i >= a.pixels) return;
   const float* f = a.frames + (size_t)n * 4 * a.pixels + i;
@@ -80,6 +81,7 @@ struct IngestArgs {
 };
 
 __global__ void __launch_bounds__(256) ingest_rgba8_kernel(IngestArgs a) {
+  warm_kernarg<(int)sizeof(IngestArgs)>();
   const int i = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (i >= a.pixels) return;
   const uchar4 v = reinterpret_cast<const uchar4*>(a.rgba)[(size_t)n * a.pixels + i];

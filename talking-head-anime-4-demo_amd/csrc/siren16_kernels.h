@@ -386,6 +386,7 @@ THA4_DEV void face16_body(const StudentDev& d, char* smem, const WaveCtx& w) {
 
 template <int NS, int MS, int PG, int CQ>
 __global__ void __launch_bounds__(NS* MS * 64) face16_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
   THA4_DYN_LDS(smem);
   face16_body<NS, MS, PG, CQ>(d, smem, wave_ctx<typename Face16Cfg<NS, MS, PG, CQ>::G>());
 }
@@ -426,6 +427,7 @@ THA4_DEV void level0_16_body(const StudentDev& d, char* smem, const WaveCtx& w) 
 
 template <int NS, int MS, int PG, int HBA, int CQB>
 __global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
   THA4_DYN_LDS(smem);
   level0_16_body<NS, MS, PG, HBA, CQB>(d, smem, wave_ctx<typename Level016Cfg<NS, MS, PG, HBA, CQB>::G>());
 }
@@ -436,6 +438,7 @@ __global__ void __launch_bounds__(NS* MS * 64) level0_16_kernel(StudentDev d) {
 // workgroups of this launch; both bodies use the same 512-thread geometry.
 template <int FNS, int FMS, int FPG, int FCQ, int NS, int MS, int PG, int HBA, int CQB>
 __global__ void __launch_bounds__(NS* MS * 64) front16_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
   static_assert(FNS * FMS == NS * MS, "face and level 0 must use the same workgroup size");
   THA4_DYN_LDS(smem);
   const int nl0 = d.front_l0_blocks;
@@ -462,6 +465,7 @@ struct Level116Cfg {
 
 template <int NS, int MS, int PG, int CQA, int CQB, int HBA = 1>
 __global__ void __launch_bounds__(NS* MS * 64) level1_16_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
   using Cfg = Level116Cfg<NS, MS, PG, CQA, CQB, HBA>;
   using G = typename Cfg::G;
   constexpr int S = 256, NPIX = S * S;
@@ -540,6 +544,7 @@ struct Level216Cfg {
 
 template <int NS, int MS, int PG, int CQ>
 __global__ void __launch_bounds__(NS* MS * 64) level2_16_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
   using G = typename Level216Cfg<NS, MS, PG, CQ>::G;
   static_assert(MS == 1, "level 2 keeps whole rows per wave");
   constexpr int S = kImg, NPIX = S * S;
@@ -661,6 +666,7 @@ struct Level2PCfg {
 
 template <int WAVES, int SPW, int PG>
 __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
   using Cfg = Level2PCfg<WAVES, SPW, PG>;
   static_assert(SPW >= WAVES, "every wave takes its first strip statically");
   using G = typename Cfg::G;

@@ -193,6 +193,24 @@ THA4_DEV float row16_sum(float v, int lane) {                   // the device's 
 THA4_DEV int lane_pick(int v, int src_lane) { return (int)emu::shfl((float)v, src_lane); }       // |v| < 2^24: exact in fp32
 #endif
 
+// Kernel arguments: the argument block of a launch sits in device memory the host has just written - nothing on the chip holds it.  The compiler
+// reads a by-value argument struct where it first needs each field: fifteen `s_load ... s_waitcnt lgkmcnt(0)` rounds in conv_small_kernel's prologue,
+// seven of them the first touch of a 64-byte line, i.e. seven DEPENDENT cold misses (in-kernel stamps: 1.4 - 3.2 us between a workgroup's
+// entry and its first vector-memory request; profiles/r04_full_conv_tile_reading.md, section 10).  warm_kernarg() touches every line of the block at the
+// top of the kernel - one scalar load per line, all in flight together, one wait: ONE miss latency, after which every argument read hits the scalar
+// cache.  No effect on results.  THA4_NO_KERNARG_WARM builds without it (A/B).
+template <int BYTES>
+THA4_DEV void warm_kernarg() {
+#if !defined(THA4_EMU) && !defined(THA4_NO_KERNARG_WARM)
+  typedef const int __attribute__((address_space(4))) * kargp;
+  const kargp kp = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
+  int t = kp[(BYTES - 1) / 4];
+#pragma unroll
+  for (int i = 0; i < (BYTES + 63) / 64; ++i) t |= kp[i * 16];
+  asm volatile("" ::"s"(t));
+#endif
+}
+
 // fp16 hi/lo split of a PAIR of fp32 values: v = hi + lo with hi = fp16(v), lo = fp16(v - hi).  One v_cvt_pk_f16_f32 for both hi halves
 // and one v_fma_mix per lo half (the f16 -> f32 conversion of hi rides inside the FMA): 3-4 instructions per pair where the plain
 // expression `lo = fp16(v - float(hi))` compiles to 8 (two v_cvt_f16_f32, two v_cvt_f32_f16, two v_sub_f32, two packing converts).  The
