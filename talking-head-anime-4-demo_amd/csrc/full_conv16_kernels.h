@@ -201,6 +201,27 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   float* tab_sc = red + NW * TMB * 16 * 2;
   float* tab_sh = tab_sc + (fused_table_floats(a) >> 1);
   const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)cls * a.w16_class_bytes + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
+  auto fetch = [&](int chunk, int slot) {                  // chunk = K group * ntc + chunk of the group
+    const int cq = chunk / ntc, ct = chunk - cq * ntc;
+    const int t0 = ct * a.taps_per_chunk, nt = min(a.taps_per_chunk, a.ntaps - t0);
+    const char* src = gw + ((size_t)cq * a.ntaps + t0) * TMB * 2048;
+    char* dst = ring + slot * slot_bytes;
+    const int pieces = nt * TMB * 2;
+    for (int pc = wave; pc < pieces; pc += kWaves) glds16(src + pc * 1024 + (unsigned)(lane * 16), dst + pc * 1024);
+  };
+  // The first weight chunks - the largest request of the prologue, and one that needs nothing but the grid position - go out HERE, in front of
+  // the per-lane pixel / staging-item set-up (a few hundred instructions, fetched cold): the set-up runs under their round trip
+  int chunk = q_begin * ntc;
+  const int nchunks = q_end * ntc;
+  const bool reduce_phase = a.phase == 2;
+  if (reduce_phase) q_begin = q_end;                       // nothing to multiply: partials come from the workspace
+  int issued = chunk, islot = 0;                           // next chunk to fetch and the slot it goes to
+  if (q_begin < q_end) {
+    for (int i = 0; i < D - 1 && issued < nchunks; ++i) {  // D-1 chunks ahead; the D-th slot is the one being read
+      fetch(issued++, islot);
+      islot = islot + 1 == D ? 0 : islot + 1;
+    }
+  }
 
   // ---- per-lane output pixels ------------------------------------------------------------------
   int ly[PG], lx[PG], boff[PG];
@@ -234,14 +255,6 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
 
   // glds instructions EVERY wave issues per chunk (wave w issues ceil((pieces - w) / 8)): the lower bound the counted barrier uses
   const int keep_per_chunk = ((a.ntaps - (ntc - 1) * a.taps_per_chunk) * TMB * 2) / kWaves;     // (of the shortest chunk)
-  auto fetch = [&](int chunk, int slot) {                  // chunk = K group * ntc + chunk of the group
-    const int cq = chunk / ntc, ct = chunk - cq * ntc;
-    const int t0 = ct * a.taps_per_chunk, nt = min(a.taps_per_chunk, a.ntaps - t0);
-    const char* src = gw + ((size_t)cq * a.ntaps + t0) * TMB * 2048;
-    char* dst = ring + slot * slot_bytes;
-    const int pieces = nt * TMB * 2;
-    for (int pc = wave; pc < pieces; pc += kWaves) glds16(src + pc * 1024 + (unsigned)(lane * 16), dst + pc * 1024);
-  };
 
   // one quad of one K group: which source, its scale/shift/activation for lane group sg
   struct QuadCtx { const char* base; f32x4 sc, sh; int act; int kind; };   // base: wave-uniform
@@ -360,16 +373,8 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
 #define THA4_CSTAMP()
 #endif
   THA4_CSTAMP();                                           // 0: entry (after index set-up)
-  int slot = 0, chunk = q_begin * ntc;
-  const int nchunks = q_end * ntc;
-  const bool reduce_phase = a.phase == 2;
-  if (reduce_phase) q_begin = q_end;                       // nothing to multiply: partials come from the workspace
-  int issued = chunk, islot = 0;                           // next chunk to fetch and the slot it goes to
+  int slot = 0;
   if (q_begin < q_end) {
-    for (int i = 0; i < D - 1 && issued < nchunks; ++i) {  // D-1 chunks ahead; the D-th slot is the one being read
-      fetch(issued++, islot);
-      islot = islot + 1 == D ? 0 : islot + 1;
-    }
     if (a.fnorm.enabled) {                                 // scale/shift table from the producer's moments (scratch: the window region)
       fused_norm_table(a, n, tid, kThreads, tab_sc, tab_sh, reinterpret_cast<double*>(smem));
       __syncthreads();

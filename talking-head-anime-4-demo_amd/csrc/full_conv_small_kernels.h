@@ -27,6 +27,9 @@ constexpr int kSmallThreads = kSmallWaves * 64;
 constexpr int kSmallMaxItems = 7;     // staging items (pixel, lane group) per lane and K group: window <= 112 pixels
 constexpr int kSmallTapChunk = 3;     // taps per register-resident weight chunk (two chunks in flight)
 
+#ifndef THA4_SMALL_PREFETCH_EPI
+#define THA4_SMALL_PREFETCH_EPI(PG, POOL) (!((PG) == 4 && (POOL)))     // (the instantiation without spare registers requests them after the exchange)
+#endif
 template <int PG, int INMODE>
 __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   warm_kernarg<(int)sizeof(ConvArgs)>();
@@ -91,6 +94,34 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   char* win_hi = wins + wave * 8 * PLANE;
   char* win_lo = win_hi + 4 * PLANE;
   const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)cls * a.w16_class_bytes + (size_t)bo * NQ * a.ntaps * 2048 + lane * 16;
+
+  // weights of one chunk of <= TC taps of K group Q, straight from L2: fragment-linear pieces [Q][tap][hi 1 KiB | lo 1 KiB]
+  struct WChunk { f16x8 h[TC], l[TC]; };
+  auto load_weights = [&](int Q, int t0, int t1, WChunk& w) {
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+      const int t = min(t0 + i, t1 - 1);                    // past the range: re-read the last tap (never multiplied)
+      const char* pc = gw + ((size_t)Q * a.ntaps + t) * 2048;
+      w.h[i] = *reinterpret_cast<const f16x8*>(pc);
+      w.l[i] = *reinterpret_cast<const f16x8*>(pc + 1024);
+    }
+  };
+  // three register-resident weight chunks (3 taps each: a whole 3x3 K group) are in flight per wave; longer tap ranges
+  // (4x4 stride 2: 16 taps) roll through the three slots
+  WChunk w0, w1, w2;
+  auto load_unit_head = [&](int Q, int t0, int t1) {       // the first three chunks of a unit
+    load_weights(Q, t0, t1, w0);
+    if (t0 + TC < t1) load_weights(Q, t0 + TC, t1, w1);
+    if (t0 + 2 * TC < t1) load_weights(Q, t0 + 2 * TC, t1, w2);
+  };
+  // The first unit's weights - the largest request of the prologue, and one that needs nothing but the grid position - go out HERE, in front
+  // of the per-lane pixel / staging-item set-up (a few hundred instructions, fetched cold): they used to land ~1.2 k cycles after the window
+  // (in-kernel stamps), now the set-up runs under their round trip
+  int u = wave;
+  if (u < nunits) {
+    const int t0 = (u % upq) * tpu;
+    load_unit_head(u / upq, t0, min(a.ntaps, t0 + tpu));
+  }
 
   // ---- per-lane output pixels ------------------------------------------------------------------
   int ly[PG], lx[PG], boff[PG];
@@ -223,18 +254,6 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     }
   };
 
-  // weights of one chunk of <= TC taps of K group Q, straight from L2: fragment-linear pieces [Q][tap][hi 1 KiB | lo 1 KiB]
-  struct WChunk { f16x8 h[TC], l[TC]; };
-  auto load_weights = [&](int Q, int t0, int t1, WChunk& w) {
-#pragma unroll
-    for (int i = 0; i < TC; ++i) {
-      const int t = min(t0 + i, t1 - 1);                    // past the range: re-read the last tap (never multiplied)
-      const char* pc = gw + ((size_t)Q * a.ntaps + t) * 2048;
-      w.h[i] = *reinterpret_cast<const f16x8*>(pc);
-      w.l[i] = *reinterpret_cast<const f16x8*>(pc + 1024);
-    }
-  };
-
   f32x4 acc[PG];
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) acc[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -259,21 +278,10 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
 
   THA4_SSTAMP();                                           // 0: entry (index set-up done)
   // ---- first unit's loads go out before the normalisation table is built -------------------------
-  // three register-resident weight chunks (3 taps each: a whole 3x3 K group) are in flight per wave; longer tap ranges
-  // (4x4 stride 2: 16 taps) roll through the three slots
-  int u = wave;
   int curQ = -1;
-  WChunk w0, w1, w2;
-  auto load_unit_head = [&](int Q, int t0, int t1) {       // the first three chunks of a unit
-    load_weights(Q, t0, t1, w0);
-    if (t0 + TC < t1) load_weights(Q, t0 + TC, t1, w1);
-    if (t0 + 2 * TC < t1) load_weights(Q, t0 + 2 * TC, t1, w2);
-  };
   if (u < nunits) {
     curQ = u / upq;
     load_window(curQ);
-    const int t0 = (u % upq) * tpu;
-    load_unit_head(curQ, t0, min(a.ntaps, t0 + tpu));
   }
   // wave 0 runs the epilogue: its residual values are requested now, not after the reduction
   const int out_px = a.out_h * a.out_w;
@@ -299,12 +307,23 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
       if (wave == 0 && a.residual && inside[pg]) resv[pg] = load_residual(pg);
     }
   }
+  // ... and so are its bias and output-activation codes: requested after the partial-sum exchange they were FIVE dependent memory round
+  // trips at the end of every launch (bias, then one code per channel in front of apply_act's branches: ~3 k of a 26 k-cycle launch)
+  constexpr bool kPrefetchEpi = THA4_SMALL_PREFETCH_EPI(PG, kPool);
+  f32x4 bias_pre = f32x4{0.f, 0.f, 0.f, 0.f};
+  int codes_pre[4] = {ACT_NONE, ACT_NONE, ACT_NONE, ACT_NONE};
+  if (kPrefetchEpi && wave == 0) {
+    if (a.bias) bias_pre = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+    if (a.act_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) codes_pre[j] = a.act_out[bo * 16 + g4 + j];
+    }
+  }
   THA4_SSTAMP();                                           // 1: first unit's loads issued
 #if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
   if (a.dbg) {                                             // tuning aid: when do the window (requested first) and the weights land?
-    asm volatile("s_waitcnt vmcnt(19)" ::: "memory");      // 18 weight loads + the stamp's store are younger than the window loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the weights are requested first since round 4: they are older than the window)
     THA4_SSTAMP();                                         // 2: window landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     THA4_SSTAMP();                                         // 3: weights landed
   }
 #endif
@@ -358,38 +377,66 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   __syncthreads();
   THA4_SSTAMP();                                           // partial sums exchanged
   if (wave != 0) return;
-  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+  // every operand of the epilogue is requested (or already here) before anything is consumed; the stores go out LAST, behind the DPP
+  // reduction of the moments, so that no instruction waits for a store's acknowledgement (same operations on the same values as the
+  // one-position-at-a-time form: same bits)
+  f32x4 bias = bias_pre;
+  int codes[4] = {codes_pre[0], codes_pre[1], codes_pre[2], codes_pre[3]};
+  if (!kPrefetchEpi) {
+    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + bo * 16 + g4);
+    if (a.act_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) codes[j] = a.act_out[bo * 16 + g4 + j];
+    }
+  }
+  f32x4 resl[kPrefetchRes ? 1 : PG];
+  if (!kPrefetchRes) {
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      resl[pg] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.residual && inside[pg]) resl[pg] = load_residual(pg);
+    }
+  }
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 vout[PG];
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) {
     f32x4 s = red[(0 * PG + pg) * 64 + lane];
 #pragma unroll
     for (int w2i = 1; w2i < kSmallWaves; ++w2i) s = s + red[(w2i * PG + pg) * 64 + lane];
+    vout[pg] = s;
     if (!inside[pg]) continue;                             // ragged tile: position outside the map
-    const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
-    const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
     f32x4 v = s * a.w16_inv_scale + bias;
-    if (a.residual) v = v + (kPrefetchRes ? resv[kPrefetchRes ? pg : 0] : load_residual(pg));
+    if (a.residual) v = v + (kPrefetchRes ? resv[kPrefetchRes ? pg : 0] : resl[kPrefetchRes ? 0 : pg]);
     if (a.act_out) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act_out[bo * 16 + g4 + j]);
+      for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], codes[j]);
     }
-    *reinterpret_cast<f32x4*>(a.out + off) = v;
+    vout[pg] = v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]); }
   }
+  float rs[4], rq[4];
   if (a.stats) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float s = ssum[j], q = ssq[j];
-      s = row16_sum(s, lane);
-      q = row16_sum(q, lane);
-      if (p == 0) {
-        float* dst = a.stats + ((((size_t)n * a.stats_tiles + cg.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
-        dst[0] = s;
-        dst[1] = q;
-      }
+      rs[j] = row16_sum(ssum[j], lane);
+      rq[j] = row16_sum(ssq[j], lane);
+    }
+  }
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    if (!inside[pg]) continue;
+    const int oy = (tile_y0 + ly[pg]) * a.out_sy + cg.out_oy, ox = (tile_x0 + lx[pg]) * a.out_sx + cg.out_ox;
+    const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
+    *reinterpret_cast<f32x4*>(a.out + off) = vout[pg];
+  }
+  if (a.stats && p == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* dst = a.stats + ((((size_t)n * a.stats_tiles + cg.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
+      dst[0] = rs[j];
+      dst[1] = rq[j];
     }
   }
   THA4_SSTAMP();                                           // wave 0: epilogue issued

@@ -723,17 +723,30 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
   double* part = reinterpret_cast<double*>(smem);            // [S][ctot][2]
   double* csum = part + (size_t)S * ctot * 2;                // [ctot]
   double* csq = csum + ctot;
+  // the affine / FiLM operands of this thread's channel (ctot <= kNormThreads: thread t finishes channel cbeg + t) are requested
+  // here, together with the moments - not after the two reduction barriers, where they were one more dependent memory round trip
+  // (same-box A/B: +0.45 % on the batch-1 frame, profiles/r04_raw/c25_ab.txt)
+  // All six loads are unconditional (a clamped channel; an absent FiLM row reads gamma instead and is never used): conditional loads
+  // are waited for at the end of their `if`, which made three dependent round trips of them
+  const int cpre = min(cbeg + (int)threadIdx.x, a.channels - 1);
+  const float* f0 = a.film0 ? a.film0 + (size_t)n * a.film0_stride : nullptr;
+  const float* f1 = a.film1 ? a.film1 + (size_t)n * a.film1_stride : nullptr;
+  const float p_gam = a.gamma[cpre], p_bet = a.beta[cpre];
+  const float p_s0 = (f0 ? f0 : a.gamma)[cpre], p_b0 = (f0 ? f0 + a.channels : a.gamma)[cpre];
+  const float p_s1 = (f1 ? f1 : a.gamma)[cpre], p_b1 = (f1 ? f1 + a.channels : a.gamma)[cpre];
   for (int cl0 = threadIdx.x % ctot, sl = threadIdx.x / ctot; sl < S && cl0 < ctot; sl += kNormThreads) {   // one pass (S*ctot <= threads)
     const int c = cbeg + cl0;
     const int s = c < c0 ? 0 : 1;
     const int cl = c - (s ? c0 : 0);
-    const int cw = a.cb[s] * 16;
-    const float* ps = a.stats[s] + ((size_t)n * a.tiles[s] * cw + cl) * 2;
+    // (the two-entry argument arrays are read with CONSTANT indices and selected: indexed by `s` they become vector loads from the
+    // argument block, a dependent memory round trip in front of the moment loads - and two more in front of the final stores)
+    const int cw = (s ? a.cb[1] : a.cb[0]) * 16;
+    const int nt = s ? a.tiles[1] : a.tiles[0];
+    const float* ps = (s ? a.stats[1] : a.stats[0]) + ((size_t)n * nt * cw + cl) * 2;
     // four independent partial sums (fixed assignment t -> sum (t/S)%4, combined in a fixed order): the loads of four
     // tiles are in flight at once instead of one fp64 add chain waiting on each 8-byte load in turn
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     double su[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
-    const int nt = a.tiles[s];
     int t = sl;
     for (; t + 3 * S < nt; t += 4 * S) {
       f32x2 v[4];
@@ -779,22 +792,23 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
         var = sq * a.inv_count / gs - mean * mean;
       }
       const double rstd = 1.0 / sqrt(fmax(var, 0.0) + (double)a.eps);
-      double k = (double)a.gamma[c] * rstd;
-      double b = (double)a.beta[c] - mean * k;
+      double k = (double)p_gam * rstd;                      // (cl0 == threadIdx.x: the loop runs once)
+      double b = (double)p_bet - mean * k;
       if (a.film0) {
-        const double s0 = a.film0[(size_t)n * a.film0_stride + c], b0 = a.film0[(size_t)n * a.film0_stride + a.channels + c];
+        const double s0 = p_s0, b0 = p_b0;
         k *= (1.0 + s0); b = b * (1.0 + s0) + b0;
       }
       if (a.film1) {
-        const double s1 = a.film1[(size_t)n * a.film1_stride + c], b1 = a.film1[(size_t)n * a.film1_stride + a.channels + c];
+        const double s1 = p_s1, b1 = p_b1;
         k *= (1.0 + s1); b = b * (1.0 + s1) + b1;
       }
       sc = (float)k;
       sh = (float)b;
       report_fault_unless_finite(a.fault, sc, sh);
     }
-    a.scale[s][(size_t)n * a.cb[s] * 16 + cl] = sc;
-    a.shift[s][(size_t)n * a.cb[s] * 16 + cl] = sh;
+    const size_t oidx = (size_t)n * (s ? a.cb[1] : a.cb[0]) * 16 + cl;
+    (s ? a.scale[1] : a.scale[0])[oidx] = sc;
+    (s ? a.shift[1] : a.shift[0])[oidx] = sh;
   }
 }
 
