@@ -273,6 +273,9 @@ THA4_DEV void first16_pos(const float* wx, const float* wy, const float* pb, con
   }
 }
 
+#ifndef THA4_TAP_PIPELINE
+#define THA4_TAP_PIPELINE 1   // 1: explicit two-block software pipeline of the first layers' tap requests (round 4); 0: the loop of rounds 2-3
+#endif
 #ifndef THA4_TAP_BLOCKS
 #define THA4_TAP_BLOCKS 4     // blocks whose 4 upsample taps are requested together in the first layers (power of two)
 #endif
@@ -297,27 +300,53 @@ THA4_DEV void first16_up_to(const float* zframe, int lowS, const float* wx, cons
     const unsigned o01 = (unsigned)(z_offset(0, w.lane >> 4, y0 * lowS + x1, npix) * sizeof(float));
     const unsigned o10 = (unsigned)(z_offset(0, w.lane >> 4, y1 * lowS + x0, npix) * sizeof(float));
     const unsigned o11 = (unsigned)(z_offset(0, w.lane >> 4, y1 * lowS + x1, npix) * sizeof(float));
-#pragma unroll
-    for (int bb = 0; bb < NBW; ++bb) {
+    // Two blocks' requests in flight (THA4_TAP_PIPELINE, round 4): block bb + 1 is requested BEFORE block bb is consumed, pinned by scheduling
+    // fences.  Left to itself the compiler serialised the blocks of the weights-resident level 2 - six loads, s_waitcnt vmcnt(0), six loads ... :
+    // five dependent memory round trips per strip (tools/isa_waits.py) where the streamed level 1 already overlapped two blocks.
+    struct Taps { f32x4 vx, a, bq, c, d, vy; };
+    auto request = [&](int bb) -> Taps {
       const int b = mbase + bb;
       const char* zb = reinterpret_cast<const char*>(zframe) + (size_t)b * npix * 16 * sizeof(float);      // wave-uniform
-      const f32x4 vx = ldg4(wx + b * 16, g4 * 4u);
-      const f32x4 a = THA4_HOOK_ZLOAD(zb + o00, vx);
-      const f32x4 bq = THA4_HOOK_ZLOAD(zb + o01, vx);
-      const f32x4 c = THA4_HOOK_ZLOAD(zb + o10, vx);
-      const f32x4 d = THA4_HOOK_ZLOAD(zb + o11, vx);
-      const f32x4 vy = ldg4(wy + b * 16, g4 * 4u);
+      Taps t;
+      t.vx = ldg4(wx + b * 16, g4 * 4u);
+      t.a = THA4_HOOK_ZLOAD(zb + o00, t.vx);
+      t.bq = THA4_HOOK_ZLOAD(zb + o01, t.vx);
+      t.c = THA4_HOOK_ZLOAD(zb + o10, t.vx);
+      t.d = THA4_HOOK_ZLOAD(zb + o11, t.vx);
+      t.vy = ldg4(wy + b * 16, g4 * 4u);
+      return t;
+    };
+    auto consume = [&](int bb, const Taps& t) {
+      const int b = mbase + bb;
       const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // six FMAs per value: position + pose bias, then the four taps with their products of the axis weights (the separable
         // form ly0 (lx0 a + lx1 b) + ly1 (lx0 c + lx1 d) + position term took nine VALU instructions)
-        const float t = fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j]));                               // z and tables carry the 30x
-        v[j] = sin_u(fmaf(w00, a[j], fmaf(w01, bq[j], fmaf(w10, c[j], fmaf(w11, d[j], t)))));
+        const float u = fmaf(t.vx[j], x[pg], fmaf(t.vy[j], y[pg], vb[j]));                            // z and tables carry the 30x
+        v[j] = sin_u(fmaf(w00, t.a[j], fmaf(w01, t.bq[j], fmaf(w10, t.c[j], fmaf(w11, t.d[j], u)))));
       }
       sink(pg, b, v);
-      if ((bb & (THA4_TAP_BLOCKS - 1)) == THA4_TAP_BLOCKS - 1) THA4_SCHED_FENCE();      // at most THA4_TAP_BLOCKS blocks (4 tap loads each) in flight: 12 blocks at once spill
+    };
+    if (THA4_TAP_PIPELINE) {
+      Taps cur = request(0);
+#pragma unroll
+      for (int bb = 0; bb < NBW; ++bb) {
+        Taps nxt = cur;
+        if (bb + 1 < NBW) nxt = request(bb + 1);
+        THA4_SCHED_FENCE();
+        consume(bb, cur);
+        THA4_SCHED_FENCE();
+        cur = nxt;
+      }
+    } else {
+#pragma unroll
+      for (int bb = 0; bb < NBW; ++bb) {
+        const Taps t = request(bb);
+        consume(bb, t);
+        if ((bb & (THA4_TAP_BLOCKS - 1)) == THA4_TAP_BLOCKS - 1) THA4_SCHED_FENCE();      // at most THA4_TAP_BLOCKS blocks (4 tap loads each) in flight: 12 blocks at once spill
+      }
     }
   }
 }
