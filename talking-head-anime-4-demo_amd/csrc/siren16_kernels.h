@@ -555,8 +555,8 @@ THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bia
     const float blended = (1.0f - al) * wv + al * col;
     const size_t pix = (size_t)pix0[pg] + p;
     THA4_HOOK_BEFORE_STORES();
+    if (d.out_rgba8) store_display(d, n, pix, g, p, blended);      // (first: it LOADS the background colour, and a load behind a store waits for the store's acknowledgement)
     if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
-    if (d.out_rgba8) store_display(d, n, pix, g, p, blended);
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
     if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = wv;
     if (d.out_alpha && g == 0) d.out_alpha[(size_t)n * NPIX + pix] = al;
@@ -621,6 +621,8 @@ THA4_DEV void put_rows(f16x8 (&xh)[kKG2][PG], f16x8 (&xl)[kKG2][PG], int pg, int
   }
 }
 
+// (Round 4, measured negative: the layer biases / scales of the weights-resident level 2 copied to LDS once per workgroup instead of three dependent
+// global round trips per strip - the kernel alone 45.1 -> 44.6 us, the batch-1 STREAM 7640 -> 7535 frames/s on the same box, profiles/r04_raw/c31_student_bias_lds.txt.)
 #ifndef THA4_L2_GROUP_BLOCKS
 #define THA4_L2_GROUP_BLOCKS 3    // A fragments of this many blocks (hi + lo) are double-buffered in registers: 3 -> 48 VGPRs, 2 -> 32
 #endif

@@ -642,8 +642,8 @@ __global__ void __launch_bounds__(NS* MS * 64) level2_kernel(StudentDev d) {
     wv += body_source(img, face, g, y1, x1) * wse;
     const float blended = (1.0f - al) * wv + al * col;            // siren_morpher_03.py:131
     const size_t pix = (size_t)pix0[pg] + p;
+    if (d.out_rgba8) store_display(d, n, pix, g, p, blended);      // (first: it LOADS the background colour, and a load behind a store waits for the store's acknowledgement)
     if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
-    if (d.out_rgba8) store_display(d, n, pix, g, p, blended);
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
     if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = wv;
     if (d.out_alpha && g == 0) d.out_alpha[(size_t)n * NPIX + pix] = al;
