@@ -11,9 +11,13 @@ for line in open(sys.argv[1]):
     if line.startswith("conv "):
         kv = dict(re.findall(r"(\w+)=([\w()x ]+?)(?= \w+=|$)", line.strip()[line.index("kind="):]))
         sched.append(kv)
+def merged(kv):          # round 4: the four parity classes of a transposed convolution are ONE launch of conv_tile / conv_small (full_net.h merge_classes)
+    return int(kv["classes"]) == 4 and kv.get("tiled") in ("1", "2")
+
+
 launches = []
 for kv in sched:
-    for c in range(int(kv["classes"]) * (2 if int(kv.get("ksplit", "1")) > 1 else 1)):   # conv_small (tiled=2) never splits K over launches
+    for c in range((1 if merged(kv) else int(kv["classes"])) * (2 if int(kv.get("ksplit", "1")) > 1 else 1)):   # conv_small (tiled=2) never splits K over launches
         launches.append(kv)
 rows = [r for r in csv.DictReader(open(sys.argv[2]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -29,7 +33,7 @@ for kv, r in zip(launches, last):
     taps = int(kv["taps"]) // (4 if int(kv["classes"]) == 4 else 1)
     th, tw = map(int, kv["tile"].split("x"))
     cin = int(kv["cin"].split("(")[0])
-    gflop = 2.0 * th * tw * cin * int(kv["cout"]) * taps / 1e9
+    gflop = 2.0 * th * tw * cin * int(kv["cout"]) * taps / 1e9 * (4 if merged(kv) else 1)
     key = (kv["kind"], kv["tile"], kv["mode"], cin, kv["cout"], kv["splitk"] + ("S" if kv.get("tiled") == "2" else "P" if kv.get("tiled") == "3" else ""), kv["tmb"], kv["pg"], kv["wgs"], kv.get("ksplit", "1"))
     agg[key][0] += 1
     agg[key][1] += us
