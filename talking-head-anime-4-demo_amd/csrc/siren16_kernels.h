@@ -183,6 +183,9 @@ THA4_DEV void gemm16_stream(const char*& gw, char* ring, int& slot, const char* 
   gw += (size_t)NC * CHUNK;
 }
 
+#ifndef THA4_BIAS_AHEAD
+#define THA4_BIAS_AHEAD 1
+#endif
 // sine hidden layer: act <- split(sin(acc / S + 30 b))          (30 and S are folded into the packed weights)
 template <class G, int NB, int KG, int HB, int CQ, int NEXT_PIECES>
 THA4_DEV void sine16_layer(const char*& gw, const float*& bias, const float*& scl, char* ring, int& slot, char* act, const WaveCtx& w) {
@@ -191,13 +194,25 @@ THA4_DEV void sine16_layer(const char*& gw, const float*& bias, const float*& sc
   const int mbase = w.ms * NBW;
   f32x4 acc[NBW][PG];
   zero_acc<NBW, PG>(acc);
+  // The layer's scale and biases are requested HERE, ahead of the GEMM (THA4_BIAS_AHEAD, round 4): requested in the epilogue they sat behind the
+  // global_load_lds of the NEXT layer's first weight chunk in the in-order vmcnt queue - every wave's sine epilogue waited for that whole chunk
+  // to land instead of running under it (tools/isa_waits.py: vmcnt(5) right behind three glds).  Older than every ring fetch, they do not disturb the
+  // counted chunk waits.
+  const int g4 = (w.lane >> 4) * 4;
+  float inv_pre = 0.f;
+  f32x4 bias_pre[NBW];
+  if (THA4_BIAS_AHEAD) {
+    inv_pre = *scl;
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) bias_pre[b] = ldg4(bias + (mbase + b) * 16, g4 * 4u);
+  }
   gemm16_stream<G, NB, NBW, KG, HB, CQ, NEXT_PIECES>(gw, ring, slot, act, acc, w, true);
   THA4_PRIO_VALU();
-  const int g4 = (w.lane >> 4) * 4;
-  const float inv = *scl++;
+  const float inv = THA4_BIAS_AHEAD ? inv_pre : *scl;
+  ++scl;
 #pragma unroll
   for (int b = 0; b < NBW; ++b) {
-    const f32x4 bb = ldg4(bias + (mbase + b) * 16, g4 * 4u);
+    const f32x4 bb = THA4_BIAS_AHEAD ? bias_pre[b] : ldg4(bias + (mbase + b) * 16, g4 * 4u);
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       f32x4 v;
@@ -219,9 +234,9 @@ THA4_DEV void z16_layer(const char*& gw, const float*& scl, char* ring, int& slo
   const int mbase = w.ms * NBW;
   f32x4 acc[NBW][PG];
   zero_acc<NBW, PG>(acc);
+  const float inv = *scl++;                                // (requested ahead of the GEMM: see sine16_layer)
   gemm16_stream<G, NB, NBW, KG, HB, CQ, 0>(gw, ring, slot, act, acc, w, true);
   const int p = w.lane & 15;
-  const float inv = *scl++;
 #pragma unroll
   for (int b = 0; b < NBW; ++b)
 #pragma unroll
