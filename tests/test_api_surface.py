@@ -207,3 +207,59 @@ def test_library_holds_no_packed_fp32_instructions(built):
     # the hi/lo operand split rides on v_fma_mix (tha4_platform.h split_pair): if the optimiser ever folds the opaque -1 again the
     # split decays to 8 instructions per pair and these disappear
     assert dis.count("v_fma_mix") > 1000, dis.count("v_fma_mix")
+
+
+def test_every_kernel_touches_its_whole_argument_block_at_entry(built):
+    """warm_kernarg() (tha4_platform.h, round 4): a kernel's by-value argument struct is read where the compiler first needs each field - seven
+    DEPENDENT cold misses in conv_small_kernel's prologue - unless every 64-byte line of the block is touched by scalar loads in front of the
+    first two waits (+4.4 % on the full model's batch-1 frame, profiles/r04_full_conv_tile_reading.md section 10).  A refactor that drops the call changes no
+    result, only the frame time: look at the ISA that ships."""
+    import re
+    import subprocess
+    import tempfile
+    from tha4_amd import _build
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    if not (os.path.exists(objdump) and os.path.exists(bundler)):
+        pytest.skip("llvm-objdump / clang-offload-bundler not available")
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", _build.LIB, fat], check=True)
+        co = os.path.join(d, "gfx950.co")
+        subprocess.run([bundler, "--type=o", "--unbundle", f"--input={fat}", f"--output={co}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True)
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    # explicit kernarg bytes per kernel from the code object's metadata (.kernarg_segment_size counts the hidden arguments behind them too:
+    # the by-value struct is the one explicit argument, its size is that argument's .size)
+    size = {}
+    for m in re.finditer(r"\.args:\s*\n\s*- (.*?)\.name:\s+(\S+)", notes, re.S):
+        first = re.search(r"\.size:\s+(\d+)", m.group(1))
+        byval = re.search(r"\.value_kind:\s+(\w+)", m.group(1))
+        if first and byval and byval.group(1) == "by_value":
+            size[m.group(2)] = int(first.group(1))
+    kernels, cur = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif cur is not None and line.strip():
+            cur.append(line.split("//")[0].strip())
+    checked = 0
+    for name, ins in kernels.items():
+        if not any(k in name for k in ("conv_tile_kernel", "conv_small_kernel", "conv_point_kernel", "norm_finalize_kernel", "attention_kernel", "affine_add_kernel",
+                                       "front16_kernel", "level1_16_kernel", "level2_16p_kernel")):
+            continue
+        nbytes = size.get(name)
+        assert nbytes, name
+        waits = [i for i, x in enumerate(ins) if x.startswith("s_waitcnt")]       # (the scheduler may split the batch over the first two waits)
+        lines = set()
+        for x in ins[:waits[1]]:
+            m = re.match(r"s_load_dword(x\d+)?\s+\S+\s+s\[0:1\],\s+(0x[0-9a-f]+|\d+)", x)
+            if m:
+                off = int(m.group(2), 0)
+                width = 4 * int((m.group(1) or "x1")[1:])
+                lines.update(range(off // 64, (off + width - 1) // 64 + 1))
+        want = set(range((nbytes + 63) // 64))
+        assert want <= lines, (name, nbytes, sorted(want - lines))
+        checked += 1
+    assert checked >= 45 + 9 + 3       # every conv_tile instantiation, the conv_small ones, the student's three
