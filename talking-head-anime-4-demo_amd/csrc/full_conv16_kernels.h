@@ -166,14 +166,16 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
 
   // ---- tile decomposition -------------------------------------------------------------------
   const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (NW * PG * 16) >> twl;
-  const int tiles_x = (a.tile_w + TWW - 1) >> twl;
-  const int tiles_per_frame = tiles_x * ((a.tile_h + TWH - 1) / TWH);
+  // (every divisor below is a launch constant with a host-computed reciprocal - FastDiv, full_kernels.h)
+  const int tiles_x = a.tiles_x;
+  const int tiles_per_frame = a.tiles_per_frame;
   int cls = 0, bx = (int)blockIdx.x;                        // merged transposed convolution: the parity class is the slowest part of blockIdx.x
-  if (a.nclass > 1) { cls = bx / (a.batch * tiles_per_frame); bx -= cls * (a.batch * tiles_per_frame); }
+  if (a.nclass > 1) { cls = fast_div(bx, a.d_class); bx -= cls * a.d_class.d; }
   const ConvClass cg = conv_class(a, cls, tiles_per_frame);
-  const int n = bx / tiles_per_frame;
-  const int tile = bx % tiles_per_frame;
-  const int tile_y0 = (tile / tiles_x) * TWH, tile_x0 = (tile % tiles_x) << twl;
+  const int n = fast_div(bx, a.d_tpf);
+  const int tile = bx - n * tiles_per_frame;
+  const int tile_row = fast_div(tile, a.d_tiles_x);
+  const int tile_y0 = tile_row * TWH, tile_x0 = (tile - tile_row * tiles_x) << twl;
   const int mtile = blockIdx.y;
   const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (kPool ? a.in_h / 2 : a.in_h);
   const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (kPool ? a.in_w / 2 : a.in_w);
@@ -186,10 +188,10 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
   const int NQ = (cbtot + 1) >> 1;                       // 32-channel K groups
   const int ksplit = a.phase == 0 ? 1 : a.ksplit, ks = a.phase == 1 ? (int)blockIdx.z : 0;
-  const int q_per = (NQ + ksplit - 1) / ksplit;
+  const int q_per = a.phase == 0 ? NQ : a.q_per;         // ceil(NQ / ksplit)
   int q_begin = ks * q_per;
   const int q_end = min(NQ, q_begin + q_per);              // this workgroup's K groups
-  const int ntc = (a.ntaps + a.taps_per_chunk - 1) / a.taps_per_chunk;   // weight chunks per K group (the last one may be shorter: 9 = 5 + 4)
+  const int ntc = a.ntc;                                  // weight chunks per K group = ceil(ntaps / taps_per_chunk) (the last one may be shorter: 9 = 5 + 4)
   const int slot_bytes = a.taps_per_chunk * TMB * 2048;
   char* win_hi = smem;
   char* win_lo = smem + 4 * PLANE;
@@ -202,7 +204,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   float* tab_sh = tab_sc + (fused_table_floats(a) >> 1);
   const char* gw = reinterpret_cast<const char*>(a.w16) + (size_t)cls * a.w16_class_bytes + (size_t)mtile * NQ * a.ntaps * TMB * 2048;
   auto fetch = [&](int chunk, int slot) {                  // chunk = K group * ntc + chunk of the group
-    const int cq = chunk / ntc, ct = chunk - cq * ntc;
+    const int cq = fast_div(chunk, a.d_ntc), ct = chunk - cq * ntc;
     const int t0 = ct * a.taps_per_chunk, nt = min(a.taps_per_chunk, a.ntaps - t0);
     const char* src = gw + ((size_t)cq * a.ntaps + t0) * TMB * 2048;
     char* dst = ring + slot * slot_bytes;
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   for (int k = 0; k < KI; ++k) {
     const int item = tid + k * kThreads;
     const int px = item >> 2;
-    const int wy = px / WW, wx = px - wy * WW;
+    const int wy = fast_div(px, a.d_win_w), wx = px - wy * WW;
     const int vy = vy0 + wy, vx = vx0 + wx;
     const bool ok = item < nitems && (unsigned)vy < (unsigned)vh && (unsigned)vx < (unsigned)vw;
     int o;

@@ -48,30 +48,34 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
 #else
 #define THA4_SSTAMP()
 #endif
+  THA4_SSTAMP();                                           // (phase-timing builds) S0: wave start (argument block warm)
 
   // ---- tile decomposition (16*PG output positions, TH x 2^twl) ------------------------------------
+  // (every divisor below is a launch constant with a host-computed reciprocal - FastDiv, full_kernels.h: the eight run-time integer divisions of this
+  // prologue were 2.3 k cycles of scalar work per wave)
   const int twl = a.wg_tw_log2, TWW = 1 << twl, TWH = (PG * 16) >> twl;
-  const int tiles_x = (a.tile_w + TWW - 1) >> twl;
-  const int tiles_per_frame = tiles_x * ((a.tile_h + TWH - 1) / TWH);
+  const int tiles_x = a.tiles_x;
+  const int tiles_per_frame = a.tiles_per_frame;
   // 1-D grid of batch * tiles * nb workgroups.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2):
   // all pixel tiles of one output block share that block's weights, so they are mapped to ONE XCD (block bo -> XCD
   // bo % 8) and every weight is fetched from HBM / MALL once per frame instead of once per XCD
   const int G = a.batch * tiles_per_frame;                 // workgroups per output block
   int cls = 0, bx = (int)blockIdx.x;                        // merged transposed convolution: the parity class is the slowest grid dimension
-  if (a.nclass > 1) { cls = bx / (G * a.nb); bx -= cls * (G * a.nb); }
+  if (a.nclass > 1) { cls = fast_div(bx, a.d_class); bx -= cls * a.d_class.d; }
   const ConvClass cg = conv_class(a, cls, tiles_per_frame);
   int bo, tl;
   if ((a.nb & 7) == 0) {
-    const int xcd = bx & 7, slot = bx >> 3;
-    bo = xcd + 8 * (slot / G);
-    tl = slot % G;
+    const int xcd = bx & 7, slot = bx >> 3, sq = fast_div(slot, a.d_group);
+    bo = xcd + 8 * sq;
+    tl = slot - sq * G;
   } else {
-    bo = bx / G;
-    tl = bx % G;
+    bo = fast_div(bx, a.d_group);
+    tl = bx - bo * G;
   }
-  const int n = tl / tiles_per_frame;
-  const int tile = tl % tiles_per_frame;
-  const int tile_y0 = (tile / tiles_x) * TWH, tile_x0 = (tile % tiles_x) << twl;
+  const int n = fast_div(tl, a.d_tpf);
+  const int tile = tl - n * tiles_per_frame;
+  const int tile_row = fast_div(tile, a.d_tiles_x);
+  const int tile_y0 = tile_row * TWH, tile_x0 = (tile - tile_row * tiles_x) << twl;
   const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (kPool ? a.in_h / 2 : a.in_h);
   const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (kPool ? a.in_w / 2 : a.in_w);
   const int in_px = a.in_h * a.in_w;
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   for (int s = 0; s < a.nsrc; ++s) cbtot += a.src[s].cb;
   const int NQ = (cbtot + 1) >> 1;                         // 32-channel K groups
   const int upq = a.units_per_q;                           // tap ranges per K group (1 unless NQ < 8)
-  const int tpu = (a.ntaps + upq - 1) / upq;               // taps per unit
+  const int tpu = a.taps_per_unit;                         // taps per unit = ceil(ntaps / upq)
   const int nunits = NQ * upq;
 
   // ---- LDS: [scale | shift table] [8 waves x (4 hi + 4 lo planes)]; the reduction buffer aliases the windows -----
@@ -114,15 +118,17 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     if (t0 + TC < t1) load_weights(Q, t0 + TC, t1, w1);
     if (t0 + 2 * TC < t1) load_weights(Q, t0 + 2 * TC, t1, w2);
   };
+  THA4_SSTAMP();                                           // S1: tile decomposition + LDS carve-up done (scalar work)
   // The first unit's weights - the largest request of the prologue, and one that needs nothing but the grid position - go out HERE, in front
   // of the per-lane pixel / staging-item set-up (a few hundred instructions, fetched cold): they used to land ~1.2 k cycles after the window
   // (in-kernel stamps), now the set-up runs under their round trip
   int u = wave;
   if (u < nunits) {
-    const int t0 = (u % upq) * tpu;
-    load_unit_head(u / upq, t0, min(a.ntaps, t0 + tpu));
+    const int uq = fast_div(u, a.d_upq), t0 = (u - uq * upq) * tpu;
+    load_unit_head(uq, t0, min(a.ntaps, t0 + tpu));
   }
 
+  THA4_SSTAMP();                                           // S2: first weights requested
   // ---- per-lane output pixels ------------------------------------------------------------------
   int ly[PG], lx[PG], boff[PG];
   bool inside[PG];
@@ -143,7 +149,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   for (int k = 0; k < KI; ++k) {
     const int item = lane + k * 64;
     const int px = item >> 2;
-    const int wy = px / WW, wx = px - wy * WW;
+    const int wy = fast_div(px, a.d_win_w), wx = px - wy * WW;
     const int vy = vy0 + wy, vx = vx0 + wx;
     const bool ok = item < nitems && (unsigned)vy < (unsigned)vh && (unsigned)vx < (unsigned)vw;
     int o;
@@ -276,11 +282,11 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     }
   };
 
-  THA4_SSTAMP();                                           // 0: entry (index set-up done)
+  THA4_SSTAMP();                                           // S3 (was 0): per-lane set-up done
   // ---- first unit's loads go out before the normalisation table is built -------------------------
   int curQ = -1;
   if (u < nunits) {
-    curQ = u / upq;
+    curQ = fast_div(u, a.d_upq);
     load_window(curQ);
   }
   // wave 0 runs the epilogue: its residual values are requested now, not after the reduction
@@ -334,8 +340,8 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   THA4_SSTAMP();                                           // 2: normalisation table built
   bool staged = false;
   for (; u < nunits; u += kSmallWaves) {
-    const int Q = u / upq;
-    const int t0 = (u % upq) * tpu, t1 = min(a.ntaps, t0 + tpu);
+    const int Q = fast_div(u, a.d_upq);
+    const int t0 = (u - Q * upq) * tpu, t1 = min(a.ntaps, t0 + tpu);
     if (Q != curQ) { load_window(Q); curQ = Q; staged = false; }
     if (!staged) {                                         // wave-private LDS: program order, no workgroup barrier
       THA4_PRIO_VALU();
@@ -361,9 +367,9 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     // the next unit's window + weights are requested before this wave idles: one memory round trip per unit
     const int un = u + kSmallWaves;
     if (un < nunits) {
-      const int Qn = un / upq;
+      const int Qn = fast_div(un, a.d_upq);
       if (Qn != curQ) { load_window(Qn); curQ = Qn; staged = false; }
-      const int tn = (un % upq) * tpu;
+      const int tn = (un - Qn * upq) * tpu;
       load_unit_head(Qn, tn, min(a.ntaps, tn + tpu));
     }
   }

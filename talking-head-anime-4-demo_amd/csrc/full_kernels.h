@@ -61,6 +61,19 @@ struct FusedNorm {
   int* fault;              // sticky numeric-fault flag of the handle (a non-finite scale/shift sets it), or null
 };
 
+// Division by a launch constant: q = (x * m) >> 40 with m = ceil(2^40 / d) - exact for 0 <= x < 2^22 and 1 <= d < 2^18 (x * (m d - 2^40) < 2^40), a handful of
+// instructions where the compiler's sequence for a run-time divisor is ~30.  In-kernel stamps (profiles/r04_raw/c37_phase_prologue.txt) put 2.3 k cycles of
+// SCALAR work - the decomposition of blockIdx.x, eight such divisions - in front of a conv_small_kernel wave's first request, another ~2 k of per-lane divisions
+// behind it: every divisor of the prologues is a constant of the launch, computed on the host (finish_conv_args / finish_conv_batch).
+struct FastDiv { unsigned long long m; int d; int pad_; };
+inline bool fastdiv_make(FastDiv& f, long long d) {
+  if (d < 1 || d >= (1 << 18)) return false;
+  f.d = (int)d; f.pad_ = 0;
+  f.m = ((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d;
+  return true;
+}
+THA4_DEV int fast_div(int x, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)x * f.m) >> 40); }
+
 struct ConvArgs {
   ConvSrc src[2];
   int nsrc;
@@ -104,10 +117,39 @@ struct ConvArgs {
   // one class, geometry from the fields above.
   int nclass;
   long long w16_class_bytes;
+  // launch constants of the tile / small kernels' prologues, computed on the host (finish_conv_args: plan time; finish_conv_batch: per call)
+  int tiles_x, tiles_per_frame;   // pixel tiles per row / per frame (and parity class)
+  int taps_per_unit;               // conv_small_kernel: ceil(ntaps / units_per_q)
+  int q_per, ntc;                  // conv_tile_kernel: K groups per split, weight chunks per K group
+  FastDiv d_tiles_x, d_tpf, d_upq, d_win_w, d_ntc;
+  FastDiv d_group;                 // batch * tiles_per_frame
+  FastDiv d_class;                 // workgroups of one parity class: conv_small batch * tiles_per_frame * nb, conv_tile batch * tiles_per_frame
 #ifdef THA4_PHASE_TIMING
   long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
 #endif
 };
+
+// Host: the launch constants that do not depend on the batch.  `px_per_wg` = output positions of a workgroup tile (16 * PG * pixel-slot waves), `nq` = 32-channel
+// K groups of the convolution (conv_tile_kernel's K split).  False when a divisor is out of FastDiv's range.
+inline bool finish_conv_args(ConvArgs& a, int px_per_wg, int nq) {
+  const int twl = a.wg_tw_log2, tww = 1 << twl, twh = px_per_wg >> twl;
+  if (twh < 1) return false;
+  a.tiles_x = (a.tile_w + tww - 1) >> twl;
+  a.tiles_per_frame = a.tiles_x * ((a.tile_h + twh - 1) / twh);
+  const int upq = a.units_per_q > 0 ? a.units_per_q : 1;
+  a.taps_per_unit = (a.ntaps + upq - 1) / upq;
+  const int ksplit = a.ksplit > 0 ? a.ksplit : 1;
+  a.q_per = (nq + ksplit - 1) / ksplit;
+  const int tpc = a.taps_per_chunk > 0 ? a.taps_per_chunk : 1;
+  a.ntc = (a.ntaps + tpc - 1) / tpc;
+  return fastdiv_make(a.d_tiles_x, a.tiles_x) && fastdiv_make(a.d_tpf, a.tiles_per_frame) && fastdiv_make(a.d_upq, upq) &&
+         fastdiv_make(a.d_win_w, a.win_w > 0 ? a.win_w : 1) && fastdiv_make(a.d_ntc, a.ntc);
+}
+// Host, per call: the divisors that carry the batch.  `grid_x` = blockIdx.x range of the launch (the dividend bound).
+inline bool finish_conv_batch(ConvArgs& a, bool small, long long grid_x) {
+  const long long g = (long long)a.batch * a.tiles_per_frame;
+  return grid_x < (1 << 22) && fastdiv_make(a.d_group, g) && fastdiv_make(a.d_class, small ? g * a.nb : g);
+}
 
 // Geometry of one launch class.  Merged transposed convolution (nclass = 4): class (py, px), tap t = 2a + b reads input (i + dd[py][a],
 // j + dd[px][b]) with dd = {{0, -1}, {1, 0}} and writes output (2i + py, 2j + px) - geom_convT4_s2 (full_layout.h, conv.py:164-177).

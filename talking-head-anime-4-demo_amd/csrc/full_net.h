@@ -508,6 +508,17 @@ class FullModel {
       a.res_mode = res_mode;
       a.stats_tiles = out.stats_tiles; a.stats_tile0 = cls * tiles;
       a.nb = nb; a.chunk_quads = cq;
+      if (small || tiled) {                                 // launch constants of the prologues (FastDiv reciprocals, full_kernels.h)
+        a.ksplit = ksplit;
+        ConvArgs probe = a;
+        probe.batch = max_batch;
+        const long long gx = (long long)max_batch * tiles * (small ? nb : 1) * grid_classes;
+        if (!finish_conv_args(a, 16 * pg * (small ? 1 : nw4 ? 4 : 8), (cbtot + 1) / 2) || a.tiles_per_frame != tiles ||
+            (probe.tiles_per_frame = a.tiles_per_frame, !finish_conv_batch(probe, small, gx))) {
+          if (error.empty()) error = "internal: convolution launch constants out of range";
+          return FTensor();
+        }
+      }
       std::vector<Src> sv = srcs;
       const Pending fp = fpend ? *fpend : Pending();
       const FTensor outc = out;
@@ -548,6 +559,7 @@ class FullModel {
         c.out = Wk(outc.off);
         c.stats = outc.stats_tiles ? Wk(outc.stats_off) : nullptr;
         c.batch = f.batch;
+        if (small || tiled) finish_conv_batch(c, small, 0);
         if (small) {
           dispatch_small(pg, in_mode, c, dim3(f.batch * tiles * nb * grid_classes, 1, 1), lds, f.stream);
         } else if (point) {

@@ -237,6 +237,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       a.win_dy0 = sg.dy0; a.win_dx0 = sg.dx0;
       const int nq = (cb0 + cb1 + 1) / 2;
       a.units_per_q = ksplit > 0 ? ksplit : plan_small_conv(g, th, tw, nb, nq).units_per_q;
+      if (!tha4::finish_conv_args(a, 16 * spg, nq) || a.tiles_per_frame != sg.tiles || !tha4::finish_conv_batch(a, true, (long long)n * sg.tiles * nb * grid_classes)) return -5;
     }
     if (tiled) {
       tg = tile_geom(g, th, tw, tpg, tmb, tw_log2, table_bytes, tnw);
@@ -248,6 +249,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
       a.w16_class_bytes = (long long)class_bytes;
       a.w16 = M.up(P16); a.w16_inv_scale = inv; a.wg_tw_log2 = tg.tw_log2; a.win_h = tg.win_h; a.win_w = tg.win_w;
       a.win_dy0 = tg.dy0; a.win_dx0 = tg.dx0; a.taps_per_chunk = tg.taps_per_chunk; a.ring_slots = tg.ring_slots; a.win_buffers = tg.win_buffers;
+      if (!tha4::finish_conv_args(a, 16 * tpg * tnw, (cb0 + cb1 + 1) / 2) || a.tiles_per_frame != tg.tiles || !tha4::finish_conv_batch(a, false, (long long)n * tg.tiles * grid_classes)) return -5;
     }
     if (point) {
       float inv = 1.f;
