@@ -450,4 +450,15 @@ int emu_upscaler_input(int n, const float* rest, const float* merged, const floa
   return 0;
 }
 
+#ifdef THA4_EMU
+// FastDiv (full_kernels.h) as the kernels evaluate it: out[i] = fast_div(x[i], d[i]); -1 where the host refuses the divisor
+int emu_fast_div(const int* x, const int* d, int count, int* out) {
+  for (int i = 0; i < count; ++i) {
+    FastDiv f;
+    out[i] = fastdiv_make(f, d[i]) ? fast_div(x[i], f) : -1;
+  }
+  return 0;
+}
+#endif
+
 }  // extern "C"

@@ -502,3 +502,24 @@ def test_small_conv_launch_plans(lib):
         ntaps = {0: k * k, 1: 16, 2: 4}[kind]
         assert upq in (1, 2, 4, 8) and upq <= max(1, ntaps) and (nq * upq >= 8 or upq * 2 > ntaps)
         assert 128 <= wgs <= 256, (th, tw, cin, cout, wgs)
+
+
+def test_fastdiv_is_exact_on_the_range_the_planner_allows(lib):
+    """FastDiv (csrc/full_kernels.h): q = (x * ceil(2^40 / d)) >> 40 replaces every run-time integer division of the convolution prologues.  Exact for
+    0 <= x < 2^22, 1 <= d < 2^18 - the bounds finish_conv_args / finish_conv_batch check; refused outside."""
+    rng = np.random.default_rng(7)
+    ds = np.concatenate([np.arange(1, 4097), rng.integers(1, 1 << 18, 20000), np.array([(1 << 18) - 1, 65535, 65536, 65537, 3, 7, 9, 18, 24, 48, 96])]).astype(np.int32)
+    xs = []
+    for d in ds:
+        k = rng.integers(0, ((1 << 22) - 1) // int(d) + 1, 6)
+        xs.append(np.clip(np.array([0, d - 1, d, d + 1, (1 << 22) - 1, (1 << 22) - int(d), *(k * int(d)), *(k * int(d) + int(d) - 1)], np.int64), 0, (1 << 22) - 1))
+    x = np.concatenate(xs).astype(np.int32)
+    d = np.repeat(ds, len(xs[0])).astype(np.int32)
+    out = np.empty_like(x)
+    ip = C.POINTER(C.c_int)
+    assert lib.emu_fast_div(x.ctypes.data_as(ip), d.ctypes.data_as(ip), int(x.size), out.ctypes.data_as(ip)) == 0
+    np.testing.assert_array_equal(out, x // d)
+    bad = np.array([0, -3, 1 << 18, 1 << 20], np.int32)
+    o2 = np.empty_like(bad)
+    lib.emu_fast_div(np.zeros(4, np.int32).ctypes.data_as(ip), bad.ctypes.data_as(ip), 4, o2.ctypes.data_as(ip))
+    assert (o2 == -1).all()
