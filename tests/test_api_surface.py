@@ -263,3 +263,39 @@ def test_every_kernel_touches_its_whole_argument_block_at_entry(built):
         assert want <= lines, (name, nbytes, sorted(want - lines))
         checked += 1
     assert checked >= 45 + 9 + 3       # every conv_tile instantiation, the conv_small ones, the student's three
+
+
+def test_convolution_prologues_hold_no_integer_division(built):
+    """FastDiv (full_kernels.h, round 4): every divisor of the conv_small / conv_tile prologues is a launch constant whose reciprocal the host computes; the
+    compiler's sequence for a run-time divisor (v_rcp_iflag_f32 + ~30 instructions, eight per wave) was 2.3 k cycles of scalar work in front of a wave's first
+    request (+1.6 % on the full model).  Changes no result when it comes back - only this test and the frame time notice."""
+    import re
+    import subprocess
+    import tempfile
+    from tha4_amd import _build
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    if not (os.path.exists(objdump) and os.path.exists(bundler)):
+        pytest.skip("llvm-objdump / clang-offload-bundler not available")
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", _build.LIB, fat], check=True)
+        co = os.path.join(d, "gfx950.co")
+        subprocess.run([bundler, "--type=o", "--unbundle", f"--input={fat}", f"--output={co}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True)
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+    kernels, cur = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif cur is not None and line.strip():
+            cur.append(line.split("//")[0].strip())
+    checked = 0
+    for name, ins in kernels.items():
+        if "conv_tile_kernel" not in name and "conv_small_kernel" not in name:
+            continue
+        first = next(i for i, x in enumerate(ins) if x.startswith(("global_load_dwordx4", "global_load_lds")))
+        assert first < 400, (name, first)                    # ~200-230 instructions in front of the first operand request (650 before round 4)
+        assert not [x for x in ins[:first] if "v_rcp" in x], name
+        checked += 1
+    assert checked == 45 + 9
