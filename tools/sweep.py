@@ -68,6 +68,11 @@ VARIANTS = {
     "l1w8x2_wait0": ["-DTHA4_L116_CFG=4,2,1,1,1,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     "plainsplit": ["-DTHA4_PLAIN_SPLIT"],          # hi/lo split as `lo = fp16(v - float(hi))` (8 instructions per pair instead of 3-4 with v_fma_mix)
     "hook": ["-DTHA4_L2_HOOK"],                      # with the level-2 code-object hook of the fault hunt (tools/hunt/check_co.py)
+    # round 4: the dependent-round-trip work, each switch back to the form it replaced (results identical either way; profiles/r04_full_conv_tile_reading.md sections 10-13)
+    "no_kernarg_warm": ["-DTHA4_NO_KERNARG_WARM"],                 # without warm_kernarg(): the argument block read as a chain of dependent cold misses
+    "no_tap_pipeline": ["-DTHA4_TAP_PIPELINE=0"],                  # student first layers: the tap requests as the compiler orders them
+    "no_bias_ahead": ["-DTHA4_BIAS_AHEAD=0"],                      # student streamed layers: scale + biases requested in the epilogue (behind the next chunk's fetch)
+    "small_epi_late": ["-DTHA4_SMALL_PREFETCH_EPI(PG,POOL)=0"],    # conv_small_kernel: bias + activation codes requested after the partial-sum exchange (still together)
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
