@@ -234,7 +234,9 @@ int tha4_full_numeric_status(tha4_full* h, int synchronize);
  * returns THA4_ERR_NUMERIC_RANGE once without enqueueing that call (a caller that never polls still learns of the fault, at the
  * price of one refused frame).  THA4_FAULT_STATUS_ONLY: tha4_full_pose never refuses; the fault is reported through
  * tha4_full_numeric_status only - for real-time callers that poll it (synchronize = 0 costs nothing) and cannot lose a frame to a
- * deferred report.  Either way the outputs of the faulting call itself are not finite / not trustworthy. */
+ * deferred report; while a fault is pending (raised, not yet polled) reuse_decomposer is ignored - the persistent eyebrow-decomposer
+ * outputs may be the faulted call's, so they are recomputed every call until the status is read.  Either way the outputs of the
+ * faulting call itself are not finite / not trustworthy. */
 #define THA4_FAULT_REFUSE_NEXT 0
 #define THA4_FAULT_STATUS_ONLY 1
 int tha4_full_set_fault_policy(tha4_full* h, int policy);

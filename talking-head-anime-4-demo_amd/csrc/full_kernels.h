@@ -61,18 +61,20 @@ struct FusedNorm {
   int* fault;              // sticky numeric-fault flag of the handle (a non-finite scale/shift sets it), or null
 };
 
-// Division by a launch constant: q = (x * m) >> 40 with m = ceil(2^40 / d) - exact for 0 <= x < 2^22 and 1 <= d < 2^18 (x * (m d - 2^40) < 2^40), a handful of
+// Division by a launch constant: q = (x * m) >> 42 with m = ceil(2^42 / d) - exact for 0 <= x < 2^22 and 1 <= d < 2^20 (x * (m d - 2^42) < x d < 2^42; x * m < 2^64), a handful of
 // instructions where the compiler's sequence for a run-time divisor is ~30.  In-kernel stamps (profiles/r04_raw/c37_phase_prologue.txt) put 2.3 k cycles of
 // SCALAR work - the decomposition of blockIdx.x, eight such divisions - in front of a conv_small_kernel wave's first request, another ~2 k of per-lane divisions
-// behind it: every divisor of the prologues is a constant of the launch, computed on the host (finish_conv_args / finish_conv_batch).
+// behind it: every divisor of the prologues is a constant of the launch, computed on the host (finish_conv_args / finish_conv_batch).  The range covers the largest
+// batch-sized divisor of the documented handle limit (max_batch = 256 x 1024 tiles of a 512x512 map = 2^18; round 4's 2^40 / d < 2^18 form refused exactly that plan).
+constexpr int kFastDivShift = 42;
 struct FastDiv { unsigned long long m; int d; int pad_; };
 inline bool fastdiv_make(FastDiv& f, long long d) {
-  if (d < 1 || d >= (1 << 18)) return false;
+  if (d < 1 || d >= (1 << 20)) return false;
   f.d = (int)d; f.pad_ = 0;
-  f.m = ((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d;
+  f.m = ((1ull << kFastDivShift) + (unsigned long long)d - 1) / (unsigned long long)d;
   return true;
 }
-THA4_DEV int fast_div(int x, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)x * f.m) >> 40); }
+THA4_DEV int fast_div(int x, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)x * f.m) >> kFastDivShift); }
 
 struct ConvArgs {
   ConvSrc src[2];

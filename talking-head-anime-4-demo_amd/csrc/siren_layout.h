@@ -219,17 +219,19 @@ constexpr double kSineTurnsLimit = 256.0;
 inline double sine_argument_bound_turns(const StudentWeightsView& v) {
   const double c = 30.0 / 6.283185307179586476925;
   double worst = 0.0;
-  auto layer = [&](const LinearView& l) {
+  bool nan_seen = false;                                // sticky: a NaN row anywhere makes the bound NaN (reported as over the limit),
+  auto layer = [&](const LinearView& l) {               // whatever rows follow it
     for (int o = 0; o < l.out_ch; ++o) {
       double s = std::fabs((double)l.bias[o]);
       for (int i = 0; i < l.in_ch; ++i) s += std::fabs((double)l.weight[(size_t)o * l.in_ch + i]);
-      if (!(s * c <= worst)) worst = s * c;             // (a NaN weight makes the bound NaN: reported as over the limit)
+      if (std::isnan(s)) nan_seen = true;
+      else if (s * c > worst) worst = s * c;
     }
   };
   for (int i = 0; i < 8; ++i) layer(v.face_sine[i]);
   for (int l = 0; l < 3; ++l)
     for (int j = 0; j < 3; ++j) layer(v.body_sine[l][j]);
-  return worst;
+  return nan_seen ? std::nan("") : worst;
 }
 
 // exact affine_grid(identity, align_corners=False) axis: x_j = (2j+1)/S - 1 (dyadic, exact in fp32)

@@ -509,7 +509,10 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
   auto* h = new tha4_full();
   h->device = device;
   if (!h->model.build(nets, max_batch, eyebrow_morphed_image_index, num_networks, (flags & THA4_FULL_EXACT_FP32) != 0)) {
-    std::string msg = std::string(num_networks == 5 ? "not a mode_07 model: " : "not a mode_12 model: ") + h->model.error;
+    // a planner failure ("internal: ...") is ours, not a property of the caller's state_dicts: say so
+    const bool internal = h->model.error.rfind("internal:", 0) == 0;
+    std::string msg = (internal ? std::string("launch planning failed for max_batch = ") + std::to_string(max_batch) + ": "
+                                : std::string(num_networks == 5 ? "not a mode_07 model: " : "not a mode_12 model: ")) + h->model.error;
     delete h;
     return fail(THA4_ERR_INVALID_ARGUMENT, msg);
   }
@@ -586,7 +589,11 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
   bool want_dec[6];
   for (int i = 0; i < 33; ++i) f.out[i] = outputs_dev[i] ? outputs_dev[i] : m.Wk(m.scratch_out[i]);
   for (int i = 0; i < 6; ++i) want_dec[i] = outputs_dev[27 + i] != nullptr;
-  const bool reuse = reuse_decomposer && h->decomposer_valid && h->last_batch == batch;
+  // THA4_FAULT_STATUS_ONLY: the call is never refused, but while a fault is pending (raised and not yet polled through
+  // tha4_full_numeric_status) the persistent decomposer outputs may be the faulted call's: they are recomputed, not reused.
+  // The flag is only peeked at - reporting and clearing stay with tha4_full_numeric_status
+  const bool fault_pending = *reinterpret_cast<volatile int*>(h->fault) != 0;
+  const bool reuse = reuse_decomposer && h->decomposer_valid && h->last_batch == batch && !fault_pending;
   h->decomposer_valid = false;              // valid again only once every launch of this call has been accepted
   m.run(f, !reuse, want_dec);
   HIP_TRY(hipGetLastError());

@@ -165,7 +165,25 @@ class HipFullPoser(Poser):
     #: how a numeric fault of an earlier call is delivered (tha4_full_set_fault_policy): "refuse_next" (default) - the next pose()
     #: raises once and is not enqueued; "status_only" - pose() never refuses, `check_numeric_range()` is the only report (real-time
     #: callers that poll it and cannot lose a frame).  pose() never synchronises: its outputs are unchecked until the check is called.
-    fault_policy = "refuse_next"
+    #: A property: the setter validates the value and, when the handle already exists, applies it to the LIVE handle at once
+    #: (round-4 advisor finding: it used to be read only when a handle was created).
+    _fault_policy = "refuse_next"
+
+    @property
+    def fault_policy(self) -> str:
+        return self._fault_policy
+
+    @fault_policy.setter
+    def fault_policy(self, value: str):
+        if value not in ("refuse_next", "status_only"):
+            raise _capi.Tha4Error(f"unknown fault_policy {value!r} (expected 'refuse_next' or 'status_only')")
+        self._fault_policy = value
+        if getattr(self, "_handle", None) is not None:
+            self._apply_fault_policy(self._handle)
+
+    def _apply_fault_policy(self, handle):
+        _capi.check(self._lib, self._lib.tha4_full_set_fault_policy(handle, 1 if self._fault_policy == "status_only" else 0),
+                    "tha4_full_set_fault_policy")
 
     #: the reference's content rule for the eyebrow-decomposer cache (mode_07.py:56-61), behind the identity / version rules:
     #: costs one device->host synchronisation per call whose identity key misses, like the reference pays on every call
@@ -197,9 +215,7 @@ class HipFullPoser(Poser):
         _capi.check(self._lib, st, "tha4_full_create_ex")
         del keep
         self._handle = handle
-        if self.fault_policy not in ("refuse_next", "status_only"):
-            raise _capi.Tha4Error(f"unknown fault_policy {self.fault_policy!r}")
-        _capi.check(self._lib, self._lib.tha4_full_set_fault_policy(handle, 1 if self.fault_policy == "status_only" else 0), "tha4_full_set_fault_policy")
+        self._apply_fault_policy(handle)
 
     def _run(self, image: Tensor, pose: Tensor, wanted: List[int], image_changed: bool,
              image_version: Optional[int] = None, display=None):

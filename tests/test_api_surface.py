@@ -299,3 +299,39 @@ def test_convolution_prologues_hold_no_integer_division(built):
         assert not [x for x in ins[:first] if "v_rcp" in x], name
         checked += 1
     assert checked == 45 + 9
+
+
+def test_launch_plan_at_the_documented_batch_limit(built):
+    """Round-4 advisor finding: the prologues' host-computed reciprocals (FastDiv) refused the batch-sized divisor of the documented
+    upper bound - max_batch = 256 x 1024 four-wave tiles of a 512x512 map = 2^18 - and the handle failed with a misleading "not a
+    mode_07 model".  Planning is host code: with THA4_DUMP_SCHEDULE set and no device the plan is built and printed before the call
+    fails with THA4_ERR_NO_DEVICE.  Both plans, at the limit; a subprocess because the dump goes to stderr."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.getcwd())
+from tha4_amd import _capi, synthetic
+if torch.cuda.is_available():
+    print("RESULT skipped"); sys.exit(0)
+sd = {net: {k: np.zeros(s, np.float32) for k, s in d.items()} for net, d in synthetic.full_param_shapes().items()}
+ws, keep = _capi.build_full_weights(sd)
+lib = _capi.load_library()
+for flags in (0, 1):
+    h = C.c_void_p()
+    st = lib.tha4_full_create_ex(C.byref(ws), 2, 0, 256, 5, flags, C.byref(h))
+    print("RESULT", flags, st, lib.tha4_last_error().decode())
+'''
+    env = dict(os.environ, THA4_DUMP_SCHEDULE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    if lines == ["RESULT skipped"]:
+        pytest.skip("a device is visible: the plan-only route needs none (the device tests create real handles)")
+    assert len(lines) == 2, r.stdout
+    for l in lines:
+        assert " -3 " in l and "launch plan was printed" in l, l          # THA4_ERR_NO_DEVICE after a complete plan
+    assert "conv #" in r.stderr and "out of range" not in r.stderr

@@ -136,6 +136,17 @@ def test_sine_argument_bound_and_domain(built, golden_weights, char_weights):
         assert 1.0 < b < 64.0, (name, b)                 # the shipped students: a wide margin to 256 turns
     big = {k: (v * 100.0 if k.endswith("sine_layers.3.linear.weight") else v) for k, v in golden_weights.items()}
     assert bound(big) > limit
+    # a NaN weight in an EARLY layer makes the bound NaN whatever follows it (round-4 advisor finding: a later finite row used to
+    # overwrite it), alone and behind an over-limit row
+    def poisoned(with_big):
+        d = {k: np.array(v, copy=True) for k, v in golden_weights.items()}
+        if with_big:
+            d["face.siren.sine_layers.0.linear.weight"] = d["face.siren.sine_layers.0.linear.weight"] * 1000.0
+        d["face.siren.sine_layers.1.linear.weight"][3, 5] = np.nan
+        return d
+    for with_big in (False, True):
+        b = bound(poisoned(with_big))
+        assert np.isnan(b) and not (b < limit), (with_big, b)
     # it IS an upper bound: the largest |30 (W x + b)| / 2 pi the fp64 oracle meets in the face morpher's hidden layers for a pose
     pose = so.random_poses(1, seed=5)[0]
     x = None

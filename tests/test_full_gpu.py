@@ -413,6 +413,24 @@ def test_numeric_range_guard_and_regrow_policy(weights, golden_io, full_io):
     with pytest.raises(_capi.Tha4Error, match="numeric fault"):
         p.check_numeric_range()
     p.free()
+    # the policy reaches a LIVE handle (round-4 advisor finding: it used to be read at handle creation only): default policy,
+    # first pose() creates the handle and faults, THEN the caller switches - the next pose() must not be refused
+    p = mode_07.create_poser_from_state_dicts(dev, bad, max_batch=1)
+    p.pose(image, pose)
+    torch.cuda.synchronize()
+    p.fault_policy = "status_only"
+    p.pose(image, pose)                                              # would raise under "refuse_next"
+    torch.cuda.synchronize()
+    with pytest.raises(_capi.Tha4Error, match="numeric fault"):
+        p.check_numeric_range()
+    p.fault_policy = "refuse_next"                                   # ... and back, on the same handle
+    p.pose(image, pose)
+    torch.cuda.synchronize()
+    with pytest.raises(_capi.Tha4Error, match="numeric fault"):
+        p.pose(image, pose)
+    with pytest.raises(_capi.Tha4Error, match="unknown fault_policy"):
+        p.fault_policy = "ignore"
+    p.free()
     # the same gain at 1e3 (staged values of O(1e3..1e4)) is inside the range: no flag, finite outputs
     ok = copy.deepcopy(weights)
     ok["face_morpher"]["downsample_blocks.0.1.weight"] = ok["face_morpher"]["downsample_blocks.0.1.weight"] * 1e3
