@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 import tha4_amd  # noqa: E402,F401
 from tha4_amd import synthetic  # noqa: E402
 from tha4_amd.poser.modes import mode_07, mode_14  # noqa: E402
-from tha4_amd.sharding import FrameShardedStream  # noqa: E402
+from tha4_amd.sharding import FrameShardedStream, tapered_schedule  # noqa: E402
 from tha4_amd.weights import split_flat_weights  # noqa: E402
 
 # Algorithmic work of the reference's forward passes as written (SURVEY.md §8d, 2*MAC), per 512x512 frame and per
@@ -194,8 +194,8 @@ class StudentWork:
 class FullWork:
     kind = "full"
 
-    def __init__(self, dev, rank, B, steps, steady):
-        self.poser = mode_07.create_poser_from_state_dicts(dev, synthetic.synth_full_weights(), max_batch=B)
+    def __init__(self, dev, rank, B, steps, steady, exact_fp32=False):
+        self.poser = mode_07.create_poser_from_state_dicts(dev, synthetic.synth_full_weights(), max_batch=B, exact_fp32=exact_fp32)
         self.B, self.steady = B, steady
         _, self.image_np = load_character("lambda_00")
         if B == 1:
@@ -235,13 +235,29 @@ def timed_steps(work, lo, hi):
     return out
 
 
-def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fresh=True):
+def gather_plan(args, K, B):
+    """Frames per gather round for a rank that poses K steps of B frames: rounds of `chunk` frames (default: a fifth of the rank's
+    frames, at most 32) ending in a taper, so that the last round - the only exchange nothing overlaps - is at most 5 % of the
+    rank's frames (sharding.tapered_schedule; round-4 review: `--steps 20` used to end on a 4-frame round, 20 % of the stream)."""
+    want_chunk = args.gather_chunk if args.gather_chunk is not None else min(32, max(1, K * B // 5))
+    chunk = max(B, want_chunk // B * B)
+    return chunk, tapered_schedule(K * B, chunk, unit=B, tail_frac=0.05)
+
+
+def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fresh=True, variant=None, rehearse=None):
     """Settle, W warm-up steps, then EXACTLY K timed steps between barriers (N > 1: with the gather of the finished frames to
     rank 0 inside the timed region, after an untimed rehearsal of the exchange).  Returns this rank's elapsed seconds (and, for
     the tests, what rank 0 gathered).  `fresh=False` (the `repeats` of the JSON line) times the same K steps again without
-    settle / warm-up / rehearsal.  Device-agnostic: tests/test_bench_stream_gloo.py runs it on CPU tensors over gloo."""
+    settle / warm-up / rehearsal.  `variant` = "fp32" | "rgba8" | "none" overrides the exchange the command line asks for (the
+    N > 1 line reports all three); `rehearse` forces / suppresses the untimed rehearsal of the exchange (default: with `fresh`).
+    Device-agnostic: tests/test_bench_stream_gloo.py runs it on CPU tensors over gloo."""
     cuda = dev.type == "cuda"
-    gather = world > 1 and not args.no_gather
+    if variant is None:
+        variant = "none" if args.no_gather else ("rgba8" if args.rgba8_gather else "fp32")
+    gather = world > 1 and variant != "none"
+    rgba8 = variant == "rgba8"
+    if rehearse is None:
+        rehearse = fresh
     frames = None
 
     def barrier():
@@ -265,13 +281,13 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
             work.settle_steps = settle_steps
             timed_steps(work, 0, W)
         if gather:
-            want_chunk = args.gather_chunk if args.gather_chunk is not None else min(32, max(1, K * B // 5))
-            chunk = max(B, want_chunk // B * B)
-            shape, dtype = ((512, 512, 4), torch.uint8) if args.rgba8_gather else ((4, 512, 512), torch.float32)
+            chunk, schedule = gather_plan(args, K, B)
+            work.gather_schedule = schedule
+            shape, dtype = ((512, 512, 4), torch.uint8) if rgba8 else ((4, 512, 512), torch.float32)
 
             # frames leave the rank as fp32 [4,512,512] or - display epilogue FUSED into the composing kernel (tha4_display) -
             # as uint8 [512,512,4]: a quarter of the bytes, and no fp32 frame is ever written
-            step = work.step_rgba8 if args.rgba8_gather else work.step
+            step = work.step_rgba8 if rgba8 else work.step
 
             def frame_fn(lo, hi):          # global frame ids of this rank start at rank*K*B; whole steps only
                 base = rank * K * B
@@ -288,10 +304,11 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
                     step(0, out=blk[f:f + B])
                 return blk
 
-            if fresh:
+            if rehearse:
                 FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
             if return_frames:              # tests: archive the whole (short) stream on rank 0
-                stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True)
+                stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True,
+                                            schedule=schedule)
                 gathered = stream.allocate_result()       # allocated outside the timed region
             else:
                 # the root is a STREAM: a ring of 3 gather rounds (world x chunk frames each; 8 x 32 x 4 MiB x 3 = 3 GiB) whose
@@ -302,7 +319,7 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
                     work.delivered += hi - lo
 
                 stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True,
-                                            on_chunk=consume, ring_slots=3)
+                                            on_chunk=consume, ring_slots=3, schedule=schedule)
                 work.ring_bytes = stream.ring_bytes()
                 gathered = None
             barrier()
@@ -322,6 +339,43 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
             barrier()
             t1 = time.perf_counter()
     return (t1 - t0, frames) if return_frames else t1 - t0
+
+
+def run_regions(work, args, dev, rank, world, K, W, B, dist):
+    """The timed regions of one bench run: `value`'s region, its `--repeats`, and - N > 1 - the same K steps under each form of the
+    exchange.  Returns (elapsed of the first region, frames/s of the repeats, per-variant dict or None, name of the primary form).
+    Shared by the real run and `--stub-gloo` (tests)."""
+    def region(**kw):                      # one timed region: this rank's seconds -> maximum over ranks
+        e = measure(work, args, dev, rank, world, K, W, B, dist, **kw)
+        if world > 1:
+            t = torch.tensor([e], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
+
+    elapsed = region()
+    # `value` is the region above; the SAME K steps are timed `--repeats` more times so that a short region (20 steps of the student
+    # stream = 2.5 ms) carries its own spread.  Same barriers, maximum over ranks per repeat.
+    rep_fps = [K * B * world / region(fresh=False) for _ in range(max(0, args.repeats))]
+    # N > 1: the same K steps under each form of the exchange - fp32 frames (what Poser.pose() returns: the default and `value`),
+    # RGBA8 frames (display epilogue fused into the composing kernel: a quarter of the bytes) and no exchange at all - so that a
+    # scaling figure below target is attributable to the gather (xGMI / root ingest) or to the compute path (round-4 review)
+    primary = "none" if args.no_gather else ("rgba8" if args.rgba8_gather else "fp32")
+    variants = None
+    if world > 1:
+        variants = {}
+        for v in ("fp32", "rgba8", "none"):
+            if v == primary:
+                es = [elapsed] + [K * B * world / f for f in rep_fps]
+            else:
+                region(fresh=False, rehearse=True, variant=v)              # untimed: first use of this form (buffers, connections)
+                es = [region(fresh=False, variant=v) for _ in range(max(1, min(3, args.repeats)))]
+            e = float(np.median(es))
+            frame_bytes = {"fp32": 4 * 512 * 512 * 4, "rgba8": 512 * 512 * 4, "none": 0}[v]
+            variants[v] = {"fps": round(K * B * world / e, 2), "per_gpu_fps": round(K * B / e, 2), "regions": len(es),
+                           "root_ingest_GBps": round((world - 1) * K * B * frame_bytes / e / 1e9, 2),
+                           "per_sender_GBps": round(K * B * frame_bytes / e / 1e9, 2)}
+    return elapsed, rep_fps, variants, primary
 
 
 def main():
@@ -383,21 +437,7 @@ def main():
     work = StudentWork(dev, rank, B, K + W, characters) if student else FullWork(dev, rank, B, K + W, steady=not args.cold)
     gather = world > 1 and not args.no_gather
 
-    elapsed = measure(work, args, dev, rank, world, K, W, B, dist)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # `value` is the region above; the SAME K steps are timed `--repeats` more times so that a short region (20 steps of the student
-    # stream = 2.5 ms) carries its own spread.  Same barriers, maximum over ranks per repeat.
-    rep_fps = []
-    for _ in range(max(0, args.repeats)):
-        e = measure(work, args, dev, rank, world, K, W, B, dist, fresh=False)
-        if world > 1:
-            t = torch.tensor([e], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e = float(t.item())
-        rep_fps.append(K * B * world / e)
+    elapsed, rep_fps, variants, primary = run_regions(work, args, dev, rank, world, K, W, B, dist)
 
     if rank == 0:
         fps = K * B * world / elapsed
@@ -414,6 +454,16 @@ def main():
                "gather": ("rgba8 (display epilogue fused into the composing kernel)" if args.rgba8_gather else "fp32") if gather else False}
         if gather:
             par["gather_root_ring_bytes"] = getattr(work, "ring_bytes", None)
+        if variants is not None:
+            sched = getattr(work, "gather_schedule", None)
+            par["gather_schedule"] = ({"frames_per_round": sched, "rounds": len(sched),
+                                       "unoverlapped_tail_fraction": round(sched[-1] / max(1, K * B), 4),
+                                       "what": "frames of every rank per gather round; round c's exchange runs on a side stream under round c+1's compute, "
+                                               "only the last round's is exposed (sharding.tapered_schedule)"} if sched else None)
+            result["gather_variants"] = dict(variants, value_is=primary,
+                                             what="median of the timed regions of the same K steps under each form of the exchange to rank 0 (whole-job frames/s); "
+                                                  "root_ingest_GBps = bytes arriving at rank 0 from the other ranks / region time; `value` is the "
+                                                  f"'{primary}' form's first region")
         if student:
             result["data"] = ("synthetic pose stream (seed 1234+rank, pose_parameters ranges); shipped student weights + character image "
                               "(tests/golden fixtures made from the reference's lambda_00 / lambda_01 .pt and .png)")
@@ -467,19 +517,20 @@ def stub_gloo_main(args, rank, world):
     K = args.steps if args.steps is not None else 4
     W = args.warmup if args.warmup is not None else 1
     work = _StubWork(rank, B)
-    elapsed = measure(work, args, dev, rank, world, K, W, B, dist)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if args.repeats == 5:                  # (the real run's default; the stub's regions are CPU fills of 4 MiB frames)
+        args.repeats = 1
+    elapsed, rep_fps, variants, primary = run_regions(work, args, dev, rank, world, K, W, B, dist)
     if rank == 0:
         gather = world > 1 and not args.no_gather
+        sched = getattr(work, "gather_schedule", None)
         print(json.dumps({"metric": "STUB: driver logic only, nothing was posed", "value": round(K * B * world / elapsed, 2), "unit": "stub frames/s",
                           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "gather_variants": dict(variants, value_is=primary) if variants else None,
                           "config": {"workload": "stub (tests/test_bench_launch_gloo.py)", "frames_per_gpu": K * B, "batch": B,
                                      "parallelism": f"frame-parallel x{world}",
                                      "gather": ("rgba8" if args.rgba8_gather else "fp32") if gather else False,
+                                     "gather_schedule": sched if world > 1 else None,
                                      "gather_root_ring_bytes": getattr(work, "ring_bytes", None) if gather else None,
                                      "delivered": getattr(work, "delivered", None) if gather else None}}), flush=True)
     if world > 1:
@@ -613,6 +664,19 @@ def student_extras(args, work, dev, world, fps, K, W, B):
             fw = FullWork(dev, 0, 1, args.full_frames + 3, steady=True)
             out["full_model"] = measure_full_b1(fw, dev, args.full_frames)
             fw.poser.free()
+            out["full_model"]["roofline"] = full_roofline(out["full_model"]["steady"]["fps"], GFLOP_FULL_STEADY, cold=False, batch1=True)
+            # the strict-precision number next to it: the same frames on the exact-fp32 plan (THA4_FULL_EXACT_FP32: every convolution on
+            # v_mfma_f32_16x16x4_f32 with fp32 operands - no 22-bit operand split to argue about)
+            nx = max(6, min(12, args.full_frames // 2))
+            fx = FullWork(dev, 0, 1, nx + 3, steady=True, exact_fp32=True)
+            ex = measure_full_b1(fx, dev, nx)
+            fx.poser.free()
+            for k in ("steady", "cold"):
+                ex[k]["frac_of_fp32_mfma_peak"] = round(ex[k]["achieved_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+                ex[k].pop("frac_of_f16_mfma_peak", None)
+                ex[k].pop("frac_of_split_ceiling", None)
+            ex["what"] = f"the same workload on the exact-fp32 plan (tha4_full_create_ex flags = THA4_FULL_EXACT_FP32), {nx} frames each"
+            out["full_model"]["exact_fp32"] = ex
         except Exception as e:
             out["full_model"] = {"error": repr(e)}
     if single and args.batched_steps > 0:
@@ -668,20 +732,34 @@ def measure_full_b1(fw, dev, frames):
     return res
 
 
+def full_roofline(fps_per_gpu, gflop, cold, batch1):
+    """Roofline object of the full model: the frame is ~320 launches of a static schedule, so the unit is the WHOLE FRAME (as-written
+    FLOPs of the reference's five networks / measured frame time) against the dense fp16 MFMA peak of the instruction issued; the
+    launch class with the largest share of the frame in the newest committed rocprofv3 capture is quoted beside it with its own
+    per-launch figures (profiles/r*_full_b1_layers.json, written by tools/conv_breakdown.py from the kernel trace)."""
+    ach = fps_per_gpu * gflop / 1e3
+    prof, prof_file = newest_profile("r*_full_b1_traffic.json")
+    per_frame = prof.get("cold_frame_bytes" if cold else "steady_frame_bytes") if (prof and batch1) else None
+    layers, layers_file = newest_profile("r*_full_b1_layers.json")
+    dominant = None
+    if layers and batch1 and layers.get("classes"):
+        c = max(layers["classes"], key=lambda r: r["total_us"])
+        dominant = dict(c, frac_of_f16_mfma_peak=round(c["tflops"] / PEAK_F16_MFMA_TFLOPS, 4), source=layers_file,
+                        what="the launch class (kind, map, channels) with the largest total time per cold frame in that capture: "
+                             "as-written TFLOP/s of its launches")
+    return {"bound": "mfma", "kernel": "whole frame (static schedule of conv_tile / conv_small / conv_point / attention / image kernels)",
+            "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
+            "frac_of_split_ceiling": round(ach * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
+            "vs_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
+            "traffic": per_frame, "traffic_unit": f"bytes/frame = sum over the frame's launches of 2 x FETCH_SIZE + WRITE_SIZE ({prof_file})",
+            "dominant_class": dominant, "algorithmic_gflop_per_frame": gflop}
+
+
 def full_extras(args, work, dev, world, fps, B):
     cold = args.cold or B > 1
     gflop = GFLOP_FULL_COLD if cold else GFLOP_FULL_STEADY
-    ach = fps / world * gflop / 1e3
-    prof, prof_file = newest_profile("r*_full_b1_traffic.json")
-    per_frame = None
-    if prof and B == 1:
-        per_frame = prof.get("cold_frame_bytes" if cold else "steady_frame_bytes")
-    roofline = {"bound": "mfma", "kernel": "whole frame (static schedule of conv_tile / conv_small / conv_point / attention / image kernels)",
-                "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
-                "frac_of_split_ceiling": round(ach * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
-                "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
-                "traffic": per_frame, "traffic_unit": f"bytes/frame = sum over the frame's launches of 2 x FETCH_SIZE + WRITE_SIZE ({prof_file})",
-                "algorithmic_gflop_per_frame": gflop}
+    roofline = full_roofline(fps / world, gflop, cold, B == 1)
     out = {"roofline": roofline, "cpu_baseline": None}
     if world == 1 and B == 1:
         other = FullWork.__new__(FullWork)

@@ -30,6 +30,30 @@ def all_shard_sizes(total: int, world: int) -> List[int]:
     return [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
 
 
+def tapered_schedule(frames: int, chunk: int, unit: int = 1, tail_frac: float = 0.05) -> List[int]:
+    """Gather-round sizes for a rank that produces ``frames`` frames in calls of ``unit`` frames: full ``chunk``s first, then
+    rounds that halve down to the smallest one, whose exchange is the only part of the stream that nothing overlaps (round c's
+    gather runs on the side stream under round c + 1's compute; behind the LAST round there is no compute left).  The last round
+    is at most ``tail_frac`` of the rank's frames (never less than one call: ``unit``), so a short region - the driver's
+    ``--steps 20`` - does not end on a full-chunk exchange (round-4 review: 4 of 20 frames = 20 % of the stream exposed).
+    Every size is a multiple of ``unit``; the sizes sum to ``frames`` and never increase."""
+    if frames < 0 or chunk < 1 or unit < 1 or frames % unit:
+        raise ValueError(f"bad schedule request frames={frames} chunk={chunk} unit={unit}")
+    chunk = max(unit, chunk // unit * unit)
+    last = max(unit, int(frames * tail_frac) // unit * unit)
+    taper, t = [], last                           # last, 2 last, 4 last, ... (all below a full chunk)
+    while t < chunk:
+        taper.append(t)
+        t *= 2
+    while taper and sum(taper) > frames:          # a stream shorter than its taper: drop the largest rounds
+        taper.pop()
+    body = frames - sum(taper)
+    sizes = [chunk] * (body // chunk) + ([body % chunk] if body % chunk else []) + taper
+    sizes.sort(reverse=True)
+    assert sum(sizes) == frames and all(x > 0 and x % unit == 0 for x in sizes)
+    return sizes
+
+
 class FrameShardedStream:
     """Pose a stream of ``total`` independent frames split across the ranks of ``group``.
 
@@ -43,7 +67,7 @@ class FrameShardedStream:
                  dtype: torch.dtype, device: torch.device, chunk: int = 32,
                  group: Optional[dist.ProcessGroup] = None, gather: bool = True,
                  on_chunk: Optional[Callable[[int, int, torch.Tensor], None]] = None, ring_slots: int = 3,
-                 force_collective: bool = False):
+                 force_collective: bool = False, schedule: Optional[Sequence[int]] = None):
         """``on_chunk(lo, hi, frames)`` switches the root from an ARCHIVE of the whole stream (``allocate_result``:
         ``total`` frames on rank 0 - 2000 steps x 32 frames x 8 ranks would be 2 TB) to a STREAM: rank 0 owns a ring of
         ``ring_slots`` buffers of one gather round each (``world x chunk`` frames: 3 x 8 x 32 x 4 MiB = 3 GiB) and hands
@@ -66,6 +90,11 @@ class FrameShardedStream:
         self.dtype = dtype
         self.device = torch.device(device)
         self.chunk = max(1, int(chunk))
+        self.schedule = [int(x) for x in schedule] if schedule is not None else None
+        if self.schedule is not None:
+            if any(x < 1 for x in self.schedule):
+                raise ValueError("schedule entries must be positive")
+            self.chunk = max(self.schedule) if self.schedule else self.chunk
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.distributed else 0
@@ -95,7 +124,19 @@ class FrameShardedStream:
 
     def run(self, result: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         sizes = all_shard_sizes(self.total, self.world)
-        rounds = max((s + self.chunk - 1) // self.chunk for s in sizes)
+        if self.schedule is not None:
+            if sum(self.schedule) < max(sizes):
+                raise RuntimeError(f"the gather schedule covers {sum(self.schedule)} frames, the largest shard has {max(sizes)}")
+            starts, acc = [], 0
+            for x in self.schedule:
+                starts.append(acc)
+                acc += x
+            rounds = sum(1 for st in starts if st < max(sizes))
+            round_size = list(self.schedule)
+        else:
+            rounds = max((s + self.chunk - 1) // self.chunk for s in sizes)
+            starts = [c * self.chunk for c in range(rounds)]
+            round_size = [self.chunk] * rounds
         streaming = self.gather and self.on_chunk is not None
         local_streaming = (not self.gather) and self.on_chunk is not None      # no exchange: this rank's blocks go straight to the consumer
         ring = None
@@ -116,8 +157,8 @@ class FrameShardedStream:
 
         def span(r, c):                      # global rows [a, b) rank r produces in round c (analytic: no size exchange)
             rlo, rhi = shard_bounds(self.total, r, self.world)
-            a = min(rlo + c * self.chunk, rhi)
-            return a, min(a + self.chunk, rhi)
+            a = min(rlo + starts[c], rhi)
+            return a, min(a + round_size[c], rhi)
 
         if self.gather and rounds > 0:
             # RCCL builds a group's communicator lazily inside the first operation and that blocks until EVERY rank of the
@@ -137,7 +178,7 @@ class FrameShardedStream:
                         result[a - self.lo:b - self.lo] = block
                 continue
             spans = [span(r, c) for r in range(self.world)]
-            full_round = all(rb - ra == self.chunk for ra, rb in spans)
+            full_round = all(rb - ra == round_size[c] for ra, rb in spans)
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 if block is not None:

@@ -114,9 +114,10 @@ def test_oracle_matches_the_pinned_sweep_and_edge_poses(character, char_weights,
 def test_local_affine_grid_table_against_the_fixture_build():
     """The kernels take the LOCAL torch build's fp32 `affine_grid` axes (`match_aten_positions=True`: they track "the reference on
     this machine"); the committed reference frames were made with the torch build recorded in the sweep fixture.  A different
-    local table moves up to ~1e-4 of the 1e-3 budget (test_exact_positions_shift_output_by_1e4): never silently - this test WARNS
-    with both versions and the number of differing entries (and fails only if an axis is outside what fp32 linspace rounding can
-    produce, i.e. more than 1 ulp from the exact dyadic grid)."""
+    local table moves up to ~1e-4 of the 1e-3 budget (test_exact_positions_shift_output_by_1e4): never silently - this test FAILS
+    with both versions and the number of differing entries (round-4 review: a warning is not a gate), unless the environment says
+    the mismatch is known and accepted (THA4_ACCEPT_AFFINE_GRID_MISMATCH=1: the reference frames then carry that much less margin);
+    it also fails if an axis is outside what fp32 linspace rounding can produce (more than 1 ulp from the exact dyadic grid)."""
     import os
     import warnings
     import torch
@@ -132,6 +133,11 @@ def test_local_affine_grid_table_against_the_fixture_build():
         if n:
             differing[sz] = n
     if differing:
-        warnings.warn(f"local torch {torch.__version__} produces a different fp32 affine_grid table than the fixtures' torch "
-                      f"{str(z['torch_version'])}: differing entries {differing} - the kernels follow the LOCAL table, the committed reference "
-                      f"frames the fixture's (up to ~1e-4 of the 1e-3 budget)", RuntimeWarning)
+        msg = (f"local torch {torch.__version__} produces a different fp32 affine_grid table than the fixtures' torch "
+               f"{str(z['torch_version'])}: differing entries {differing} - the kernels follow the LOCAL table, the committed reference "
+               f"frames the fixture's (up to ~1e-4 of the 1e-3 budget); regenerate the fixtures (tests/golden/make_golden*.py) or set "
+               f"THA4_ACCEPT_AFFINE_GRID_MISMATCH=1")
+        if os.environ.get("THA4_ACCEPT_AFFINE_GRID_MISMATCH") == "1":
+            warnings.warn(msg, RuntimeWarning)
+        else:
+            pytest.fail(msg)

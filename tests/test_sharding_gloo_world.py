@@ -245,9 +245,89 @@ def test_bench_py_gpus_8_launched_like_the_driver_under_gloo(extra):
     else:
         assert j["config"]["delivered"] == 8 * K * B                # the root's consumer saw every frame of every rank once
         assert j["config"]["gather"] == ("rgba8" if "--rgba8-gather" in extra else "fp32")
+    # the N > 1 line carries all three forms of the exchange (round-4 review), `value` being the one the command line asks for
+    gv = j["gather_variants"]
+    assert set(gv) == {"fp32", "rgba8", "none", "value_is"}
+    assert gv["value_is"] == ("none" if "--no-gather" in extra else "rgba8" if "--rgba8-gather" in extra else "fp32")
+    for v in ("fp32", "rgba8", "none"):
+        assert gv[v]["fps"] > 0 and gv[v]["regions"] >= 1
+    assert gv["none"]["root_ingest_GBps"] == 0
+    # ... and the gather rounds end on a taper: whole calls, never increasing, the exposed last round <= max(one call, 5 %)
+    sched = j["config"]["gather_schedule"]
+    assert sum(sched) == K * B and all(x % B == 0 for x in sched) and sched == sorted(sched, reverse=True)
+    assert sched[-1] <= max(B, int(0.05 * K * B))
+
+
+def test_tapered_schedule_tail_rule():
+    """The gather schedule of `bench.py --gpus N`: the only exchange nothing overlaps is the last round's, so it is at most 5 % of
+    the rank's frames (one call at least) - at the driver's `--steps 20` the default used to end on 4 of 20 frames."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tha4_amd.sharding import tapered_schedule
+    for K, B, chunk in [(20, 1, None), (20, 1, 32), (2000, 1, None), (64, 32, None), (20, 8, None), (100, 1, None), (5, 1, None), (1, 1, None),
+                        (7, 2, 6), (1000, 4, 100)]:
+        args = argparse.Namespace(gather_chunk=chunk)
+        c, sched = bench.gather_plan(args, K, B)
+        assert sum(sched) == K * B and all(x > 0 and x % B == 0 for x in sched), (K, B, sched)
+        assert sched == sorted(sched, reverse=True) and max(sched) <= c
+        assert sched[-1] <= max(B, int(0.05 * K * B)), (K, B, sched)
+    assert bench.gather_plan(argparse.Namespace(gather_chunk=None), 20, 1)[1] == [4, 4, 4, 4, 2, 1, 1]
+    assert tapered_schedule(0, 4) == []
+    with pytest.raises(ValueError):
+        tapered_schedule(5, 4, unit=2)
 
 
 def test_bench_py_refuses_a_rank_count_that_differs_from_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub-gloo"], capture_output=True, text=True,
                        timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0"), cwd=ROOT)
     assert r.returncode != 0 and "needs torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def _schedule_worker(rank, world, rendezvous, total, schedule, streaming, q):
+    _init(rank, world, rendezvous)
+    calls, got = [], []
+
+    def frame_fn(lo, hi):
+        calls.append((lo, hi))
+        return torch.stack([_frame(i) for i in range(lo, hi)])
+
+    # (numpy through the result queue: tensors travel as file descriptors the exiting worker may close first)
+    kw = dict(on_chunk=lambda lo, hi, fr: got.append((lo, hi, fr.numpy().copy())), ring_slots=2) if streaming else {}
+    s = FrameShardedStream(frame_fn, total, (2, 4, 4), torch.float32, torch.device("cpu"), chunk=99, gather=True, schedule=schedule, **kw)
+    out = s.run()
+    q.put((rank, calls, got, None if out is None else out.numpy().copy(), s.ring_bytes()))
+    _finish()
+
+
+@pytest.mark.parametrize("world,total,schedule,streaming", [
+    (3, 23, [4, 2, 1, 1], False),      # ragged shards 8 / 8 / 7 under a tapered schedule: the last round is a tail for rank 2 only
+    (3, 24, [4, 2, 1, 1], True),       # equal shards, streaming root with a 2-slot ring sized for the LARGEST round
+    (8, 160, [4, 4, 4, 4, 2, 1, 1], True),     # the driver's `--steps 20` at world 8
+    (3, 5, [4, 2, 1, 1], False),       # a schedule longer than the stream: the surplus rounds never run
+])
+def test_gather_under_a_tapered_schedule(world, total, schedule, streaming):
+    res = _spawn(_schedule_worker, world, (total, schedule, streaming))
+    for r in range(world):
+        lo, hi = shard_bounds(total, r, world)
+        done = [i for (a, b) in res[r][1] for i in range(a, b)]
+        assert done == list(range(lo, hi))
+        sizes = [b - a for a, b in res[r][1]]
+        assert all(x <= s for x, s in zip(sizes, schedule)) and sum(sizes) == hi - lo
+    if streaming:
+        seen = sorted((a, b) for a, b, _ in res[0][2])
+        assert [i for a, b in seen for i in range(a, b)] == list(range(total))
+        for a, b, fr in res[0][2]:
+            for i in range(a, b):
+                assert (fr[i - a] == _frame(i).numpy()).all()
+        assert res[0][4] == 2 * world * max(schedule) * 2 * 4 * 4 * 4          # ring: slots x world x largest round x frame bytes
+    else:
+        full = res[0][3]
+        assert full.shape == (total, 2, 4, 4)
+        for i in range(total):
+            assert (full[i] == _frame(i).numpy()).all()
+
+
+def test_a_schedule_that_does_not_cover_the_largest_shard_is_refused():
+    s = FrameShardedStream(lambda lo, hi: torch.zeros(hi - lo, 1), 10, (1,), torch.float32, torch.device("cpu"), gather=False, schedule=[4, 2])
+    with pytest.raises(RuntimeError, match="covers 6 frames"):
+        s.run()

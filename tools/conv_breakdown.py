@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Join the conv schedule dump (THA4_DUMP_SCHEDULE=1, stderr of poser creation) with a rocprofv3 kernel trace:
-per-layer time of the LAST cold frame.  usage: conv_breakdown.py <schedule.txt> <kernel_trace.csv>"""
+per-layer time of the LAST cold frame.  usage: conv_breakdown.py <schedule.txt> <kernel_trace.csv> [<classes.json>]
+(the JSON - profiles/rNN_full_b1_layers.json - is what bench.py's full-model roofline quotes its dominant launch class from)"""
 import csv
 import re
 import sys
@@ -43,3 +44,13 @@ print(f"total conv time {tot / 1e3:.2f} ms")
 for key, (cnt, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"kind={key[0]} tile={key[1]:8s} mode={key[2]} cin={key[3]:4d} cout={key[4]:>4s} splitk={key[5]} tmb={key[6]} pg={key[7]} wgs={key[8]:>5s} ksplit={key[9]:>2s}  "
           f"launches={cnt:3d}  total={us:8.1f} us  avg={us / cnt:7.1f} us  {gf / (us * 1e-6) / 1e3:6.1f} TFLOP/s")
+
+if len(sys.argv) > 3:
+    import json
+    kinds = {"0": "conv3x3", "1": "conv1x1", "2": "conv4x4 stride 2", "3": "convT4x4 stride 2"}
+    classes = [{"class": f"{kinds.get(key[0], key[0])} {key[1]} cin={key[3]} cout={key[4]}", "in_mode": int(key[2]), "kernel": ("conv_small_kernel" if key[5].endswith("S") else
+                "conv_point_kernel" if key[5].endswith("P") else "conv_tile_kernel"), "tmb": int(key[6]), "pg": int(key[7]), "workgroups": int(key[8]), "ksplit": int(key[9]),
+                "launches": cnt, "total_us": round(us, 1), "avg_us": round(us / cnt, 2), "gflop_per_launch": round(gf / cnt, 4), "tflops": round(gf / (us * 1e-6) / 1e3, 1)}
+               for key, (cnt, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+    json.dump({"source": "tools/conv_breakdown.py: schedule dump (THA4_DUMP_SCHEDULE) joined with the rocprofv3 --kernel-trace of the last cold frame",
+               "conv_launches_per_cold_frame": n, "total_conv_us": round(tot, 1), "classes": classes}, open(sys.argv[3], "w"), indent=1)
