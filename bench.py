@@ -677,6 +677,7 @@ def student_extras(args, work, dev, world, fps, K, W, B):
                 ex[k].pop("frac_of_split_ceiling", None)
             ex["what"] = f"the same workload on the exact-fp32 plan (tha4_full_create_ex flags = THA4_FULL_EXACT_FP32), {nx} frames each"
             out["full_model"]["exact_fp32"] = ex
+            out["full_model"]["two_frames_in_flight"] = measure_full_two_in_flight(dev, args.full_frames)
         except Exception as e:
             out["full_model"] = {"error": repr(e)}
     if single and args.batched_steps > 0:
@@ -730,6 +731,35 @@ def measure_full_b1(fw, dev, frames):
                          "frac_of_f16_mfma_peak": round(f * gflop / 1e3 / PEAK_F16_MFMA_TFLOPS, 4),
                          "frac_of_split_ceiling": round(f * gflop * MFMA_PASSES / 1e3 / PEAK_F16_MFMA_TFLOPS, 4)}
     return res
+
+
+def measure_full_two_in_flight(dev, frames):
+    """NOT the configs[2] number (that is one pose() after the other on one stream): the same batch-1 frames through TWO handles on two
+    streams, frame i on stream i % 2 - what a throughput caller (offline rendering, a second character) gets from a chip that a single
+    batch-1 frame leaves latency-bound (a frame is a chain of ~320 dependent launches).  Host-side only: no kernel differs."""
+    try:
+        works = [FullWork(dev, 0, 1, frames + 3, steady=True) for _ in range(2)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        with torch.no_grad():
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    for i in range(3):
+                        works[k].step(i)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(frames):
+                with torch.cuda.stream(streams[i % 2]):
+                    works[i % 2].step(3 + i)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        for wk in works:
+            wk.poser.free()
+        f = frames / dt
+        return {"fps": round(f, 2), "frames": frames, "achieved_tflops": round(f * GFLOP_FULL_STEADY / 1e3, 2),
+                "what": "steady batch-1 frames alternating over two handles on two streams (two independent frames in flight); "
+                        "never `value`, never the configs[2] figure"}
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def full_roofline(fps_per_gpu, gflop, cold, batch1):

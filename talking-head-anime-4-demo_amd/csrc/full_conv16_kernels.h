@@ -169,14 +169,19 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   // (every divisor below is a launch constant with a host-computed reciprocal - FastDiv, full_kernels.h)
   const int tiles_x = a.tiles_x;
   const int tiles_per_frame = a.tiles_per_frame;
-  int cls = 0, bx = (int)blockIdx.x;                        // merged transposed convolution: the parity class is the slowest part of blockIdx.x
+  int cls = 0, bx = (int)blockIdx.x, mtile = (int)blockIdx.y;   // merged transposed convolution: the parity class is the slowest part of the x index
+  if (a.xcd_remap) {                                        // 1-D grid: the output-channel tiles of one pixel tile are consecutive workgroups of one XCD (ConvArgs::xcd_remap)
+    const int xcd = bx & 7, s = bx >> 3;
+    const int ts = fast_div(s, a.d_mtiles);
+    mtile = s - ts * a.d_mtiles.d;
+    bx = ts * 8 + xcd;
+  }
   if (a.nclass > 1) { cls = fast_div(bx, a.d_class); bx -= cls * a.d_class.d; }
   const ConvClass cg = conv_class(a, cls, tiles_per_frame);
   const int n = fast_div(bx, a.d_tpf);
   const int tile = bx - n * tiles_per_frame;
   const int tile_row = fast_div(tile, a.d_tiles_x);
   const int tile_y0 = tile_row * TWH, tile_x0 = (tile - tile_row * tiles_x) << twl;
-  const int mtile = blockIdx.y;
   const int vh = INMODE == IN_UP2 ? a.in_h * 2 : (kPool ? a.in_h / 2 : a.in_h);
   const int vw = INMODE == IN_UP2 ? a.in_w * 2 : (kPool ? a.in_w / 2 : a.in_w);
   const int in_px = a.in_h * a.in_w;

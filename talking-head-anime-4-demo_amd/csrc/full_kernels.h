@@ -126,6 +126,11 @@ struct ConvArgs {
   FastDiv d_tiles_x, d_tpf, d_upq, d_win_w, d_ntc;
   FastDiv d_group;                 // batch * tiles_per_frame
   FastDiv d_class;                 // workgroups of one parity class: conv_small batch * tiles_per_frame * nb, conv_tile batch * tiles_per_frame
+  // conv_tile_kernel, XCD-aware workgroup order (round 5, finish_conv_remap): 1 = a 1-D grid of gx * mtiles workgroups in which the `mtiles` output-channel
+  // tiles of one pixel tile are CONSECUTIVE workgroups of ONE XCD (workgroups are dealt round-robin to the 8 XCDs: id & 7), so that the fp32 window lines the
+  // first of them fetches are L2 hits for the others; 0 = the (gx, mtiles) grid of rounds 2-4 (same XCD when gx % 8 == 0, but a whole grid row apart in time)
+  int xcd_remap;
+  FastDiv d_mtiles;
 #ifdef THA4_PHASE_TIMING
   long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
 #endif
@@ -151,6 +156,13 @@ inline bool finish_conv_args(ConvArgs& a, int px_per_wg, int nq) {
 inline bool finish_conv_batch(ConvArgs& a, bool small, long long grid_x) {
   const long long g = (long long)a.batch * a.tiles_per_frame;
   return grid_x < (1 << 22) && fastdiv_make(a.d_group, g) && fastdiv_make(a.d_class, small ? g * a.nb : g);
+}
+
+// Host, per call: the XCD-aware order applies when the x extent deals whole pixel tiles to XCDs (gx % 8 == 0) and there is more than one output-channel tile.
+inline bool finish_conv_remap(ConvArgs& a, int mtiles, long long gx) {
+  a.xcd_remap = 0;
+  if (mtiles > 1 && gx > 0 && (gx & 7) == 0 && gx * mtiles < (1 << 22) && fastdiv_make(a.d_mtiles, mtiles)) a.xcd_remap = 1;
+  return a.xcd_remap != 0;
 }
 
 // Geometry of one launch class.  Merged transposed convolution (nclass = 4): class (py, px), tap t = 2a + b reads input (i + dd[py][a],

@@ -110,11 +110,60 @@ class FullModel {
   // ---- schedule -------------------------------------------------------------------------------
   struct Frame {            // per-call bindings
     const float* image; long long image_stride; const float* pose; int batch; hipStream_t stream;
+    hipStream_t side;       // second stream of the handle for independent side branches (null: everything on `stream`)
     float* out[33];         // NCHW outputs in the reference order (never null: unrequested ones point into scratch)
     unsigned char* rgba8; int rgba8_has_bg; float rgba8_bg[3];    // fused display epilogue of out[0] (tha4_display) or null
   };
   using Op = std::function<void(const Frame&)>;
   std::vector<Op> ops_decomposer, ops_rest;
+
+  // ---- side branches (round 5) ------------------------------------------------------------------
+  // A batch-1 frame is a chain of ~320 DEPENDENT launches, each a chain of dependent memory round trips: the chip idles
+  // on latency, not on throughput.  The few branches of the graph that do NOT lie on that chain - the 1x1 skip convolution of every
+  // ResBlock that changes width (unet.py:149-152: it reads the block's INPUT, the chain runs norm0 -> conv0 -> norm1 beside it), the
+  // cond MLP + FiLM projections of both U-Nets (they read the pose only) - are enqueued on a second stream of the handle between a fork
+  // (side waits for main) and a join (main waits for side) and run under the main chain.  Same kernels on the same operands: the bytes of
+  // a frame do not change.  Events are taken round-robin from a small pool; cudaStreamWaitEvent captures the state of the event at the
+  // call, so re-recording it later is safe.
+  hipStream_t side_stream = nullptr;               // owned by the C ABI handle (created / destroyed there)
+  std::vector<hipEvent_t> side_events;
+  size_t side_cursor = 0;
+  int side_branches = 0;                           // fork / join pairs per steady frame (diagnostics)
+  hipEvent_t next_side_event() { return side_events[side_cursor++ % side_events.size()]; }
+  bool side_planned() const { return !tune_env("THA4_NO_SIDE_STREAM"); }
+  // fork: everything emitted between side_fork() and side_join() that is wrapped by side_wrap() runs on the side stream
+  size_t side_fork(std::vector<Op>& ops) {
+    if (!side_planned()) return ops.size();
+    ++side_branches;
+    ops.push_back([this](const Frame& f) {
+      if (!f.side) return;
+      hipEvent_t e = next_side_event();
+      (void)hipEventRecord(e, f.stream);
+      (void)hipStreamWaitEvent(f.side, e, 0);
+    });
+    return ops.size();
+  }
+  void side_wrap(std::vector<Op>& ops, size_t first) {        // ops [first, end) -> the side stream
+    if (!side_planned()) return;
+    for (size_t i = first; i < ops.size(); ++i) {
+      Op inner = ops[i];
+      ops[i] = [inner](const Frame& f) {
+        if (!f.side) return inner(f);
+        Frame g = f;
+        g.stream = f.side;
+        inner(g);
+      };
+    }
+  }
+  void side_join(std::vector<Op>& ops) {
+    if (!side_planned()) return;
+    ops.push_back([this](const Frame& f) {
+      if (!f.side) return;
+      hipEvent_t e = next_side_event();
+      (void)hipEventRecord(e, f.side);
+      (void)hipStreamWaitEvent(f.stream, e, 0);
+    });
+  }
   size_t scratch_out[33];   // workspace offsets used for outputs the caller did not ask for
   int out_ch[33], out_size[33];
 
@@ -201,6 +250,11 @@ class FullModel {
     const int bit = tmb == 4 && pg == 1 ? 1 : tmb == 2 && pg == 4 ? 2 : tmb == 2 && pg == 1 ? 4 : tmb == 2 && pg == 2 ? 8 : tmb == 4 && pg == 2 ? 16 :
                     tmb == 4 && pg == 4 ? 32 : 0;
     return (nw4_mask() & bit) != 0;
+  }
+  // XCD-aware workgroup order of conv_tile_kernel (ConvArgs::xcd_remap); THA4_NO_XCD_REMAP is a tuning aid (A/B)
+  static bool xcd_remap_enabled() {
+    static const bool on = !tune_env("THA4_NO_XCD_REMAP");
+    return on;
   }
   static void dispatch_tile(int tmb, int pg, int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, bool nw4 = false) {
     if (nw4) {
@@ -576,7 +630,11 @@ class FullModel {
             c.phase = 2;                       // one output block per workgroup: 4x the workgroups, a quarter of the load rounds each
             dispatch_tile(1, pg, in_mode, c, dim3(f.batch * tiles * grid_classes, mtiles * tmb, 1), lds, f.stream);
           } else {
-            dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles * grid_classes, mtiles, 1), lds, f.stream, nw4);
+            const long long gxl = (long long)f.batch * tiles * grid_classes;
+            if (xcd_remap_enabled() && finish_conv_remap(c, mtiles, gxl))
+              dispatch_tile(tmb, pg, in_mode, c, dim3((unsigned)(gxl * mtiles), 1, 1), lds, f.stream, nw4);
+            else
+              dispatch_tile(tmb, pg, in_mode, c, dim3(f.batch * tiles * grid_classes, mtiles, 1), lds, f.stream, nw4);
           }
         } else {
           dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
@@ -780,6 +838,20 @@ class FullModel {
     int cin = 0;
     std::vector<FTensor> ts;
     for (auto& f : ins) { cin += f.channels; ts.push_back(f.t); }
+    // skip branch (unet.py:149-152,165) FIRST, on the side stream: it reads the block's inputs only, the chain norm0 -> conv0 -> norm1 runs beside it
+    FTensor res;
+    int res_mode = mode;
+    const bool has_skip = cin != cout;
+    if (has_skip) {
+      std::vector<Src> ss;
+      for (auto& f : ins) ss.push_back(src_tensor(f.t, f.channels));
+      const size_t first = side_fork(ops);
+      res = conv(ops, K_SAME1, ss, IN_DIRECT, ACT_NONE, get(w, p + ".skip.weight"), get(w, p + ".skip.bias").data, cout, false);
+      side_wrap(ops, first);
+      res_mode = IN_DIRECT;
+    } else {
+      res = ins[0].t;     // resampling blocks and same-width blocks have a single input
+    }
     std::vector<Pending> p0 = norm(ops, ts, cin, 32, get(w, p + ".norm0.weight"), get(w, p + ".norm0.bias"));
     std::vector<Src> s0;
     for (size_t i = 0; i < ins.size(); ++i) s0.push_back(src_tensor(ins[i].t, ins[i].channels, p0[i]));
@@ -790,17 +862,7 @@ class FullModel {
     const size_t my_row = film1_row;
     film1_row += 2 * (size_t)cout;
     Pending p1 = norm(ops, {h}, cout, 32, get(w, p + ".norm1.weight"), get(w, p + ".norm1.bias"), f0_off, film1_base + my_row, film1_stride)[0];
-    // skip branch (unet.py:149-152,165)
-    FTensor res;
-    int res_mode = mode;
-    if (cin != cout) {
-      std::vector<Src> ss;
-      for (auto& f : ins) ss.push_back(src_tensor(f.t, f.channels));
-      res = conv(ops, K_SAME1, ss, IN_DIRECT, ACT_NONE, get(w, p + ".skip.weight"), get(w, p + ".skip.bias").data, cout, false);
-      res_mode = IN_DIRECT;
-    } else {
-      res = ins[0].t;     // resampling blocks and same-width blocks have a single input
-    }
+    if (has_skip) side_join(ops);
     FTensor o = conv(ops, K_SAME3, {src_tensor(h, cout, p1)}, IN_DIRECT, ACT_SILU, get(w, p + ".conv1.weight"),
                      get(w, p + ".conv1.bias").data, cout, true, &res, res_mode);
     return Feat{o, cout};
@@ -856,13 +918,17 @@ class FullModel {
     const size_t c2b = add_param(get(w, key("cond_embed.2.bias")).data, sizeof(float) * 256);
     const size_t fw = add_param(wall), fb = add_param(ball);
     const size_t h1 = alloc_work(256), cemb = alloc_work(256), film1 = alloc_work(rows);
+    // cond MLP + all FiLM-1 projections: they read the pose only - on the side stream, under the first convolution
+    const size_t side_first = side_fork(ops);
     gemv(ops, c0w, c0b, 256, 6, [](const Frame& f) { return f.pose + 39; }, 45, h1, ACT_NONE, ACT_SILU);   // rotation pose = pose[:, 39:45]
     gemv(ops, c2w, c2b, 256, 256, [=](const Frame&) { return (const float*)Wk(h1); }, 256, cemb, ACT_NONE, ACT_NONE);
     gemv(ops, fw, fb, (int)rows, 256, [=](const Frame&) { return (const float*)Wk(cemb); }, 256, film1, ACT_SILU, ACT_NONE);
+    side_wrap(ops, side_first);
 
     size_t row = 0;
     const long long fstride = (long long)rows;
     FTensor h0 = conv(ops, K_SAME3, first_srcs, IN_DIRECT, ACT_NONE, first_w, nullptr, cfg.model, true, nullptr, IN_DIRECT, nullptr, &first_bias);
+    side_join(ops);
     std::vector<Feat> hs = {Feat{h0, cfg.model}};
     Feat h = hs[0];
     for (int i = 0; i < L; ++i) {

@@ -156,7 +156,7 @@ def full_param_shapes() -> Dict[str, Dict[str, tuple]]:
 
 
 def synth_full_weights(seed: int = 20260925, small_gain: float = 1.0, conv_gain: float = 1.0,
-                       film_gain: float = 1.0) -> Dict[str, Dict[str, np.ndarray]]:
+                       film_gain: float = 1.0, head_gains=(1.0, 1.0, 1.0)) -> Dict[str, Dict[str, np.ndarray]]:
     """Deterministic synthetic parameters (numpy PCG64) for all five networks, following SURVEY.md
     §8c: ordinary layers get He-normal conv weights / default-Linear-range weights / near-identity
     norm affines; every tensor the reference zero-initialises (ResBlock.conv1, attention.conv,
@@ -168,6 +168,11 @@ def synth_full_weights(seed: int = 20260925, small_gain: float = 1.0, conv_gain:
     (larger warps, a residual stream that is no longer dominated by the skip path), `conv_gain` the He-normal
     convolutions that feed a normalisation layer (pre-normalisation activations and moments of O(conv_gain); the
     network function is unchanged up to the eps of the norm, so the reference stays well conditioned), `film_gain` the FiLM projections `cond*_layers` (O(1) scale/shift modulation as in a trained model).
+    `head_gains` = (direct, grid, alpha): per-output-row gains of the two U-Nets' last convolution (`body.last.2`: rows 0-3 direct
+    image, 4-5 grid change, 6 alpha logit - morpher_00.py:54-60, upscaler_02.py:84-90) - the MID-GAIN set of
+    tests/golden/make_golden_full_midgain.py: U-Net outputs of O(0.2-0.3) and an alpha that spans most of (0, 1), so that the posed
+    frame really carries the U-Net interior (with the standard set alpha ~ 0.5 +- 0.015 and direct ~ +-0.07: the frame is ~ half the
+    warped input whatever the U-Net computes), while the reference stays well conditioned.
     The same random stream is drawn whatever the gains are."""
     rng = np.random.default_rng(seed)
     out: Dict[str, Dict[str, np.ndarray]] = {}
@@ -194,6 +199,9 @@ def synth_full_weights(seed: int = 20260925, small_gain: float = 1.0, conv_gain:
                     a = 1.0 + 0.1 * rng.standard_normal(shp)
                 else:
                     a = (0.01 if small else 0.05) * rng.standard_normal(shp)
+            if key in ("body.last.2.weight", "body.last.2.bias") and net in ("body_morpher", "upscaler"):
+                rows = np.array([head_gains[0]] * 4 + [head_gains[1]] * 2 + [head_gains[2]], dtype=np.float64)
+                a = a * rows.reshape((7,) + (1,) * (a.ndim - 1))
             sd[key] = a.astype(np.float32)
         out[net] = sd
     return out

@@ -77,7 +77,10 @@ struct FusedSpec {
 } g_fused;
 }  // namespace
 
+static int g_remap_launches = 0;      // conv_tile launches that took the XCD-aware 1-D order (ConvArgs::xcd_remap)
+
 extern "C" {
+int emu_remap_launches() { return g_remap_launches; }
 
 // stats0/1: per-tile moments [n][tiles][cb*16][2] of the two sources; film0 [2*channels] constant, film1 [n][2*channels]
 void emu_set_fused_norm(const float* stats0, int tiles0, const float* stats1, int tiles1, int channels, int groups, float inv_count,
@@ -280,6 +283,8 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     a.phase = phases == 1 ? 0 : ph + 1;
     const int run_tmb = a.phase == 2 ? 1 : tmb;          // phase 2 runs one output block per workgroup
     dim3 grid(n * tiles_per_class * (tiled ? grid_classes : 1), a.phase == 2 ? nb : mtiles, a.phase == 1 ? ksplit : 1);
+    // the XCD-aware 1-D order of FullModel::conv (ConvArgs::xcd_remap) wherever the product takes it: one phase, several output-channel tiles, gx % 8 == 0
+    if (tiled && phases == 1 && !std::getenv("THA4_NO_XCD_REMAP") && tha4::finish_conv_remap(a, mtiles, (long long)grid.x)) { grid = dim3(grid.x * mtiles, 1, 1); ++g_remap_launches; }
 #define RUN(TM, PGV)                                                                                        \
   if (!tiled && !splitk && tmb == TM && pg == PGV) {                                                        \
     if (in_mode == IN_DIRECT) THA4_RUN((conv_mfma_kernel<TM, PGV, IN_DIRECT>), grid, 256, lds, a);          \

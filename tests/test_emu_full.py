@@ -141,6 +141,10 @@ CASES = [
     (0, 3, 4, 51, 2, "silu", 16, 0, False, 32, 32, 64, True, False, False, True, (4, 1)),   # avg-pool 2x2 on load
     (0, 3, 2, 51, 0, "relu", 32, 0, False, 24, 24, 32, True, True, False, True, (3, 1)),    # ragged 24x24 map in 8x8 tiles
     (0, 3, 4, 54, 0, "none", 4, 0, False, 48, 48, 64, True, False, False, False, (4, 1)),   # 4-channel image input, 48x48 (3x3 tiles of 16x16)
+    # conv_tile_kernel in the XCD-aware 1-D order (round 5, ConvArgs::xcd_remap): several output-channel tiles and gx = frames x tiles x classes a multiple of 8
+    (0, 3, 2, 12, 0, "relu", 32, 0, False, 32, 32, 96, True, True, False, True, (4, 1)),    # <2,2>: 3 output tiles x (2 frames x 4 pixel tiles)
+    (0, 3, 2, 52, 0, "silu", 32, 16, False, 32, 32, 64, True, False, False, True, (4, 1)),  # four-wave <2,2>: 2 output tiles x (2 x 8), concat
+    (2, 4, 2, 12, 0, "relu", 32, 0, False, 16, 16, 64, False, False, False, True, (4, 1)),  # convT: 2 output tiles x (2 frames x 1 tile x 4 classes)
     # conv_small_kernel (pg = 20 + PG, tmb = 1): K split across the 8 waves of a workgroup, weights from L2 to registers
     # last field: (log2 tile width, units per K group; 0 = the planner's choice)
     (0, 3, 1, 21, 0, "relu", 96, 0, False, 16, 16, 32, True, True, False, True, (4, 0)),    # 3x3, 1x16 row tiles, 3 K groups -> tap split x4, residual
@@ -191,6 +195,21 @@ def test_conv_kernel_matches_torch(lib, case):
     assert np.abs(out - ref).max() < (3e-5 if pg >= 10 else 2e-5)
     assert np.abs(stats[..., 0] - ref.sum(axis=(2, 3))).max() < 2e-3
     assert np.abs(stats[..., 1] - (ref ** 2).sum(axis=(2, 3))).max() < 5e-3
+
+
+def test_xcd_aware_order_is_taken_where_the_product_takes_it(lib):
+    """The three remap cases of CASES really run conv_tile_kernel on the 1-D grid (the emulator driver mirrors FullModel::conv's rule), a case with
+    one output-channel tile does not."""
+    lib.emu_remap_launches.restype = C.c_int
+    remap = [c for c in CASES if (c[:4], c[9], c[11], c[16]) in (((0, 3, 2, 12), 32, 96, (4, 1)), ((0, 3, 2, 52), 32, 64, (4, 1)), ((2, 4, 2, 12), 16, 64, (4, 1)))]
+    assert len(remap) == 3
+    for case in remap:
+        before = lib.emu_remap_launches()
+        test_conv_kernel_matches_torch(lib, case)
+        assert lib.emu_remap_launches() == before + 1, case
+    before = lib.emu_remap_launches()
+    test_conv_kernel_matches_torch(lib, CASES[[c[3] for c in CASES].index(14)])
+    assert lib.emu_remap_launches() == before
 
 
 def _partials(x, tiles):
@@ -505,10 +524,12 @@ def test_small_conv_launch_plans(lib):
 
 
 def test_fastdiv_is_exact_on_the_range_the_planner_allows(lib):
-    """FastDiv (csrc/full_kernels.h): q = (x * ceil(2^40 / d)) >> 40 replaces every run-time integer division of the convolution prologues.  Exact for
-    0 <= x < 2^22, 1 <= d < 2^18 - the bounds finish_conv_args / finish_conv_batch check; refused outside."""
+    """FastDiv (csrc/full_kernels.h): q = (x * ceil(2^42 / d)) >> 42 replaces every run-time integer division of the convolution prologues.  Exact for
+    0 <= x < 2^22, 1 <= d < 2^20 - the bounds finish_conv_args / finish_conv_batch check (round 5: the range covers the batch-sized divisor of the
+    documented handle limit, max_batch = 256 x 1024 tiles = 2^18, which round 4's 2^40 / d < 2^18 form refused); refused outside."""
     rng = np.random.default_rng(7)
-    ds = np.concatenate([np.arange(1, 4097), rng.integers(1, 1 << 18, 20000), np.array([(1 << 18) - 1, 65535, 65536, 65537, 3, 7, 9, 18, 24, 48, 96])]).astype(np.int32)
+    ds = np.concatenate([np.arange(1, 4097), rng.integers(1, 1 << 18, 20000), rng.integers(1 << 18, 1 << 20, 20000),
+                         np.array([(1 << 18) - 1, 1 << 18, (1 << 18) + 1, (1 << 20) - 1, 65535, 65536, 65537, 3, 7, 9, 18, 24, 48, 96])]).astype(np.int32)
     xs = []
     for d in ds:
         k = rng.integers(0, ((1 << 22) - 1) // int(d) + 1, 6)
@@ -519,7 +540,7 @@ def test_fastdiv_is_exact_on_the_range_the_planner_allows(lib):
     ip = C.POINTER(C.c_int)
     assert lib.emu_fast_div(x.ctypes.data_as(ip), d.ctypes.data_as(ip), int(x.size), out.ctypes.data_as(ip)) == 0
     np.testing.assert_array_equal(out, x // d)
-    bad = np.array([0, -3, 1 << 18, 1 << 20], np.int32)
+    bad = np.array([0, -3, 1 << 20, 1 << 22], np.int32)
     o2 = np.empty_like(bad)
     lib.emu_fast_div(np.zeros(4, np.int32).ctypes.data_as(ip), bad.ctypes.data_as(ip), 4, o2.ctypes.data_as(ip))
     assert (o2 == -1).all()

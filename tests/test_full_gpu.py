@@ -620,3 +620,50 @@ def test_mode_07_create_poser_from_pt_files_on_device(weights, poser1, full_io, 
     with pytest.raises(FileNotFoundError):
         mode_07.create_poser(dev, module_file_names={**files, "upscaler": str(tmp_path / "missing.pt")}).pose(image, pose)
     p.free()
+
+
+# ---- mid-gain parameter set: the posed frame carries the U-Net interior (tests/golden/make_golden_full_midgain.py) ----------------
+SUB7 = slice(3, None, 7)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_midgain_set_all_33_outputs_vs_reference_fixture(exact, golden_io):
+    """Round-4 review, task 6: with the standard synthetic set output 0 is ~ half the warped input whatever the U-Nets compute
+    (alpha 0.50 +- 0.015, direct +-0.07) and the adversarial set is gated loosely; here alpha spans [0.13, 0.91], direct is +-0.28 and
+    the unmodified reference agrees with its own fp64 run to 1.7e-4 - every one of the 33 outputs is gated at 1e-3 (2.5e-3 on the
+    warped images) against the reference's fp32 run, on both plans (fp16 hi/lo split and exact fp32), at batch 1 (lambda_00 image,
+    two poses, decomposer cache) and on a dense batch of 8 distinct images (the batch-8 launch plan)."""
+    from oracle.student_oracle import synthetic_image
+    import json
+    z = _npz("full_midgain_io.npz")
+    noise8 = json.load(open(os.path.join(GOLDEN, "full_midgain_noise.json")))["b8_fp32_vs_fp64_maxabs"]
+    w = fo.synth_full_weights(int(z["seed"]), head_gains=tuple(float(x) for x in z["head_gains"]))
+    dev = torch.device("cuda:0")
+    report = []
+    # batch 1
+    p = mode_07.create_poser_from_state_dicts(dev, w, max_batch=1, exact_fp32=exact)
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    for i in range(2):
+        outs = p.get_posing_outputs(image, torch.from_numpy(z["b1_poses"][i]).to(dev), image_changed=(i == 0))
+        for k in range(33):
+            got = outs[k][0].cpu().numpy()[:, SUB, SUB]
+            report.append((f"b1 pose {i} {fo.OUTPUT_NAMES[k]}", float(np.abs(got - z[f"b1_ref32_sub3_out{k}"][i]).max()), _tol(fo.OUTPUT_NAMES[k])))
+    p.check_numeric_range()
+    p.free()
+    # batch 8, distinct images
+    p = mode_07.create_poser_from_state_dicts(dev, w, max_batch=8, exact_fp32=exact)
+    images = torch.from_numpy(np.stack([synthetic_image(seed=int(s)) for s in z["b8_image_seeds"]])).to(dev)
+    outs = p.get_posing_outputs(images, torch.from_numpy(z["b8_poses"]).to(dev))
+    for k in range(33):
+        got = outs[k].cpu().numpy()[:, :, SUB7, SUB7]
+        # (random band-limited images: the reference's own fp32 scatter is 6.6e-4 on the posed frame here - gate = max(1e-3, 3 x its fp32-vs-fp64 distance))
+        report.append((f"b8 {fo.OUTPUT_NAMES[k]}", float(np.abs(got - z[f"b8_ref32_sub7_out{k}"]).max()), _tol(fo.OUTPUT_NAMES[k], noise8[fo.OUTPUT_NAMES[k]])))
+    p.check_numeric_range()
+    p.free()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/full_midgain_parity_report_{'exact' if exact else 'split'}.txt", "w") as fh:
+        fh.write("\n".join(f"{n:40s} {e:.3e} (tol {t:.1e})" for n, e, t in report) + "\n")
+    bad = [r for r in report if r[1] > r[2]]
+    assert not bad, bad
+    a = z["b1_ref32_sub3_out1"]
+    assert a.min() < 0.25 and a.max() > 0.8                               # the set is what it claims to be (stride-3 subset; full maps 0.13 .. 0.91)

@@ -49,6 +49,29 @@ def _worker(rank, world, port, total, chunk, q):
             ok = bool(torch.equal(full, mine)) and bool(torch.equal(rgba, image_io.to_display_rgba8(mine)))
         else:
             ok = full is None and rgba is None
+        # achieved exchange rate (printed, never asserted: the first numbers any N > 1 run of this path produces - round-4 review):
+        # a longer stream of ready-made fp32 frames (no posing inside the clock), 32 per rank in rounds of 8, streaming root
+        import time
+        n_per = 32
+        ready = torch.empty((8, 4, 512, 512), dtype=torch.float32, device=dev).normal_()
+        seen = [0]
+        st = FrameShardedStream(lambda lo, hi: ready[:hi - lo], n_per * world, (4, 512, 512), torch.float32, dev, chunk=8, gather=True,
+                                on_chunk=lambda lo, hi, fr: seen.__setitem__(0, seen[0] + hi - lo), ring_slots=3)
+        st.run()                                            # untimed: connections
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        st.run()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            gb = (world - 1) * n_per * 4 * 512 * 512 * 4 / 1e9
+            print(f"[rccl gather] world {world}: {(world - 1) * n_per} remote fp32 frames ({gb:.2f} GB) into rank 0 in {dt * 1e3:.2f} ms = "
+                  f"{gb / dt:.1f} GB/s root ingest, {gb / dt / (world - 1):.1f} GB/s per sender", flush=True)
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(f"gpurun_out/rccl_gather_rate_world{world}.txt", "a") as fh:
+                fh.write(f"world {world} remote_frames {(world - 1) * n_per} GB {gb:.3f} seconds {dt:.6f} root_ingest_GBps {gb / dt:.2f}\n")
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
