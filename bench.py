@@ -663,8 +663,9 @@ def student_extras(args, work, dev, world, fps, K, W, B):
             poser.free()
             fw = FullWork(dev, 0, 1, args.full_frames + 3, steady=True)
             out["full_model"] = measure_full_b1(fw, dev, args.full_frames)
+            fw.steady = True
+            out["full_model"]["roofline"] = full_roofline(out["full_model"]["steady"]["fps"], GFLOP_FULL_STEADY, cold=False, batch1=True, work=fw)
             fw.poser.free()
-            out["full_model"]["roofline"] = full_roofline(out["full_model"]["steady"]["fps"], GFLOP_FULL_STEADY, cold=False, batch1=True)
             # the strict-precision number next to it: the same frames on the exact-fp32 plan (THA4_FULL_EXACT_FP32: every convolution on
             # v_mfma_f32_16x16x4_f32 with fp32 operands - no 22-bit operand split to argue about)
             nx = max(6, min(12, args.full_frames // 2))
@@ -762,34 +763,73 @@ def measure_full_two_in_flight(dev, frames):
         return {"error": repr(e)}
 
 
-def full_roofline(fps_per_gpu, gflop, cold, batch1):
-    """Roofline object of the full model: the frame is ~320 launches of a static schedule, so the unit is the WHOLE FRAME (as-written
-    FLOPs of the reference's five networks / measured frame time) against the dense fp16 MFMA peak of the instruction issued; the
-    launch class with the largest share of the frame in the newest committed rocprofv3 capture is quoted beside it with its own
-    per-launch figures (profiles/r*_full_b1_layers.json, written by tools/conv_breakdown.py from the kernel trace)."""
+def full_live_classes(work, frames=8):
+    """Per-launch-class durations of the full model measured LIVE: HIP events on the launch stream around every op of the schedule
+    (tha4_full_set_timing, ABI v5) over `frames` steady frames; classes = ops with the same label (reference layer shape + kernel).
+    Returns the classes sorted by total time per frame.  Events add 1-3 us of chain time per op: a conservative TFLOP/s."""
+    poser = work.poser
+    info = poser.op_info()
+    tot, cnt = {}, {}
+    poser.set_timing(True)
+    try:
+        with torch.no_grad():
+            for i in range(frames):
+                work.step(i)
+                for (label, gf), ms in zip(info, poser.last_op_ms()):
+                    if ms > 0.0:
+                        tot[label] = tot.get(label, 0.0) + ms
+                        cnt[label] = cnt.get(label, 0) + 1
+    finally:
+        poser.set_timing(False)
+    gfl = {label: gf for label, gf in info}
+    rows = [{"class": label, "launches_per_frame": round(cnt[label] / frames, 2), "ms_per_frame": round(tot[label] / frames, 4),
+             "avg_us": round(1e3 * tot[label] / cnt[label], 2), "gflop_per_launch": round(gfl[label], 4),
+             "tflops": round(gfl[label] / (tot[label] / cnt[label]), 1) if gfl[label] > 0 else None} for label in tot]
+    rows.sort(key=lambda r: -r["ms_per_frame"])
+    return rows, sum(tot.values()) / frames
+
+
+def full_roofline(fps_per_gpu, gflop, cold, batch1, work=None):
+    """Roofline object of the full model.  The frame is ~320 launches of a static schedule: `achieved` is the WHOLE FRAME (as-written FLOPs
+    of the reference's five networks / measured frame time) against the dense fp16 MFMA peak of the instruction issued; `dominant_class` is
+    the launch class (reference layer shape + kernel) with the largest share of the frame, its as-written FLOPs per launch / its average
+    launch duration measured live with HIP events on the launch stream (tha4_full_set_timing), with the rocprofv3 figure of the newest
+    committed capture beside it (profiles/r*_full_b1_layers.json, tools/conv_breakdown.py)."""
     ach = fps_per_gpu * gflop / 1e3
     prof, prof_file = newest_profile("r*_full_b1_traffic.json")
     per_frame = prof.get("cold_frame_bytes" if cold else "steady_frame_bytes") if (prof and batch1) else None
+    dominant, top = None, None
+    if work is not None:
+        try:
+            rows, event_ms = full_live_classes(work)
+            convs = [r for r in rows if r["tflops"] is not None]
+            if convs:
+                d = convs[0]
+                dominant = dict(d, frac_of_f16_mfma_peak=round(d["tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
+                                frac_of_split_ceiling=round(d["tflops"] * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
+                                what="the convolution class with the largest total time per steady frame; tflops = as-written GFLOP of the layer / its "
+                                     "average launch duration from HIP events on the launch stream (conservative: the events add chain time)")
+            top = {"event_timed_frame_ms": round(event_ms, 3), "classes": rows[:8]}
+        except Exception as e:                     # a measurement aid must not take the line down
+            dominant = {"error": repr(e)}
     layers, layers_file = newest_profile("r*_full_b1_layers.json")
-    dominant = None
+    rocprof = None
     if layers and batch1 and layers.get("classes"):
         c = max(layers["classes"], key=lambda r: r["total_us"])
-        dominant = dict(c, frac_of_f16_mfma_peak=round(c["tflops"] / PEAK_F16_MFMA_TFLOPS, 4), source=layers_file,
-                        what="the launch class (kind, map, channels) with the largest total time per cold frame in that capture: "
-                             "as-written TFLOP/s of its launches")
+        rocprof = dict(c, frac_of_f16_mfma_peak=round(c["tflops"] / PEAK_F16_MFMA_TFLOPS, 4), source=layers_file)
     return {"bound": "mfma", "kernel": "whole frame (static schedule of conv_tile / conv_small / conv_point / attention / image kernels)",
             "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
             "frac_of_split_ceiling": round(ach * MFMA_PASSES / PEAK_F16_MFMA_TFLOPS, 4),
             "vs_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
             "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
             "traffic": per_frame, "traffic_unit": f"bytes/frame = sum over the frame's launches of 2 x FETCH_SIZE + WRITE_SIZE ({prof_file})",
-            "dominant_class": dominant, "algorithmic_gflop_per_frame": gflop}
+            "dominant_class": dominant, "dominant_class_rocprof": rocprof, "live_classes": top, "algorithmic_gflop_per_frame": gflop}
 
 
 def full_extras(args, work, dev, world, fps, B):
     cold = args.cold or B > 1
     gflop = GFLOP_FULL_COLD if cold else GFLOP_FULL_STEADY
-    roofline = full_roofline(fps / world, gflop, cold, B == 1)
+    roofline = full_roofline(fps / world, gflop, cold, B == 1, work=work if world == 1 else None)
     out = {"roofline": roofline, "cpu_baseline": None}
     if world == 1 and B == 1:
         other = FullWork.__new__(FullWork)

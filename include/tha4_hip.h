@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THA4_ABI_VERSION 4
+#define THA4_ABI_VERSION 5
 
 typedef enum tha4_status {
   THA4_OK = 0,
@@ -248,6 +248,19 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
 
 void tha4_full_destroy(tha4_full* h);
 int tha4_full_max_batch(const tha4_full* h);
+
+/* Per-op timing of the full model (ABI v5; measurement aid, no reference counterpart - the reference's callers bracket pose() with
+ * torch.cuda.Event on the current stream, full_manual_poser.py:388-398).  A frame is a static schedule of tha4_full_num_ops() ops
+ * (eyebrow-decomposer ops first, then the rest; an op is one launch, two for a convolution with a K split).  With timing enabled
+ * every pose call records a HIP event on the launch stream in front of every op and behind the last one (they cost ~1-3 us of chain
+ * time each: a timed call is slower than an untimed one); tha4_full_last_op_ms waits for the last timed call and returns the time
+ * between consecutive events (0 for decomposer ops the call reused).  tha4_full_op_info: a label naming the reference layer + the kernel
+ * that runs it, and the as-written GFLOP (2 x MAC per frame) of that layer - what bench.py prices `roofline.achieved` of the full
+ * model's dominant launch class with.  The label pointer is owned by the handle. */
+int tha4_full_set_timing(tha4_full* h, int enable);
+int tha4_full_num_ops(const tha4_full* h);
+int tha4_full_op_info(const tha4_full* h, int index, const char** label, double* gflop);
+int tha4_full_last_op_ms(tha4_full* h, float* ms, int capacity);
 int tha4_full_num_networks(const tha4_full* h);
 
 /* ------------------------------------------------------------------------------------------------

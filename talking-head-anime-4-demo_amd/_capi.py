@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtha4_hip.so")
 
-THA4_ABI_VERSION = 4
+THA4_ABI_VERSION = 5
 STUDENT_EXACT_FP32 = 1
 FULL_EXACT_FP32 = 1
 
@@ -202,6 +202,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.tha4_full_flags.argtypes = [C.c_void_p]
     lib.tha4_full_set_fault_policy.restype = C.c_int
     lib.tha4_full_set_fault_policy.argtypes = [C.c_void_p, C.c_int]
+    lib.tha4_full_set_timing.restype = C.c_int
+    lib.tha4_full_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.tha4_full_num_ops.restype = C.c_int
+    lib.tha4_full_num_ops.argtypes = [C.c_void_p]
+    lib.tha4_full_op_info.restype = C.c_int
+    lib.tha4_full_op_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]
+    lib.tha4_full_last_op_ms.restype = C.c_int
+    lib.tha4_full_last_op_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.tha4_full_num_networks.restype = C.c_int
     lib.tha4_full_num_networks.argtypes = [C.c_void_p]
     lib.tha4_full_pose.restype = C.c_int
@@ -231,7 +239,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "tha4_abi_version", "tha4_last_error", "tha4_student_create", "tha4_student_create_ex", "tha4_student_pose", "tha4_student_set_weights", "tha4_student_destroy",
     "tha4_student_max_batch", "tha4_student_device", "tha4_student_debug_read", "tha4_student_hand_off_scale", "tha4_student_set_timing", "tha4_student_last_ms",
-    "tha4_full_create", "tha4_full_create_ex", "tha4_full_num_networks", "tha4_full_flags", "tha4_full_set_fault_policy", "tha4_full_pose", "tha4_full_pose_ex", "tha4_full_numeric_status",
+    "tha4_full_create", "tha4_full_create_ex", "tha4_full_num_networks", "tha4_full_flags", "tha4_full_set_fault_policy", "tha4_full_set_timing", "tha4_full_num_ops", "tha4_full_op_info", "tha4_full_last_op_ms", "tha4_full_pose", "tha4_full_pose_ex", "tha4_full_numeric_status",
     "tha4_full_destroy", "tha4_full_max_batch",
     "tha4_display_rgba8", "tha4_ingest_rgba8",
 ]

@@ -44,9 +44,7 @@ constexpr int kTileMaxItems = 5;     // staging items (pixel, g) per thread and 
 constexpr int kTileWavesHalf = 4;    // the four-wave form (NW = 4, round 4): half the pixel tile, TWO workgroups per CU
 constexpr int kTileMaxItemsHalf = 6; // its staging items per thread: window <= 384 pixels (16 x 16 outputs + halo)
 
-// bytes of one lane-group plane of the window image; planes are skewed by 32 B so that the staging writes
-// (4 consecutive lanes = 4 planes of one pixel) hit distinct banks
-constexpr int tile_plane_bytes(int win_px) { return (win_px * 16 + 127) / 128 * 128 + 32; }
+// (tile_plane_bytes - the bytes of one lane-group plane of the window image - lives in full_kernels.h next to the pixel permutation that depends on it)
 
 // Per-channel scale/shift of the normalisation that precedes a convolution, computed by the consumer itself from the
 // producer's per-tile moments.  Mirrors norm_finalize_kernel (same fp64 arithmetic); all `nthreads` threads of the
@@ -231,11 +229,13 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
   }
 
   // ---- per-lane output pixels ------------------------------------------------------------------
+  // (column p of a 16-pixel group computes pixel pcol: the host picks the assignment that makes the B-fragment reads conflict-free, full_kernels.h)
+  const int pcol = pixel_of_column(a, p);
   int ly[PG], lx[PG], boff[PG];
   bool inside[PG];
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) {
-    const int i = (pw * PG + pg) * 16 + p;
+    const int i = (pw * PG + pg) * 16 + pcol;
     ly[pg] = i >> twl;
     lx[pg] = i & (TWW - 1);
     boff[pg] = ((ly[pg] * a.in_stride) * WW + lx[pg] * a.in_stride) * 16 + g * PLANE;

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform_i32(tid >> 6);
-  const int p = lane & 15, g = lane >> 4, g4 = g * 4;
+  const int g = lane >> 4, g4 = g * 4;
   const float m1 = split_minus_one();
 #if defined(THA4_PHASE_TIMING) && !defined(THA4_EMU)
   long long* stamps = a.dbg ? a.dbg + ((size_t)blockIdx.x * kSmallWaves + wave) * 64 : nullptr;
@@ -130,11 +130,14 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
 
   THA4_SSTAMP();                                           // S2: first weights requested
   // ---- per-lane output pixels ------------------------------------------------------------------
+  // the pixel of the group this MFMA column computes (conflict-free window reads: full_kernels.h).  Any assignment is correct; the PG = 4 instantiations sit at
+  // 256 VGPRs and one more live value spills, so they keep pixel = column (these launches are latency-, not LDS-bound: profiles/r05_boundaries_reading.md)
+  const int pcol = PG == 4 ? (lane & 15) : pixel_of_column(a, lane & 15);
   int ly[PG], lx[PG], boff[PG];
   bool inside[PG];
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) {
-    const int i = pg * 16 + p;
+    const int i = pg * 16 + pcol;
     ly[pg] = i >> twl;
     lx[pg] = i & (TWW - 1);
     boff[pg] = ((ly[pg] * a.in_stride) * WW + lx[pg] * a.in_stride) * 16 + g * PLANE;
@@ -437,7 +440,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
     const size_t off = (((size_t)n * a.nb + bo) * out_px + (size_t)oy * a.out_w + ox) * 16 + g4;
     *reinterpret_cast<f32x4*>(a.out + off) = vout[pg];
   }
-  if (a.stats && p == 0) {
+  if (a.stats && (lane & 15) == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float* dst = a.stats + ((((size_t)n * a.stats_tiles + cg.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;

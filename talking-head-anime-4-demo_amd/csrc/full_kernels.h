@@ -131,10 +131,80 @@ struct ConvArgs {
   // first of them fetches are L2 hits for the others; 0 = the (gx, mtiles) grid of rounds 2-4 (same XCD when gx % 8 == 0, but a whole grid row apart in time)
   int xcd_remap;
   FastDiv d_mtiles;
+  // conv_tile_kernel / conv_small_kernel: which pixel of a 16-pixel group each MFMA column (lane & 15) computes - sixteen 4-bit entries, chosen on the host so
+  // that the B-fragment reads of the window are free of LDS bank conflicts (pixel_permutation below; identity = 0x76543210 / 0xfedcba98)
+  unsigned pix_perm_lo, pix_perm_hi;
 #ifdef THA4_PHASE_TIMING
   long long* dbg;        // tuning aid: s_memtime stamps [workgroup][wave][64] of ONE selected convolution, else null
 #endif
 };
+
+// bytes of one lane-group plane of the LDS window image of conv_tile_kernel / conv_small_kernel; planes are skewed by 32 B so that the staging writes
+// (ds_write_b128 is serviced in contiguous 8-lane groups = 2 pixels x 4 planes, bank = (a / 4) mod 32) hit distinct banks
+constexpr int tile_plane_bytes(int win_px) { return (win_px * 16 + 127) / 128 * 128 + 32; }
+
+// ---- pixel <-> MFMA-column assignment (round 5) ----------------------------------------------------------------------------------------------
+// A wave reads the B fragment of one tap for a 16-pixel group with ONE ds_read_b128: lane (p = lane & 15, g = lane >> 4) reads the 16 bytes of pixel p in
+// plane g.  The LDS services that instruction in four 16-lane groups - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS) -
+// one cycle per group when its 16 addresses fall into 16 distinct 16-byte slots of the 256-byte bank row.  With pixel = p, a 16-wide tile and the 32-byte plane
+// skew the staging writes need, every group mixes lanes 12-15 of plane g with lanes 4-11 of plane g + 1 shifted by 32 bytes: two slots collide, five cycles
+// instead of four - the 22-30 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the conv_tile classes in profiles/r04_full_b1_profile.md (37-49 % on the narrower
+// tiles of conv_small_kernel).  Which pixel a column computes is free (the epilogue stores by pixel): lanes 4-11 take the EVEN pixels of the group and lanes
+// 0-3 / 12-15 the odd ones, and a shift by an even number of slots maps evens to evens - conflict-free for every 16-wide stride-1 geometry.  For the other
+// geometries (8- and 4-pixel-wide tiles, stride-2 windows) the host searches a permutation with the same cost function.
+inline int window_read_conflicts(const int perm[16], int twl, int win_w, int in_stride, int plane_bytes) {
+  static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  const int tw = 1 << twl;
+  int extra = 0;                                           // LDS cycles beyond the conflict-free four
+  for (int gi = 0; gi < 4; ++gi) {
+    int addr[16], worst = 1;
+    for (int k = 0; k < 16; ++k) {
+      const int lane = groups[gi][k], i = perm[lane & 15];
+      addr[k] = (lane >> 4) * (plane_bytes / 16) + ((i >> twl) * in_stride * win_w + (i & (tw - 1)) * in_stride);     // in 16-byte slots
+    }
+    for (int slot = 0; slot < 16; ++slot) {                // distinct addresses on one slot of the bank row serialise; equal addresses broadcast
+      int distinct = 0;
+      for (int k = 0; k < 16; ++k) {
+        if ((addr[k] & 15) != slot) continue;
+        bool seen = false;
+        for (int j = 0; j < k; ++j) seen = seen || addr[j] == addr[k];
+        distinct += !seen;
+      }
+      worst = distinct > worst ? distinct : worst;
+    }
+    extra += worst - 1;
+  }
+  return extra;
+}
+// deterministic search: identity, the even / odd assignment, then hill climbing by pair swaps (fixed LCG); identity is kept unless something is strictly better
+inline void pixel_permutation(int twl, int win_w, int in_stride, int plane_bytes, int out[16], int* cost_identity = nullptr, int* cost_best = nullptr) {
+  int best[16], cur[16];
+  for (int p = 0; p < 16; ++p) best[p] = p;
+  int cbest = window_read_conflicts(best, twl, win_w, in_stride, plane_bytes);
+  if (cost_identity) *cost_identity = cbest;
+  for (int p = 0; p < 16; ++p) cur[p] = (p >= 4 && p < 12) ? 2 * (p - 4) : (p < 4 ? 2 * p + 1 : 2 * (p - 8) + 1);
+  int ccur = window_read_conflicts(cur, twl, win_w, in_stride, plane_bytes);
+  if (ccur < cbest) { cbest = ccur; for (int p = 0; p < 16; ++p) best[p] = cur[p]; }
+  unsigned long long rng = 0x9E3779B97F4A7C15ull;
+  for (int restart = 0; restart < 8 && cbest > 0; ++restart) {
+    for (int p = 0; p < 16; ++p) cur[p] = best[p];
+    ccur = cbest;
+    for (int it = 0; it < 3000 && ccur > 0; ++it) {
+      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+      const int x = (int)((rng >> 33) & 15), y = (int)((rng >> 41) & 15);
+      if (x == y) continue;
+      int t = cur[x]; cur[x] = cur[y]; cur[y] = t;
+      const int c = window_read_conflicts(cur, twl, win_w, in_stride, plane_bytes);
+      if (c <= ccur) ccur = c;
+      else { t = cur[x]; cur[x] = cur[y]; cur[y] = t; }
+    }
+    if (ccur < cbest) { cbest = ccur; for (int p = 0; p < 16; ++p) best[p] = cur[p]; }
+  }
+  for (int p = 0; p < 16; ++p) out[p] = best[p];
+  if (cost_best) *cost_best = cbest;
+}
+THA4_DEV int pixel_of_column(const ConvArgs& a, int p) { return (int)(((p < 8 ? a.pix_perm_lo : a.pix_perm_hi) >> ((p & 7) * 4)) & 15u); }
 
 // Host: the launch constants that do not depend on the batch.  `px_per_wg` = output positions of a workgroup tile (16 * PG * pixel-slot waves), `nq` = 32-channel
 // K groups of the convolution (conv_tile_kernel's K split).  False when a divisor is out of FastDiv's range.
@@ -149,6 +219,15 @@ inline bool finish_conv_args(ConvArgs& a, int px_per_wg, int nq) {
   a.q_per = (nq + ksplit - 1) / ksplit;
   const int tpc = a.taps_per_chunk > 0 ? a.taps_per_chunk : 1;
   a.ntc = (a.ntaps + tpc - 1) / tpc;
+  {                                                         // pixel <-> column assignment of the B-fragment reads (above)
+    int perm[16];
+    pixel_permutation(twl, a.win_w > 0 ? a.win_w : 1, a.in_stride > 0 ? a.in_stride : 1, tile_plane_bytes(a.win_h * a.win_w), perm);
+#ifdef THA4_IDENTITY_PIXELS
+    for (int p = 0; p < 16; ++p) perm[p] = p;               // A/B build: the pixel = column assignment of rounds 2-4
+#endif
+    a.pix_perm_lo = a.pix_perm_hi = 0u;
+    for (int p = 0; p < 8; ++p) { a.pix_perm_lo |= (unsigned)perm[p] << (4 * p); a.pix_perm_hi |= (unsigned)perm[p + 8] << (4 * p); }
+  }
   return fastdiv_make(a.d_tiles_x, a.tiles_x) && fastdiv_make(a.d_tpf, a.tiles_per_frame) && fastdiv_make(a.d_upq, upq) &&
          fastdiv_make(a.d_win_w, a.win_w > 0 ? a.win_w : 1) && fastdiv_make(a.d_ntc, a.ntc);
 }
@@ -799,25 +878,35 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
     const int cw = (s ? a.cb[1] : a.cb[0]) * 16;
     const int nt = s ? a.tiles[1] : a.tiles[0];
     const float* ps = (s ? a.stats[1] : a.stats[0]) + ((size_t)n * nt * cw + cl) * 2;
-    // four independent partial sums (fixed assignment t -> sum (t/S)%4, combined in a fixed order): the loads of four
-    // tiles are in flight at once instead of one fp64 add chain waiting on each 8-byte load in turn
+    // eight independent partial sums (fixed assignment t -> sum (t/S)%8, combined in a fixed order): the loads of eight tiles are in flight at once
+    // instead of one fp64 add chain waiting on each 8-byte load in turn (round 2: four; round 5: eight - a 512x512 map has 1024-4096 tiles per channel
+    // and a 32-channel tensor gets ONE workgroup, i.e. 32-128 tiles per thread: 8-32 dependent load rounds at four in flight)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    double su[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int NP = 8;
+    double su[NP], sq[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) { su[u] = 0.0; sq[u] = 0.0; }
     int t = sl;
-    for (; t + 3 * S < nt; t += 4 * S) {
-      f32x2 v[4];
+    for (; t + (NP - 1) * S < nt; t += NP * S) {
+      f32x2 v[NP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x2*>(ps + (size_t)(t + u * S) * cw * 2);
+      for (int u = 0; u < NP; ++u) v[u] = *reinterpret_cast<const f32x2*>(ps + (size_t)(t + u * S) * cw * 2);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { su[u] += (double)v[u][0]; sq[u] += (double)v[u][1]; }
+      for (int u = 0; u < NP; ++u) { su[u] += (double)v[u][0]; sq[u] += (double)v[u][1]; }
     }
-    for (; t < nt; t += S) {                               // at most three left-over tiles
-      const f32x2 v = *reinterpret_cast<const f32x2*>(ps + (size_t)t * cw * 2);
-      su[0] += (double)v[0];
-      sq[0] += (double)v[1];
+    {                                                      // at most seven left-over tiles: requested together, added in tile order
+      f32x2 v[NP - 1];
+#pragma unroll
+      for (int u = 0; u < NP - 1; ++u) v[u] = *reinterpret_cast<const f32x2*>(ps + (size_t)min(t + u * S, nt - 1) * cw * 2);
+#pragma unroll
+      for (int u = 0; u < NP - 1; ++u) {
+        const bool keep = t + u * S < nt;
+        su[u] += keep ? (double)v[u][0] : 0.0;
+        sq[u] += keep ? (double)v[u][1] : 0.0;
+      }
     }
-    part[((size_t)sl * ctot + cl0) * 2] = (su[0] + su[1]) + (su[2] + su[3]);
-    part[((size_t)sl * ctot + cl0) * 2 + 1] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+    part[((size_t)sl * ctot + cl0) * 2] = ((su[0] + su[1]) + (su[2] + su[3])) + ((su[4] + su[5]) + (su[6] + su[7]));
+    part[((size_t)sl * ctot + cl0) * 2 + 1] = ((sq[0] + sq[1]) + (sq[2] + sq[3])) + ((sq[4] + sq[5]) + (sq[6] + sq[7]));
   }
   __syncthreads();
   for (int cl0 = threadIdx.x; cl0 < ctot; cl0 += kNormThreads) {

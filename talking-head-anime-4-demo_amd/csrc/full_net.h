@@ -85,6 +85,8 @@ class FullModel {
   size_t dbg_off = 0;        // tuning aid (THA4_PHASE_TIMING): stamp buffer
   int* fault = nullptr;      // sticky numeric-fault flag (pinned host memory mapped into the device; set by the C ABI at create)
   void finalize_scratch() {
+    while (info_decomposer.size() < ops_decomposer.size()) info_decomposer.push_back(OpInfo{"(unlabelled)", 0.0});
+    while (info_rest.size() < ops_rest.size()) info_rest.push_back(OpInfo{"(unlabelled)", 0.0});
     partial_off = alloc_work(partial_floats);
 #ifdef THA4_PHASE_TIMING
     dbg_off = alloc_work((size_t)2 << 20);
@@ -116,21 +118,33 @@ class FullModel {
   };
   using Op = std::function<void(const Frame&)>;
   std::vector<Op> ops_decomposer, ops_rest;
+  // one record per op of the schedule (ABI v5 tha4_full_op_info / tha4_full_last_op_ms: live per-launch-class timing for bench.py's roofline):
+  // what it is and the as-written FLOPs (2 x MAC of the reference's layer, per frame) it stands for - 0 for everything that is not a convolution
+  struct OpInfo { std::string label; double gflop = 0.0; };
+  std::vector<OpInfo> info_decomposer, info_rest;
+  void note(std::vector<Op>& ops, const std::string& label, double gflop = 0.0) {      // right behind every ops.push_back
+    std::vector<OpInfo>& v = &ops == &ops_decomposer ? info_decomposer : info_rest;
+    while (v.size() + 1 < ops.size()) v.push_back(OpInfo{"(unlabelled)", 0.0});
+    if (v.size() < ops.size()) v.push_back(OpInfo{label, gflop});
+  }
 
-  // ---- side branches (round 5) ------------------------------------------------------------------
+  // ---- side branches (round 5): MEASURED NEGATIVE, off unless THA4_TUNING + THA4_SIDE_STREAM are set ------------------------------
   // A batch-1 frame is a chain of ~320 DEPENDENT launches, each a chain of dependent memory round trips: the chip idles
   // on latency, not on throughput.  The few branches of the graph that do NOT lie on that chain - the 1x1 skip convolution of every
-  // ResBlock that changes width (unet.py:149-152: it reads the block's INPUT, the chain runs norm0 -> conv0 -> norm1 beside it), the
-  // cond MLP + FiLM projections of both U-Nets (they read the pose only) - are enqueued on a second stream of the handle between a fork
-  // (side waits for main) and a join (main waits for side) and run under the main chain.  Same kernels on the same operands: the bytes of
-  // a frame do not change.  Events are taken round-robin from a small pool; cudaStreamWaitEvent captures the state of the event at the
-  // call, so re-recording it later is safe.
+  // ResBlock that changes width (unet.py:149-152: it reads the block's INPUT, the chain runs norm0 -> conv0 -> norm1 beside it: 27 per
+  // frame, ~0.35 ms), the cond MLP + FiLM projections of both U-Nets (they read the pose only) - can be enqueued on a second stream of the
+  // handle between a fork (side waits for main) and a join (main waits for side).  Same kernels on the same operands: the bytes of a frame
+  // do not change (the GPU suite passes with it on).  But every fork and every join is a cross-queue dependency, and on this stack one costs
+  // ~8 us of chain time - more than the 7-38 us launches it hides save: same-box A/B (profiles/r05_raw/c2_ab.txt) 185.2 -> 169.2 frames/s
+  // steady (-9 %), 172.6 -> 157.9 cold, batch 8 343.5 -> 338.5.  Kept as a tuning aid; the product plan keeps one stream.
+  // Events are taken round-robin from a small pool; hipStreamWaitEvent captures the state of the event at the call, so re-recording it
+  // later is safe.
   hipStream_t side_stream = nullptr;               // owned by the C ABI handle (created / destroyed there)
   std::vector<hipEvent_t> side_events;
   size_t side_cursor = 0;
   int side_branches = 0;                           // fork / join pairs per steady frame (diagnostics)
   hipEvent_t next_side_event() { return side_events[side_cursor++ % side_events.size()]; }
-  bool side_planned() const { return !tune_env("THA4_NO_SIDE_STREAM"); }
+  bool side_planned() const { return tune_env("THA4_SIDE_STREAM") != nullptr; }
   // fork: everything emitted between side_fork() and side_join() that is wrapped by side_wrap() runs on the side stream
   size_t side_fork(std::vector<Op>& ops) {
     if (!side_planned()) return ops.size();
@@ -141,6 +155,7 @@ class FullModel {
       (void)hipEventRecord(e, f.stream);
       (void)hipStreamWaitEvent(f.side, e, 0);
     });
+    note(ops, "side-stream fork");
     return ops.size();
   }
   void side_wrap(std::vector<Op>& ops, size_t first) {        // ops [first, end) -> the side stream
@@ -163,6 +178,7 @@ class FullModel {
       (void)hipEventRecord(e, f.side);
       (void)hipStreamWaitEvent(f.stream, e, 0);
     });
+    note(ops, "side-stream join");
   }
   size_t scratch_out[33];   // workspace offsets used for outputs the caller did not ask for
   int out_ch[33], out_size[33];
@@ -640,6 +656,17 @@ class FullModel {
           dispatch_conv(tmb, pg, in_mode, c, dim3(f.batch * tiles, mtiles), lds, f.stream);
         }
       });
+      {
+        static const char* kinds[] = {"conv3x3", "conv1x1", "conv4x4 stride 2", "convT4x4 stride 2"};
+        static const char* modes[] = {"", " (nearest x2 on load)", " (2x2 mean on load)"};
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "%s %dx%d%s cin=%d cout=%d [%s]", kinds[(int)kind], oh, ow, modes[in_mode], cin, cout,
+                      small ? "conv_small_kernel" : point ? "conv_point_kernel" : tiled ? (ksplit > 1 ? "conv_tile_kernel, K split" : "conv_tile_kernel")
+                            : splitk ? "conv_splitk_kernel" : "conv_mfma_kernel");
+        // as written: Conv2d 2 * out_px * cout * cin * k * k; ConvTranspose2d(4, stride 2) 2 * in_px * cin * cout * 16 - shared evenly by the launches of its classes
+        const double gf = kind == K_CONVT ? 2.0 * vh * vw * (double)cin * cout * 16 / launch_classes : 2.0 * oh * ow * (double)cout * cin * k * k;
+        note(ops, buf, gf / 1e9);
+      }
     }
     return out;
   }
@@ -696,6 +723,7 @@ class FullModel {
       hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch, (ctot + a.cpb - 1) / a.cpb), dim3(kNormThreads),
                          ((size_t)S * a.cpb * 2 + 2 * a.cpb) * sizeof(double), f.stream, a);
     });
+    note(ops, groups ? "GroupNorm finalize [norm_finalize_kernel]" : "InstanceNorm finalize [norm_finalize_kernel]");
     return out;
   }
 
@@ -720,6 +748,7 @@ class FullModel {
       const size_t quads = (size_t)A.cb * A.px() * 4;
       hipLaunchKernelGGL(affine_add_kernel, dim3((unsigned)((quads + 255) / 256), f.batch), dim3(256), 256, f.stream, k);
     });
+    note(ops, "ResnetBlock add [affine_add_kernel]");
     return out;
   }
 
@@ -812,6 +841,7 @@ class FullModel {
       GemvArgs a{P(w_off), P(b_off), x(f), Wk(y_off), rows, k, x_stride, act_in, act_out};
       hipLaunchKernelGGL(gemv_kernel, dim3((rows + 3) / 4, f.batch), dim3(256), 0, f.stream, a);
     });
+    note(ops, "cond / FiLM linear [gemv_kernel]", 2.0 * rows * k / 1e9);
   }
 
   struct ResPlan { std::string p; int cin, cout; int mode; size_t film0_off; size_t film1_row; };
@@ -827,6 +857,7 @@ class FullModel {
       AttnArgs a{Wk(qkv.off), Wk(att.off), C, 8, tokens};
       hipLaunchKernelGGL(attention_kernel, dim3(8, f.batch, tokens / kAttnQueries), dim3(256), (size_t)2 * tokens * kAttnRow * sizeof(f32x4), f.stream, a);
     });
+    note(ops, "attention core [attention_kernel]", 4.0 * tokens * tokens * C / 1e9);      // q.k and p.v: 2 x 2 x L x L x C
     FTensor o = conv(ops, K_SAME1, {src_tensor(att, C)}, IN_DIRECT, ACT_NONE, get(w, p + ".conv.weight"), get(w, p + ".conv.bias").data,
                      C, true, &x.t, IN_DIRECT);
     return Feat{o, C};
@@ -973,6 +1004,7 @@ class FullModel {
       bind(f, a);
       hipLaunchKernelGGL(kernel, dim3((pixels + 255) / 256, f.batch), dim3(256), 0, f.stream, a);
     });
+    note(ops, "image-domain kernel (crop / paste / warp / blend)");
   }
 
   // ---- whole pipeline ------------------------------------------------------------------------------
@@ -1014,6 +1046,7 @@ class FullModel {
     ops.push_back([=](const Frame& f) {
       hipLaunchKernelGGL(pose_pad_kernel, dim3(f.batch), dim3(64), 0, f.stream, f.pose, Wk(pose_eb), Wk(pose_face), f.batch);
     });
+    note(ops, "pose padding [pose_pad_kernel]");
     // 2. eyebrow morphing combiner
     {
       FTensor feat; Pending fp;
@@ -1105,7 +1138,12 @@ class FullModel {
   size_t dec_persist[6];
 
   // `want_dec[i]`: the caller asked for decomposer output i (copied out of the persistent buffers)
+  // per-op timing (ABI v5): `timing_events` holds ops_decomposer.size() + ops_rest.size() + 2 events when enabled; event i is recorded on the launch stream in
+  // FRONT of op i (decomposer ops first, then one separator, then the rest) and one more behind the last op
+  std::vector<hipEvent_t> timing_events;
+  bool timing_on = false, timing_recorded = false, timing_ran_decomposer = false;
   void run(const Frame& f, bool run_decomposer, const bool want_dec[6]) {
+    if (timing_on && timing_events.size() == ops_decomposer.size() + ops_rest.size() + 2) return run_timed(f, run_decomposer, want_dec);
     if (run_decomposer)
       for (auto& op : ops_decomposer) op(f);
     for (int i = 0; i < 6; ++i)
@@ -1113,6 +1151,27 @@ class FullModel {
         (void)hipMemcpyAsync(f.out[27 + i], Wk(dec_persist[i]), sizeof(float) * (size_t)f.batch * out_ch[27 + i] * 128 * 128,
                              hipMemcpyDeviceToDevice, f.stream);
     for (auto& op : ops_rest) op(f);
+  }
+  void run_timed(const Frame& f, bool run_decomposer, const bool want_dec[6]) {
+    size_t e = 0;
+    const size_t nd = ops_decomposer.size();
+    for (size_t i = 0; i < nd; ++i) {
+      (void)hipEventRecord(timing_events[e++], f.stream);
+      if (run_decomposer) ops_decomposer[i](f);
+    }
+    (void)hipEventRecord(timing_events[e++], f.stream);      // separator: end of the decomposer ops (the copies below belong to nobody)
+    for (int i = 0; i < 6; ++i)
+      if (want_dec[i])
+        (void)hipMemcpyAsync(f.out[27 + i], Wk(dec_persist[i]), sizeof(float) * (size_t)f.batch * out_ch[27 + i] * 128 * 128,
+                             hipMemcpyDeviceToDevice, f.stream);
+    for (size_t i = 0; i < ops_rest.size(); ++i) {
+      (void)hipEventRecord(timing_events[e++], f.stream);
+      ops_rest[i](f);
+    }
+    // (e == nd + 1 + ops_rest.size(): one event left for the end)
+    (void)hipEventRecord(timing_events[e], f.stream);
+    timing_recorded = true;
+    timing_ran_decomposer = run_decomposer;
   }
 };
 

@@ -631,6 +631,58 @@ int tha4_full_set_fault_policy(tha4_full* h, int policy) {
   return THA4_OK;
 }
 
+// ---- per-op timing (ABI v5) ---------------------------------------------------------------------------------------------------------------
+int tha4_full_set_timing(tha4_full* h, int enable) {
+  if (!h) return fail(THA4_ERR_INVALID_ARGUMENT, "handle must not be NULL");
+  FullModel& m = h->model;
+  DeviceGuard guard(h->device);
+  const size_t want = m.ops_decomposer.size() + m.ops_rest.size() + 2;
+  if (enable && m.timing_events.size() != want) {
+    for (hipEvent_t e : m.timing_events) (void)hipEventDestroy(e);
+    m.timing_events.clear();
+    for (size_t i = 0; i < want; ++i) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(hipEventCreate(&e));
+      m.timing_events.push_back(e);
+    }
+  }
+  m.timing_on = enable != 0;
+  m.timing_recorded = false;
+  return THA4_OK;
+}
+
+int tha4_full_num_ops(const tha4_full* h) {
+  return h ? (int)(h->model.ops_decomposer.size() + h->model.ops_rest.size()) : THA4_ERR_INVALID_ARGUMENT;
+}
+
+int tha4_full_op_info(const tha4_full* h, int index, const char** label, double* gflop) {
+  if (!h) return fail(THA4_ERR_INVALID_ARGUMENT, "handle must not be NULL");
+  const FullModel& m = h->model;
+  const int nd = (int)m.info_decomposer.size(), n = nd + (int)m.info_rest.size();
+  if (index < 0 || index >= n) return fail(THA4_ERR_INVALID_ARGUMENT, "op index out of range");
+  const FullModel::OpInfo& o = index < nd ? m.info_decomposer[index] : m.info_rest[index - nd];
+  if (label) *label = o.label.c_str();
+  if (gflop) *gflop = o.gflop;
+  return THA4_OK;
+}
+
+int tha4_full_last_op_ms(tha4_full* h, float* ms, int capacity) {
+  if (!h || !ms) return fail(THA4_ERR_INVALID_ARGUMENT, "handle/ms must not be NULL");
+  FullModel& m = h->model;
+  const int nd = (int)m.ops_decomposer.size(), nr = (int)m.ops_rest.size();
+  if (capacity < nd + nr) return fail(THA4_ERR_INVALID_ARGUMENT, "ms must hold tha4_full_num_ops() floats");
+  if (!m.timing_on || !m.timing_recorded || (int)m.timing_events.size() != nd + nr + 2)
+    return fail(THA4_ERR_INVALID_ARGUMENT, "no timed pose call recorded (tha4_full_set_timing)");
+  DeviceGuard guard(h->device);
+  HIP_TRY(hipEventSynchronize(m.timing_events[nd + nr + 1]));
+  for (int i = 0; i < nd; ++i) {
+    ms[i] = 0.0f;
+    if (m.timing_ran_decomposer) HIP_TRY(hipEventElapsedTime(&ms[i], m.timing_events[i], m.timing_events[i + 1]));
+  }
+  for (int j = 0; j < nr; ++j) HIP_TRY(hipEventElapsedTime(&ms[nd + j], m.timing_events[nd + 1 + j], m.timing_events[nd + 2 + j]));
+  return THA4_OK;
+}
+
 int tha4_full_numeric_status(tha4_full* h, int synchronize) {
   if (!h) return fail(THA4_ERR_INVALID_ARGUMENT, "handle must not be NULL");
   if (synchronize) {
@@ -659,6 +711,8 @@ void tha4_full_destroy(tha4_full* h) {
   DeviceGuard guard(h->device);
   h->order.destroy();
   h->destroy_side();
+  for (hipEvent_t e : h->model.timing_events) (void)hipEventDestroy(e);
+  h->model.timing_events.clear();
   if (h->fault) (void)hipHostFree(h->fault);
   if (h->model.dev_params) (void)hipFree(h->model.dev_params);
   if (h->model.dev_work) (void)hipFree(h->model.dev_work);

@@ -115,6 +115,34 @@ class HipFullPoser(Poser):
         if self._handle is not None:
             _capi.check(self._lib, self._lib.tha4_full_numeric_status(self._handle, 1), "tha4_full_numeric_status")
 
+    def set_timing(self, enable: bool = True):
+        """Per-op HIP-event timing of the following pose calls (tha4_full_set_timing, ABI v5; a measurement aid: timed calls are slower).
+        The handle must exist (pose once or `get_modules()` first); a re-created handle (regrow, `set_exact_fp32`) starts untimed."""
+        if self._handle is None:
+            raise _capi.Tha4Error("set_timing needs a live handle: call get_modules() or pose() first")
+        _capi.check(self._lib, self._lib.tha4_full_set_timing(self._handle, int(bool(enable))), "tha4_full_set_timing")
+
+    def op_info(self):
+        """[(label, as-written GFLOP per frame)] for every op of the handle's schedule, decomposer ops first (tha4_full_op_info)."""
+        if self._handle is None:
+            raise _capi.Tha4Error("op_info needs a live handle")
+        n = self._lib.tha4_full_num_ops(self._handle)
+        out = []
+        for i in range(n):
+            label, gf = C.c_char_p(), C.c_double()
+            _capi.check(self._lib, self._lib.tha4_full_op_info(self._handle, i, C.byref(label), C.byref(gf)), "tha4_full_op_info")
+            out.append((label.value.decode(), float(gf.value)))
+        return out
+
+    def last_op_ms(self):
+        """Milliseconds of every op of the LAST timed pose call (waits for it; 0 for decomposer ops the call reused): tha4_full_last_op_ms."""
+        if self._handle is None:
+            raise _capi.Tha4Error("last_op_ms needs a live handle")
+        n = self._lib.tha4_full_num_ops(self._handle)
+        buf = (C.c_float * n)()
+        _capi.check(self._lib, self._lib.tha4_full_last_op_ms(self._handle, buf, n), "tha4_full_last_op_ms")
+        return [float(x) for x in buf]
+
     def set_exact_fp32(self, on: bool = True) -> "HipFullPoser":
         """Switch between the default plan (fp16 hi/lo operand halves, |operand| <= 65504) and the exact-fp32 plan; the native handle
         is re-created lazily by the next call.  Results of the two plans agree within the parity gate, not bitwise."""

@@ -81,6 +81,10 @@ static int g_remap_launches = 0;      // conv_tile launches that took the XCD-aw
 
 extern "C" {
 int emu_remap_launches() { return g_remap_launches; }
+// the host's pixel <-> MFMA-column assignment for one window geometry (full_kernels.h pixel_permutation): out[16], conflict cycles of identity / of the choice
+void emu_pixel_permutation(int twl, int win_w, int win_h, int in_stride, int* out, int* cost_identity, int* cost_best) {
+  tha4::pixel_permutation(twl, win_w, in_stride, tha4::tile_plane_bytes(win_h * win_w), out, cost_identity, cost_best);
+}
 
 // stats0/1: per-tile moments [n][tiles][cb*16][2] of the two sources; film0 [2*channels] constant, film1 [n][2*channels]
 void emu_set_fused_norm(const float* stats0, int tiles0, const float* stats1, int tiles1, int channels, int groups, float inv_count,

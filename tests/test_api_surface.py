@@ -172,6 +172,8 @@ def test_new_entry_points_validate_arguments(built):
     assert lib.tha4_full_create_ex(None, 2, 0, 1, 3, 0, None) == -1
     assert lib.tha4_full_flags(None) == -1
     assert lib.tha4_full_set_fault_policy(None, 0) == -1
+    assert lib.tha4_full_set_timing(None, 1) == -1 and lib.tha4_full_num_ops(None) == -1          # ABI v5: per-op timing
+    assert lib.tha4_full_op_info(None, 0, None, None) == -1 and lib.tha4_full_last_op_ms(None, None, 0) == -1
     assert lib.tha4_full_num_networks(None) == -1
     # stateless image entry points refuse host pointers instead of launching on them
     import ctypes as C

@@ -212,6 +212,26 @@ def test_xcd_aware_order_is_taken_where_the_product_takes_it(lib):
     assert lib.emu_remap_launches() == before
 
 
+def test_pixel_permutation_removes_the_window_read_conflicts(lib):
+    """Round 5: which pixel of a 16-pixel group an MFMA column computes is chosen on the host so that the ds_read_b128 B-fragment reads of the LDS
+    window are conflict-free (csrc/full_kernels.h).  For every 16-wide stride-1 geometry - all of the batch-8 plan's conv_tile launches - the
+    identity costs one extra LDS cycle in each of the instruction's four lane groups and the choice none; elsewhere it is never worse."""
+    ip = C.POINTER(C.c_int)
+    for twl, tile_h, stride, halo in [(4, 16, 1, 2), (4, 8, 1, 2), (4, 4, 1, 2), (4, 1, 1, 2), (5, 8, 1, 2), (4, 16, 1, 1), (4, 8, 1, 0),   # 3x3 / convT / 1x1
+                                      (3, 8, 1, 2), (3, 4, 1, 2), (2, 4, 1, 2), (3, 2, 1, 2), (4, 8, 2, 2), (3, 8, 2, 2), (3, 4, 1, 1), (2, 4, 1, 1)]:
+        tw = 1 << twl
+        win_w, win_h = tw * stride + halo, tile_h * stride + halo
+        out = np.zeros(16, np.int32)
+        ci, cb = C.c_int(), C.c_int()
+        lib.emu_pixel_permutation(twl, win_w, win_h, stride, out.ctypes.data_as(ip), C.byref(ci), C.byref(cb))
+        assert sorted(out.tolist()) == list(range(16)), (twl, tile_h, stride, out)
+        assert 0 <= cb.value <= ci.value, (twl, tile_h, stride, ci.value, cb.value)
+        if twl >= 4 and stride == 1:
+            assert ci.value == 4 and cb.value == 0, (twl, tile_h, ci.value, cb.value)
+        if cb.value == ci.value:
+            assert out.tolist() == list(range(16))                     # identity is kept unless something is strictly better
+
+
 def _partials(x, tiles):
     """[n][c][px] -> partial sums [n][tiles][cb*16][2] like the conv epilogue writes them."""
     n, c, px = x.shape

@@ -667,3 +667,32 @@ def test_midgain_set_all_33_outputs_vs_reference_fixture(exact, golden_io):
     assert not bad, bad
     a = z["b1_ref32_sub3_out1"]
     assert a.min() < 0.25 and a.max() > 0.8                               # the set is what it claims to be (stride-3 subset; full maps 0.13 .. 0.91)
+
+
+def test_per_op_timing_and_labels(poser1, full_io, golden_io):
+    """ABI v5 measurement aid (bench.py's live full-model roofline): every op of the schedule has a label naming the reference layer and
+    the kernel, the convolution labels carry the as-written GFLOP of their layer - their sum is the reference's own FLOP count of a frame -
+    and a timed call returns one duration per op; timing changes no byte of the outputs."""
+    dev = torch.device("cuda:0")
+    image = torch.from_numpy(golden_io["image_f32"]).to(dev)
+    pose = torch.from_numpy(full_io["poses"][0]).to(dev)
+    ref = poser1.pose(image, pose, image_changed=True).clone()
+    info = poser1.op_info()
+    assert len(info) > 300 and not any(lbl == "(unlabelled)" for lbl, _ in info)
+    conv_gflop = sum(g for lbl, g in info if lbl.startswith("conv"))
+    print(f"sum of the convolution labels: {conv_gflop:.2f} GFLOP per cold frame")
+    assert abs(conv_gflop - 645.4) < 0.02 * 645.4, conv_gflop           # SURVEY.md 8d: 645.90 GFLOP cold incl. 0.4 of attention bmm + linears
+    poser1.set_timing(True)
+    cold = poser1.pose(image, pose, image_changed=True)
+    ms_cold = poser1.last_op_ms()
+    warm = poser1.pose(image, pose)
+    ms_warm = poser1.last_op_ms()
+    poser1.set_timing(False)
+    assert torch.equal(cold, ref) and torch.equal(warm, ref)
+    assert len(ms_cold) == len(info) == len(ms_warm)
+    assert all(m > 0 for m in ms_cold) and 2.0 < sum(ms_cold) < 60.0
+    nd = sum(1 for m in ms_warm if m == 0.0)
+    assert 30 < nd < 80 and all(m == 0.0 for m in ms_warm[:nd]) and all(m > 0 for m in ms_warm[nd:])     # the decomposer ops were reused
+    from tha4_amd import _capi
+    with pytest.raises(_capi.Tha4Error, match="no timed pose call"):
+        poser1.last_op_ms()

@@ -45,6 +45,8 @@ def full():
     shutil.copy(os.path.join(G, "pf_kernel_stats.csv"), os.path.join(P, f"{tag}_full_b1_kernel_stats.csv"))
     if os.path.exists(os.path.join(G, "full_b1_traffic.json")):
         shutil.copy(os.path.join(G, "full_b1_traffic.json"), os.path.join(P, f"{tag}_full_b1_traffic.json"))
+    if os.path.exists(os.path.join(G, "full_b1_layers.json")):          # per-launch-class table of the last cold frame (bench.py quotes its dominant class)
+        shutil.copy(os.path.join(G, "full_b1_layers.json"), os.path.join(P, f"{tag}_full_b1_layers.json"))
     md = [f"# {tag} - full THA4 model (mode_07), batch 1, MI355X",
           f"Source: `tools/profile_{tag}.sh` (`rocprofv3 --kernel-trace --stats -- python tools/time_full.py`: 3 warm-up + 20 steady + 20 cold",
           "frames = 43 frames, 21 of them run the eyebrow decomposer; PMC passes over 9 frames; FETCH_SIZE / WRITE_SIZE passes over steady-only",

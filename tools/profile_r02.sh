@@ -33,7 +33,7 @@ python tools/pmc_summary.py gpurun_out/pmcfull_1 gpurun_out/pmcfull_2 > gpurun_o
 python tools/traffic_json.py full gpurun_out/pft_fetch_steady gpurun_out/pft_write_steady --frames 4 --cold-fetch gpurun_out/pft_fetch_cold --cold-write gpurun_out/pft_write_cold --cold-frames 4 \
   --command "tools/time_full.py --frames 4 --mode steady|cold (+ 3 warm-up frames each)" -o gpurun_out/full_b1_traffic.json > /dev/null
 grep "^conv " gpurun_out/bd_full.err > gpurun_out/bd_schedule.txt
-python tools/conv_breakdown.py gpurun_out/bd_schedule.txt $(ls gpurun_out/bd_full/*/*kernel_trace.csv | head -1) > gpurun_out/bd_report.txt 2>&1
+python tools/conv_breakdown.py gpurun_out/bd_schedule.txt $(ls gpurun_out/bd_full/*/*kernel_trace.csv | head -1) gpurun_out/full_b1_layers.json > gpurun_out/bd_report.txt 2>&1
 python tools/trace_gaps.py gpurun_out/bd_full 1200 > gpurun_out/bd_gaps.txt 2>&1
 cp $(ls gpurun_out/pf_stats/*/*kernel_stats.csv | head -1) gpurun_out/pf_kernel_stats.csv
 rm -rf gpurun_out/pf_stats gpurun_out/pmcfull_1 gpurun_out/pmcfull_2 gpurun_out/pft_* gpurun_out/bd_full
