@@ -50,6 +50,9 @@ constexpr int kTileMaxItemsHalf = 6; // its staging items per thread: window <= 
 // producer's per-tile moments.  Mirrors norm_finalize_kernel (same fp64 arithmetic); all `nthreads` threads of the
 // workgroup must call it; `scratch` holds 2*ctot doubles and may alias memory that is not in use yet.  The caller
 // synchronises the workgroup afterwards before reading the table.
+// ACC = false compiles the moment-accumulator route out (conv_small_kernel: its prologue already holds a unit's weights and window in registers - the 64
+// more the accumulator loads take spill - and the planner never gives it one: small maps have few tiles).
+template <bool ACC = true>
 THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, float* tab_sc, float* tab_sh, double* scratch) {
   const FusedNorm& f = a.fnorm;
   const int c0 = a.src[0].cb * 16;
@@ -80,6 +83,14 @@ THA4_DEV void fused_norm_table(const ConvArgs& a, int n, int tid, int nthreads, 
     const int nt = f.tiles[s];
     const float* ps = f.stats[s] + ((size_t)n * nt * cw + cl) * 2;
     double su = 0.0, sq = 0.0;
+    if (ACC && f.acc) {                                      // the producers' moment accumulators: kMomentShards (hi, lo) integer pairs per channel, all requested at once
+      const MomentAcc* pa = reinterpret_cast<const MomentAcc*>(f.stats[s]) + ((size_t)n * kMomentShards * cw + cl);
+      double vs[kMomentShards], vq[kMomentShards];
+#pragma unroll
+      for (int u2 = 0; u2 < kMomentShards; ++u2) moment_acc_read(pa + (size_t)u2 * cw, vs[u2], vq[u2]);
+#pragma unroll
+      for (int u2 = 0; u2 < kMomentShards; ++u2) { su += vs[u2]; sq += vq[u2]; }      // fixed shard order
+    } else
     for (int t0 = 0; t0 < nt; t0 += TB) {
       f32x2 v[TB];
 #pragma unroll
@@ -627,6 +638,9 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
       float* dst = a.stats + ((((size_t)n * a.stats_tiles + cg.stats_tile0 + tile) * a.nb + mtile * TMB) * 16 + i) * 2;
       dst[0] = s;
       dst[1] = q;
+      // ... and into the tensor's moment accumulators (full_kernels.h MomentAcc): the consumer's normalisation needs no finalize launch.  The shard is a
+      // function of the workgroup id only, so each shard's (integer) sum is the same whatever the order of arrival
+      if (a.stats_acc) moment_acc_add(a.stats_acc + (((size_t)n * kMomentShards + ((int)blockIdx.x & (kMomentShards - 1))) * a.nb + mtile * TMB) * 16 + i, s, q, a.acc_fault);
     }
   }
   THA4_CSTAMP();                                           // statistics written: end of the kernel

@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
   }
 #endif
   if (a.fnorm.enabled) {
-    fused_norm_table(a, n, tid, kSmallThreads, tab_sc, tab_sh, reinterpret_cast<double*>(wins));
+    fused_norm_table<false>(a, n, tid, kSmallThreads, tab_sc, tab_sh, reinterpret_cast<double*>(wins));      // (per-tile moments only: full_conv16_kernels.h)
     __syncthreads();                                       // table complete; scratch (aliasing the windows) no longer read
   }
   THA4_SSTAMP();                                           // 2: normalisation table built
@@ -446,6 +446,8 @@ __global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(ConvArgs a) {
       float* dst = a.stats + ((((size_t)n * a.stats_tiles + cg.stats_tile0 + tile) * a.nb + bo) * 16 + g4 + j) * 2;
       dst[0] = rs[j];
       dst[1] = rq[j];
+      // (many-tile outputs - the transposed convolutions of the encoder-decoders - also feed the tensor's moment accumulators: full_kernels.h MomentAcc)
+      if (a.stats_acc) moment_acc_add(a.stats_acc + (((size_t)n * kMomentShards + ((int)blockIdx.x & (kMomentShards - 1))) * a.nb + bo) * 16 + g4 + j, rs[j], rq[j], a.acc_fault);
     }
   }
   THA4_SSTAMP();                                           // wave 0: epilogue issued

@@ -58,8 +58,37 @@ struct FusedNorm {
   const float* film1;      // [n][film1_stride] per-frame (scale | shift) or null
   long long film1_stride;
   int enabled;
+  int acc;                 // 1: stats[] are MomentAcc accumulators [n][kMomentShards][cb*16] filled by the producers' atomics (tiles[] = kMomentShards), not per-tile floats
   int* fault;              // sticky numeric-fault flag of the handle (a non-finite scale/shift sets it), or null
 };
+
+// Moments of a whole tensor accumulated by its PRODUCER with integer atomics (round 5): the per-(frame, channel) sums of x and x^2 that a normalisation needs used
+// to be per-tile partial sums reduced by a separate norm_finalize_kernel launch whenever a tensor has more than 64 tiles (48 launches of 5.5 us on the
+// dependency chain of a batch-1 frame).  Here every workgroup of the producing convolution adds its tile's sums to one of kMomentShards accumulators per
+// channel, and the CONSUMER folds the 8 shards into its scale / shift table like it folds per-tile moments (fused_norm_table).  A sum travels as a pair of
+// 64-bit integers - hi = trunc(x), lo = rint((x - hi) 2^32) - so that the result does not depend on the order in which workgroups arrive (integer addition
+// is associative: a frame's bytes stay reproducible) and small tensors keep a 2^-32 absolute resolution per tile sum while large ones have the range of an
+// int64 (|sum| < 9e15 is checked: beyond it - or NaN - the numeric-fault flag is raised like for a non-finite scale / shift).
+constexpr int kMomentShards = 8;
+struct MomentAcc { long long s_hi, s_lo, q_hi, q_lo; };      // 32 bytes per (frame, shard, channel)
+THA4_DEV void moment_acc_add(MomentAcc* slot, float s, float q, int* fault) {
+  const double ds = (double)s, dq = (double)q;
+  if (!(fabs(ds) < 9.0e15 && fabs(dq) < 9.0e15)) {         // NaN / inf / out of the accumulator's range
+    if (fault) *fault = 1;
+    return;
+  }
+  const double hs = trunc(ds), hq = trunc(dq);
+  long long* w = reinterpret_cast<long long*>(slot);
+  atomic_add_i64(w + 0, (long long)hs);
+  atomic_add_i64(w + 1, (long long)rint((ds - hs) * 4294967296.0));
+  atomic_add_i64(w + 2, (long long)hq);
+  atomic_add_i64(w + 3, (long long)rint((dq - hq) * 4294967296.0));
+}
+THA4_DEV void moment_acc_read(const MomentAcc* slot, double& s, double& q) {
+  const long long* w = reinterpret_cast<const long long*>(slot);
+  s = (double)w[0] + (double)w[1] * (1.0 / 4294967296.0);
+  q = (double)w[2] + (double)w[3] * (1.0 / 4294967296.0);
+}
 
 // Division by a launch constant: q = (x * m) >> 42 with m = ceil(2^42 / d) - exact for 0 <= x < 2^22 and 1 <= d < 2^20 (x * (m d - 2^42) < x d < 2^42; x * m < 2^64), a handful of
 // instructions where the compiler's sequence for a run-time divisor is ~30.  In-kernel stamps (profiles/r04_raw/c37_phase_prologue.txt) put 2.3 k cycles of
@@ -82,7 +111,8 @@ struct ConvArgs {
   int in_h, in_w;        // stored spatial size of the tensor sources
   int in_mode;           // IN_DIRECT | IN_UP2 (virtual 2h x 2w, nearest) | IN_POOL2 (virtual h/2 x w/2, mean of 2x2); must equal the template INMODE
   int ntaps;
-  int tap_dy[kMaxTaps], tap_dx[kMaxTaps];   // virtual input coord = tile coord * in_stride + d
+  signed char tap_dy[kMaxTaps], tap_dx[kMaxTaps];   // virtual input coord = tile coord * in_stride + d (bytes since round 5: the argument block must stay within
+                                                    // the lines one batch of scalar loads warms at kernel entry - warm_kernarg, tests/test_api_surface.py)
   int in_stride;
   int tile_h, tile_w;    // grid of output positions computed by this launch (per frame)
   int out_h, out_w;      // stored output size; output coord = tile * out_s + out_o
@@ -94,6 +124,8 @@ struct ConvArgs {
   const int* act_out;    // per-output-channel activation codes [nb*16] or null (none)
   float* out;            // C16 [n][nb][out_h*out_w][16]
   float* stats;          // partial sums [n][stats_tiles][nb*16][2] (sum, sum of squares) or null
+  MomentAcc* stats_acc;  // conv_tile_kernel / conv_small_kernel: moment accumulators [n][kMomentShards][nb*16] this launch adds its tiles' sums to (MomentAcc above), or null
+  int* acc_fault;        // numeric-fault flag for sums the accumulators cannot hold
   int stats_tiles;       // tiles per frame in the stats buffer (several launches may fill one buffer: convT parity classes)
   int stats_tile0;       // first tile index written by this launch
   int nb;                // output channel blocks
@@ -835,12 +867,25 @@ struct NormArgs {
 };
 
 constexpr int kNormThreads = 1024;
+#ifndef THA4_NORM_LOADS_IN_FLIGHT
+#define THA4_NORM_LOADS_IN_FLIGHT 4      // independent 8-byte moment loads per thread and round (a power of two).  MEASURED: eight is 0.3-0.7 % SLOWER on the
+                                         // batch-1 frame than four, with either channel split (same-box A/Bs, profiles/r05_raw/c4_ab_norm.txt, c5_ab_norm.txt)
+#endif
 // channels per workgroup: whole GroupNorm groups, at least 32 channels, about an eighth of the tensor - a large map has
 // 256-512 tiles per channel, and the more tile slices a workgroup's 1024 threads form the fewer dependent load rounds each
 // thread pays (one workgroup per frame: 8-16 rounds; 4-8 workgroups: 2)
-inline int norm_channels_per_block(int ctot, int channels, int groups) {
+inline int norm_channels_per_block(int ctot, int channels, int groups, int tiles = 0) {
   const int gs = groups > 0 ? channels / groups : 1;
-  const int want = ctot / 8 > 32 ? ctot / 8 : 32;
+  int want = ctot / 8 > 32 ? ctot / 8 : 32;
+  // `tiles` > 0 (tuning aid, THA4_NORM_TILE_SPLIT): fewer channels per workgroup when a channel has many tiles (a 512x512 map: 1024+), so that a thread walks
+  // about one round of loads instead of 8+ (never below one GroupNorm group, never below 4 channels).  MEASURED NEUTRAL (profiles/r05_raw/c5_ab_norm.txt:
+  // 183.57 vs 183.57 frames/s): the 10-12 us finalize launches behind the 256x256 / 512x512 convolutions are not their own load rounds - the kernel boundary
+  // behind a convolution that left 17-34 MB of dirty lines in the L2s waits for their write-back (bytes / ~6 TB/s), whatever the next kernel is
+  if (tiles > 0) {
+    int cap = kNormThreads * THA4_NORM_LOADS_IN_FLIGHT / tiles;
+    cap = cap < 4 ? 4 : cap;
+    want = want < cap ? want : cap;
+  }
   int cpb = (want + gs - 1) / gs * gs;
   return cpb < ctot ? cpb : ctot;
 }
@@ -878,11 +923,10 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
     const int cw = (s ? a.cb[1] : a.cb[0]) * 16;
     const int nt = s ? a.tiles[1] : a.tiles[0];
     const float* ps = (s ? a.stats[1] : a.stats[0]) + ((size_t)n * nt * cw + cl) * 2;
-    // eight independent partial sums (fixed assignment t -> sum (t/S)%8, combined in a fixed order): the loads of eight tiles are in flight at once
-    // instead of one fp64 add chain waiting on each 8-byte load in turn (round 2: four; round 5: eight - a 512x512 map has 1024-4096 tiles per channel
-    // and a 32-channel tensor gets ONE workgroup, i.e. 32-128 tiles per thread: 8-32 dependent load rounds at four in flight)
+    // NP independent partial sums (fixed assignment t -> sum (t/S)%NP, combined pairwise in a fixed order): the loads of NP tiles are in flight at once
+    // instead of one fp64 add chain waiting on each 8-byte load in turn
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    constexpr int NP = 8;
+    constexpr int NP = THA4_NORM_LOADS_IN_FLIGHT;
     double su[NP], sq[NP];
 #pragma unroll
     for (int u = 0; u < NP; ++u) { su[u] = 0.0; sq[u] = 0.0; }
@@ -894,8 +938,8 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
 #pragma unroll
       for (int u = 0; u < NP; ++u) { su[u] += (double)v[u][0]; sq[u] += (double)v[u][1]; }
     }
-    {                                                      // at most seven left-over tiles: requested together, added in tile order
-      f32x2 v[NP - 1];
+    if (t < nt) {                                          // at most NP - 1 left-over tiles: requested together, added in tile order (no left-over: no
+      f32x2 v[NP - 1];                                     // extra dependent round - the unconditional form of this block cost 0.7 us on EVERY launch)
 #pragma unroll
       for (int u = 0; u < NP - 1; ++u) v[u] = *reinterpret_cast<const f32x2*>(ps + (size_t)min(t + u * S, nt - 1) * cw * 2);
 #pragma unroll
@@ -905,8 +949,12 @@ __global__ void __launch_bounds__(kNormThreads) norm_finalize_kernel(NormArgs a)
         sq[u] += keep ? (double)v[u][1] : 0.0;
       }
     }
-    part[((size_t)sl * ctot + cl0) * 2] = ((su[0] + su[1]) + (su[2] + su[3])) + ((su[4] + su[5]) + (su[6] + su[7]));
-    part[((size_t)sl * ctot + cl0) * 2 + 1] = ((sq[0] + sq[1]) + (sq[2] + sq[3])) + ((sq[4] + sq[5]) + (sq[6] + sq[7]));
+#pragma unroll
+    for (int w = 1; w < NP; w *= 2)                        // pairwise, fixed order: ((0+1) + (2+3)) + ((4+5) + (6+7))
+#pragma unroll
+      for (int u = 0; u + w < NP; u += 2 * w) { su[u] += su[u + w]; sq[u] += sq[u + w]; }
+    part[((size_t)sl * ctot + cl0) * 2] = su[0];
+    part[((size_t)sl * ctot + cl0) * 2 + 1] = sq[0];
   }
   __syncthreads();
   for (int cl0 = threadIdx.x; cl0 < ctot; cl0 += kNormThreads) {

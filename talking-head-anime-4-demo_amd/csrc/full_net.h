@@ -45,6 +45,7 @@ struct FTensor {           // C16 feature map in the workspace
   int cb = 0, h = 0, w = 0;
   size_t stats_off = 0;    // partial moments [n][tiles][cb*16][2]
   int stats_tiles = 0;
+  size_t acc_off = (size_t)-1;   // moment accumulators [n][kMomentShards][cb*16] (MomentAcc) in the accumulator arena, or none
   int px() const { return h * w; }
 };
 
@@ -52,6 +53,7 @@ struct Pending {           // transform a consumer applies while loading a tenso
   size_t scale_off = (size_t)-1, shift_off = (size_t)-1;   // workspace offsets of [n][cb*16] (written by norm_finalize_kernel)
   // ... or FUSED: no finalize launch; the consumer reduces the producer's per-tile moments itself (FusedNorm)
   bool fused = false;
+  bool acc = false;        // fused, from the producers' moment accumulators (stats_off[] are offsets in the accumulator arena, tiles[] = kMomentShards)
   size_t stats_off[2] = {0, 0};
   int tiles[2] = {0, 0};
   int channels = 0, groups = 0;
@@ -85,6 +87,9 @@ class FullModel {
   size_t dbg_off = 0;        // tuning aid (THA4_PHASE_TIMING): stamp buffer
   int* fault = nullptr;      // sticky numeric-fault flag (pinned host memory mapped into the device; set by the C ABI at create)
   void finalize_scratch() {
+    if (std::getenv("THA4_DUMP_SCHEDULE"))
+      std::fprintf(stderr, "plan: %zu + %zu ops (decomposer + rest); normalisations: %d folded from per-tile moments, %d folded from moment accumulators, %d finalize launches; "
+                   "accumulator arena %zu KiB\n", ops_decomposer.size(), ops_rest.size(), n_norm_tiles, n_norm_acc, n_norm_finalize, acc_floats * sizeof(float) >> 10);
     while (info_decomposer.size() < ops_decomposer.size()) info_decomposer.push_back(OpInfo{"(unlabelled)", 0.0});
     while (info_rest.size() < ops_rest.size()) info_rest.push_back(OpInfo{"(unlabelled)", 0.0});
     partial_off = alloc_work(partial_floats);
@@ -106,6 +111,18 @@ class FullModel {
     work_floats = at + floats_per_frame * (size_t)max_batch;
     return at;
   }
+  // moment accumulators (full_kernels.h MomentAcc): their own arena, zeroed by ONE memset at the top of every call
+  char* dev_acc = nullptr;
+  size_t acc_floats = 0;
+  size_t alloc_acc(size_t floats_per_frame) {
+    size_t at = (acc_floats + 63) / 64 * 64;
+    acc_floats = at + floats_per_frame * (size_t)max_batch;
+    return at;
+  }
+  MomentAcc* Acc(size_t off) const { return reinterpret_cast<MomentAcc*>(reinterpret_cast<float*>(dev_acc) + off); }
+  // Producer-side accumulation + consumer-side folding instead of a norm_finalize_kernel launch for tensors of more than THA4_FUSED_NORM_MAX_TILES tiles
+  // (round 5).  THA4_NO_MOMENT_ACC (tuning aid) restores the finalize launches.
+  bool acc_planned() const { return !exact_fp32 && !tune_env("THA4_NO_MOMENT_ACC") && !tune_env("THA4_NO_TILE_CONV"); }
   template <class T = float> const T* P(size_t off) const { return reinterpret_cast<const T*>(dev_params + off); }
   float* Wk(size_t off) const { return reinterpret_cast<float*>(dev_work) + off; }
 
@@ -423,12 +440,13 @@ class FullModel {
       // the tile plan would split over two launches, not the 16-tap stride-2 convolutions (their 108-pixel window per 16
       // outputs makes staging dominate) and not average-pooled inputs (four dependent samples per staged item)
       bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
+      if (fpend && fpend->acc) want = false;                // conv_small_kernel folds per-tile moments only (a tensor with accumulators has many tiles: never a small map)
       if (!tune_env("THA4_SMALL_ALL_KINDS") && (kind == K_S2K4 || in_mode == IN_POOL2)) want = false;
       if (want && !tune_env("THA4_NO_SMALL_CONV")) {
         sp = plan_small_conv(g0, th, tw, nb, nq, 256, max_batch);
         small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
       }
-      if (!small && fpend && !tiled && !tune_env("THA4_NO_SMALL_CONV")) {
+      if (!small && fpend && !fpend->acc && !tiled && !tune_env("THA4_NO_SMALL_CONV")) {
         // a folded normalisation needs one of the two kernels that can evaluate it: take conv_small_kernel even if its grid
         // runs in several rounds (1x1 projections behind a GroupNorm when the schedule is built for 2 frames)
         sp = plan_small_conv(g0, th, tw, nb, nq, 1 << 30, max_batch);
@@ -482,6 +500,10 @@ class FullModel {
     if (want_stats) {
       out.stats_tiles = tiles * nclass;
       out.stats_off = alloc_work((size_t)out.stats_tiles * nb * 16 * 2);
+      // tensors with many tiles on handles built for one or two frames: the producer (conv_tile_kernel / conv_small_kernel) also feeds the moment accumulators, so that
+      // norm() needs no finalize launch (below).  Few tiles: the consumer folds the per-tile moments themselves, as before
+      if ((tiled || small) && acc_planned() && out.stats_tiles > fused_norm_max_tiles() && max_batch <= fused_norm_max_batch())
+        out.acc_off = alloc_acc((size_t)kMomentShards * nb * 16 * (sizeof(MomentAcc) / sizeof(float)));
     }
     size_t bias_off = kNone;
     if (bias_host || bias_override) {
@@ -571,7 +593,7 @@ class FullModel {
       a.nsrc = (int)srcs.size();
       a.in_h = ih; a.in_w = iw; a.in_mode = in_mode;
       a.ntaps = g.ntaps;
-      for (int t = 0; t < g.ntaps; ++t) { a.tap_dy[t] = g.dy[t]; a.tap_dx[t] = g.dx[t]; }
+      for (int t = 0; t < g.ntaps; ++t) { a.tap_dy[t] = (signed char)g.dy[t]; a.tap_dx[t] = (signed char)g.dx[t]; }
       a.in_stride = g.in_stride;
       a.tile_h = th; a.tile_w = tw; a.out_h = oh; a.out_w = ow;
       a.out_sy = g.out_sy; a.out_sx = g.out_sx; a.out_oy = g.out_oy; a.out_ox = g.out_ox;
@@ -608,7 +630,11 @@ class FullModel {
         if (fp.fused) {
           FusedNorm& fn = c.fnorm;
           fn.enabled = 1;
-          for (int i = 0; i < 2; ++i) { fn.stats[i] = fp.tiles[i] ? Wk(fp.stats_off[i]) : nullptr; fn.tiles[i] = fp.tiles[i]; }
+          for (int i = 0; i < 2; ++i) {
+            fn.stats[i] = !fp.tiles[i] ? nullptr : fp.acc ? reinterpret_cast<const float*>(Acc(fp.stats_off[i])) : Wk(fp.stats_off[i]);
+            fn.tiles[i] = fp.tiles[i];
+          }
+          fn.acc = fp.acc ? 1 : 0;
           fn.channels = fp.channels; fn.groups = fp.groups; fn.inv_count = fp.inv_count; fn.eps = 1e-5f;
           fn.gamma = P(fp.gamma_off); fn.beta = P(fp.beta_off);
           fn.film0 = fp.film0_off == kNone ? nullptr : P(fp.film0_off);
@@ -628,6 +654,8 @@ class FullModel {
         c.residual = has_res ? Wk(resc.off) : nullptr;
         c.out = Wk(outc.off);
         c.stats = outc.stats_tiles ? Wk(outc.stats_off) : nullptr;
+        c.stats_acc = outc.acc_off != kNone ? Acc(outc.acc_off) : nullptr;
+        c.acc_fault = fault;
         c.batch = f.batch;
         if (small || tiled) finish_conv_batch(c, small, 0);
         if (small) {
@@ -671,6 +699,9 @@ class FullModel {
     return out;
   }
 
+  int n_norm_finalize = 0, n_norm_tiles = 0, n_norm_acc = 0;      // normalisations by route (THA4_DUMP_SCHEDULE prints them)
+  static int fused_norm_max_tiles() { return tune_env("THA4_FUSED_NORM_MAX_TILES") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_TILES")) : 64; }
+  static int fused_norm_max_batch() { return tune_env("THA4_FUSED_NORM_MAX_BATCH") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_BATCH")) : 2; }
   // Normalisation finalize over up to two concatenated tensors; returns the pending transform per source.
   std::vector<Pending> norm(std::vector<Op>& ops, const std::vector<FTensor>& srcs, int channels, int groups,
                             const HostTensor& gamma, const HostTensor& beta, size_t film0_off = kNone,
@@ -681,19 +712,42 @@ class FullModel {
     // few tiles: no finalize launch - every consumer reduces the per-tile moments itself (FusedNorm / FusedInstanceNorm)
     int total_tiles = 0;
     for (auto& t : srcs) total_tiles += t.stats_tiles;
-    const int fuse_max = tune_env("THA4_FUSED_NORM_MAX_TILES") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_TILES")) : 64;
+    const int fuse_max = fused_norm_max_tiles();
     // (a batched call multiplies the consumers' workgroups, each of which would redo the reduction, while one finalize launch
     // serves all frames: fusing pays for max_batch <= 2 only - measured, profiles/r02_full_b1_reading.md)
-    const int fuse_batch = tune_env("THA4_FUSED_NORM_MAX_BATCH") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_BATCH")) : 2;
+    const int fuse_batch = fused_norm_max_batch();
     if (total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !tune_env("THA4_NO_SMALL_CONV") && !tune_env("THA4_NO_TILE_CONV") &&
         !exact_fp32) {
       Pending p;
       p.fused = true;
+      ++n_norm_tiles;
       for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].stats_off; p.tiles[i] = srcs[i].stats_tiles; }
       p.channels = channels; p.groups = groups; p.inv_count = 1.0f / (float)(srcs[0].h * srcs[0].w);
       p.gamma_off = g_off; p.beta_off = b_off; p.film0_off = film0_off; p.film1_off = film1_off; p.film1_stride = film1_stride;
       for (auto& o : out) o = p;
       return out;
+    }
+    // many tiles, but every source carries moment accumulators its producer fills with atomics: folded by the consumer from kMomentShards entries per channel
+    {
+      bool all_acc = srcs.size() <= 2 && max_batch <= fuse_batch && acc_planned() && !tune_env("THA4_NO_SMALL_CONV");
+      for (auto& t : srcs) all_acc = all_acc && t.acc_off != kNone;
+      if (all_acc) {
+        Pending p;
+        p.fused = true;
+        p.acc = true;
+        ++n_norm_acc;
+        for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].acc_off; p.tiles[i] = kMomentShards; }
+        p.channels = channels; p.groups = groups; p.inv_count = 1.0f / (float)(srcs[0].h * srcs[0].w);
+        p.gamma_off = g_off; p.beta_off = b_off; p.film0_off = film0_off; p.film1_off = film1_off; p.film1_stride = film1_stride;
+        for (auto& o : out) o = p;
+        return out;
+      }
+    }
+    ++n_norm_finalize;
+    if (std::getenv("THA4_DUMP_SCHEDULE")) {
+      std::fprintf(stderr, "norm finalize launch: channels=%d groups=%d sources:", channels, groups);
+      for (auto& t : srcs) std::fprintf(stderr, " [%dx%d cb=%d tiles=%d acc=%d]", t.h, t.w, t.cb, t.stats_tiles, (int)(t.acc_off != kNone));
+      std::fprintf(stderr, "\n");
     }
     for (size_t i = 0; i < srcs.size(); ++i) {
       out[i].scale_off = alloc_work((size_t)srcs[i].cb * 16);
@@ -718,7 +772,9 @@ class FullModel {
       a.film1 = film1_off == kNone ? nullptr : Wk(film1_off); a.film1_stride = film1_stride;
       a.fault = fault;
       const int ctot = cbt * 16;
-      a.cpb = tune_env("THA4_NORM_ONE_WG") ? ctot : norm_channels_per_block(ctot, channels, groups);
+      int max_tiles = 0;
+      for (auto& t : sv) max_tiles = std::max(max_tiles, t.stats_tiles);
+      a.cpb = tune_env("THA4_NORM_ONE_WG") ? ctot : norm_channels_per_block(ctot, channels, groups, tune_env("THA4_NORM_TILE_SPLIT") ? max_tiles : 0);
       const int S = std::max(1, kNormThreads / a.cpb);
       hipLaunchKernelGGL(norm_finalize_kernel, dim3(f.batch, (ctot + a.cpb - 1) / a.cpb), dim3(kNormThreads),
                          ((size_t)S * a.cpb * 2 + 2 * a.cpb) * sizeof(double), f.stream, a);
@@ -728,6 +784,10 @@ class FullModel {
   }
 
   FTensor affine_add(std::vector<Op>& ops, const FTensor& A, Pending pa, int act_a, const FTensor& B, Pending pb) {
+    if (pa.acc || pb.acc) {
+      if (error.empty()) error = "internal: affine_add does not read moment accumulators";
+      return FTensor();
+    }
     if (((pa.fused && pa.groups) || (pb.fused && pb.groups) || (A.px() * 4) % 256 != 0) && (pa.fused || pb.fused)) {
       if (error.empty()) error = "internal: affine_add supports fused InstanceNorm on maps of >= 64 pixels only";
       return FTensor();
@@ -1143,6 +1203,7 @@ class FullModel {
   std::vector<hipEvent_t> timing_events;
   bool timing_on = false, timing_recorded = false, timing_ran_decomposer = false;
   void run(const Frame& f, bool run_decomposer, const bool want_dec[6]) {
+    if (acc_floats) (void)hipMemsetAsync(dev_acc, 0, acc_floats * sizeof(float), f.stream);      // the moment accumulators of this call's producers
     if (timing_on && timing_events.size() == ops_decomposer.size() + ops_rest.size() + 2) return run_timed(f, run_decomposer, want_dec);
     if (run_decomposer)
       for (auto& op : ops_decomposer) op(f);

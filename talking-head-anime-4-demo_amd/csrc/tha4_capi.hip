@@ -544,6 +544,8 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
   if (e == hipSuccess) e = hipMemcpy(m.dev_params, m.host_params.data(), m.host_params.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&m.dev_work, m.work_floats * sizeof(float));
   if (e == hipSuccess) e = hipMemset(m.dev_work, 0, m.work_floats * sizeof(float));
+  if (e == hipSuccess && m.acc_floats) e = hipMalloc((void**)&m.dev_acc, m.acc_floats * sizeof(float));
+  if (e == hipSuccess && m.acc_floats) e = hipMemset(m.dev_acc, 0, m.acc_floats * sizeof(float));
   if (e == hipSuccess) e = FullModel::allow_all_conv_lds();
   if (e == hipSuccess) e = h->order.create();
   if (e == hipSuccess && m.side_planned()) e = h->create_side();
@@ -557,6 +559,7 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
     if (h->fault) (void)hipHostFree(h->fault);
     if (m.dev_params) (void)hipFree(m.dev_params);
     if (m.dev_work) (void)hipFree(m.dev_work);
+    if (m.dev_acc) (void)hipFree(m.dev_acc);
     delete h;
     return fail(THA4_ERR_HIP, std::string("tha4_full_create: ") + hipGetErrorString(e));
   }
@@ -716,6 +719,7 @@ void tha4_full_destroy(tha4_full* h) {
   if (h->fault) (void)hipHostFree(h->fault);
   if (h->model.dev_params) (void)hipFree(h->model.dev_params);
   if (h->model.dev_work) (void)hipFree(h->model.dev_work);
+  if (h->model.dev_acc) (void)hipFree(h->model.dev_acc);
   delete h;
 }
 

@@ -147,6 +147,10 @@ THA4_DEV int wave_take_ticket(int* lds_counter, int lane) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 THA4_DEV float lane_read(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+// device-scope 64-bit integer add without a returned value (global_atomic_add_x2): integer sums are independent of the order of arrival
+THA4_DEV void atomic_add_i64(long long* p, long long v) {
+  __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15 = the 16 pixels a lane group holds of one channel), left in every lane of
 // the row: four v_add_f32 with a row_ror DPP operand (rotations by 8, 4, 2, 1 - a fixed, direction-independent order).  Round 4:
 // the per-channel statistics of the convolution epilogues spent 8 ds_bpermute_b32 per value (128 LDS round trips per workgroup
@@ -166,6 +170,7 @@ THA4_DEV float row16_sum(float v, int) {
 // (lane t holds entry t) replaces a scalar memory load + s_waitcnt lgkmcnt(0) inside the MFMA loops
 THA4_DEV int lane_pick(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 #else
+THA4_DEV void atomic_add_i64(long long* p, long long v) { *p += v; }      // (the emulator runs the workgroups one after the other)
 THA4_DEV void glds16(const void* gsrc_lane, void* lds_base_uniform) { emu::glds16(gsrc_lane, lds_base_uniform); }
 THA4_DEV f32x4 mfma16(float a, float b, f32x4 c) {
   float r[4] = {c[0], c[1], c[2], c[3]};

@@ -72,9 +72,11 @@ namespace {
 // normalisation folded into the NEXT emu_conv call (FusedNorm): host pointers, consumed once
 struct FusedSpec {
   bool set = false;
+  bool acc = false;                  // stats[] are MomentAcc accumulators [n][kMomentShards][cb*16] (as long long quadruples), tiles[] = kMomentShards
   const float* stats[2]; int tiles[2]; int channels, groups; float inv_count;
   const float* gamma; const float* beta; const float* film0; const float* film1;
 } g_fused;
+long long* g_acc_out = nullptr;      // the NEXT emu_conv call (conv_tile_kernel) also fills moment accumulators [n][kMomentShards][nb*16][4] here
 }  // namespace
 
 static int g_remap_launches = 0;      // conv_tile launches that took the XCD-aware 1-D order (ConvArgs::xcd_remap)
@@ -94,6 +96,16 @@ void emu_set_fused_norm(const float* stats0, int tiles0, const float* stats1, in
   g_fused.channels = channels; g_fused.groups = groups; g_fused.inv_count = inv_count;
   g_fused.gamma = gamma; g_fused.beta = beta; g_fused.film0 = film0; g_fused.film1 = film1;
 }
+
+// the same with the producers' moment accumulators (round 5, full_kernels.h MomentAcc) in place of per-tile moments: acc0/1 [n][8][cb*16][4] int64
+void emu_set_fused_norm_acc(const long long* acc0, const long long* acc1, int channels, int groups, float inv_count,
+                            const float* gamma, const float* beta, const float* film0, const float* film1) {
+  emu_set_fused_norm(reinterpret_cast<const float*>(acc0), kMomentShards, reinterpret_cast<const float*>(acc1), acc1 ? kMomentShards : 0, channels, groups,
+                     inv_count, gamma, beta, film0, film1);
+  g_fused.acc = true;
+}
+// the next emu_conv call (a conv_tile_kernel case) adds its tiles' sums to `acc_out` [n][8][nb*16][4] (zeroed here)
+void emu_set_acc_output(long long* acc_out) { g_acc_out = acc_out; }
 
 // Generic convolution driver.  All tensors NCHW on the Python side; converted to C16 here.
 //  kind: 0 conv kxk stride 1 'same', 1 conv 4x4 stride 2 pad 1, 2 convT 4x4 stride 2 pad 1
@@ -160,6 +172,11 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   if (point && (kind != 0 || k != 1 || in_mode != IN_DIRECT || vec1)) return -6;
   const FusedSpec fused = g_fused;
   g_fused.set = false;
+  g_fused.acc = false;
+  long long* const acc_out = g_acc_out;
+  g_acc_out = nullptr;
+  std::vector<long long> ACC;
+  MomentAcc* dACC = nullptr;
   const size_t table_bytes = fused.set ? (size_t)2 * (cb0 + (c1 > 0 && !vec1 ? cb1 : 0)) * 16 * sizeof(float) : 0;
   SmallPlan sp0;
   if (small) {
@@ -178,6 +195,10 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   std::vector<float> ST((size_t)n * stats_tiles * nb * 16 * 2, 0.f);
   float *dX0 = M.up(X0), *dX1 = c1 > 0 ? M.up(X1) : nullptr, *dR = residual ? M.up(R) : nullptr, *dB = M.up(B), *dO = M.up(O), *dST = M.up(ST);
   int* dA = M.up(A);
+  if (acc_out) {
+    ACC.assign((size_t)n * kMomentShards * nb * 16 * 4, 0);
+    dACC = reinterpret_cast<MomentAcc*>(M.up(ACC));
+  }
   float *dsc0 = scale ? M.up(sc0) : nullptr, *dsh0 = scale ? M.up(sh0) : nullptr, *dsc1 = scale ? M.up(sc1) : nullptr, *dsh1 = scale ? M.up(sh1) : nullptr;
   std::vector<ChannelSegment> segs = {{0, c0}};
   if (c1 > 0) segs.push_back({c0, c1});
@@ -204,8 +225,10 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     if (fused.set) {
       FusedNorm& fn = a.fnorm;
       fn.enabled = 1;
-      fn.stats[0] = M.up(fused.stats[0], (size_t)n * fused.tiles[0] * cb0 * 16 * 2); fn.tiles[0] = fused.tiles[0];
-      fn.stats[1] = fused.stats[1] ? M.up(fused.stats[1], (size_t)n * fused.tiles[1] * cb1 * 16 * 2) : nullptr; fn.tiles[1] = fused.tiles[1];
+      const size_t per = fused.acc ? 8 : 2;              // floats per (tile | shard, channel): MomentAcc = 4 x int64
+      fn.acc = fused.acc ? 1 : 0;
+      fn.stats[0] = M.up(fused.stats[0], (size_t)n * fused.tiles[0] * cb0 * 16 * per); fn.tiles[0] = fused.tiles[0];
+      fn.stats[1] = fused.stats[1] ? M.up(fused.stats[1], (size_t)n * fused.tiles[1] * cb1 * 16 * per) : nullptr; fn.tiles[1] = fused.tiles[1];
       fn.channels = fused.channels; fn.groups = fused.groups; fn.inv_count = fused.inv_count; fn.eps = 1e-5f;
       fn.gamma = M.up(fused.gamma, (size_t)fused.channels); fn.beta = M.up(fused.beta, (size_t)fused.channels);
       fn.film0 = M.up(fused.film0, (size_t)2 * fused.channels); fn.film1 = M.up(fused.film1, (size_t)n * 2 * fused.channels);
@@ -220,12 +243,13 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     }
     a.in_h = h; a.in_w = w; a.in_mode = in_mode;
     a.ntaps = g.ntaps;
-    for (int t = 0; t < g.ntaps; ++t) { a.tap_dy[t] = g.dy[t]; a.tap_dx[t] = g.dx[t]; }
+    for (int t = 0; t < g.ntaps; ++t) { a.tap_dy[t] = (signed char)g.dy[t]; a.tap_dx[t] = (signed char)g.dx[t]; }
     a.in_stride = g.in_stride;
     a.tile_h = th; a.tile_w = tw; a.out_h = oh; a.out_w = ow;
     a.out_sy = g.out_sy; a.out_sx = g.out_sx; a.out_oy = g.out_oy; a.out_ox = g.out_ox;
     a.w = M.up(P); a.bias = bias ? dB : nullptr; a.residual = residual ? dR : nullptr; a.res_mode = IN_DIRECT;
     a.act_out = act_out ? dA : nullptr; a.out = dO; a.stats = dST;
+    a.stats_acc = (tiled || small) ? dACC : nullptr;
     a.stats_tiles = stats_tiles; a.stats_tile0 = cls * tiles_per_class;
     a.nb = nb; a.chunk_quads = chunk_quads; a.batch = n;
     a.nclass = grid_classes;
@@ -331,6 +355,11 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
   if (M.sync() != 0) return -9;
   M.down(O);
   M.down(ST);
+  if (acc_out) {
+    if (!tiled && !small) return -8;       // only conv_tile_kernel / conv_small_kernel feed the accumulators
+    M.down(ACC);
+    std::memcpy(acc_out, ACC.data(), ACC.size() * sizeof(long long));
+  }
   for (int i = 0; i < n; ++i) c16_to_nchw(O.data() + (size_t)i * nb * opx * 16, cout, opx, out + (size_t)i * cout * opx);
   if (stats_out)
     for (int i = 0; i < n; ++i)
@@ -380,7 +409,7 @@ int emu_norm(int n, int nsrc, const float* st0, int tiles0, int cb0, const float
   a.film0_stride = 2 * channels; a.film1_stride = 2 * channels;
   a.scale[0] = M.up(o0); a.shift[0] = M.up(h0); a.scale[1] = M.up(o1); a.shift[1] = M.up(h1);
   const int ctot = (cb0 + (nsrc > 1 ? cb1 : 0)) * 16;
-  a.cpb = norm_channels_per_block(ctot, channels, groups);
+  a.cpb = norm_channels_per_block(ctot, channels, groups, std::max(tiles0, nsrc > 1 ? tiles1 : 0));      // tile-aware split, like FullModel::norm
   const int S = std::max(1, kNormThreads / a.cpb);
   const size_t lds = ((size_t)S * a.cpb * 2 + 2 * a.cpb) * sizeof(double);
   THA4_RUN(norm_finalize_kernel, dim3(n, (ctot + a.cpb - 1) / a.cpb), kNormThreads, lds, a);

@@ -285,6 +285,27 @@ def test_norm_finalize_instance_and_group(lib):
     assert np.abs(got - ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("tiles", [1024, 1031, 300, 72])
+def test_norm_finalize_many_tiles_narrow_split(lib, tiles):
+    """Round 5: with many tiles per channel (a 512x512 map: 1024+) the finalize launch takes few channels per workgroup (down to one GroupNorm group, at
+    least 4) so that a thread walks about one round of eight tiles - main loop, conditional tail and the group reduction over a narrow range."""
+    rng = np.random.default_rng(tiles)
+    n, C_ = 1, 32
+    px = tiles * 4
+    x = (rng.standard_normal((n, C_, px)) * 1.5 + 0.3).astype(np.float32)
+    st, cb = _partials(x, tiles)
+    gamma = (1 + 0.2 * rng.standard_normal(C_)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C_)).astype(np.float32)
+    f1 = (0.3 * rng.standard_normal((n, 2 * C_))).astype(np.float32)
+    sc = np.zeros((n, cb * 16), np.float32); sh = np.zeros_like(sc)
+    lib.emu_norm(n, 1, P(st), tiles, cb, None, 0, 0, C_, 32, C.c_float(1.0 / px), C.c_float(1e-5), P(gamma), P(beta), None, P(f1), P(sc), P(sh), None, None)
+    h = F.group_norm(torch.from_numpy(x).double().reshape(n, C_, tiles, 4), 32, torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), eps=1e-5)
+    ft = torch.from_numpy(f1).double()
+    h = h * (1 + ft[:, :C_, None, None]) + ft[:, C_:, None, None]
+    got = x * sc[:, :C_, None] + sh[:, :C_, None]
+    assert np.abs(got - h.reshape(n, C_, px).numpy()).max() < 2e-5
+
+
 def test_gemv_and_attention(lib):
     rng = np.random.default_rng(9)
     n, rows, k = 2, 37, 256
@@ -514,6 +535,56 @@ def test_conv_with_fused_norm(lib, case):
                           extra if pg < 20 or pg >= 50 else (1 if pg >= 30 else 0))
     assert np.abs(out - ref).max() < 5e-5, np.abs(out - ref).max()
     assert np.abs(stats[..., 0] - ref.sum(axis=(2, 3))).max() < 2e-3
+
+
+def _acc_to_sums(acc):
+    """MomentAcc accumulators [n][8][cw][4] int64 (hi, lo) pairs -> per-channel sums [n][cw][2] (float64): value = hi + lo 2^-32, shards added"""
+    v = acc.astype(np.float64)
+    s = (v[..., 0] + v[..., 1] / 4294967296.0).sum(1)
+    q = (v[..., 2] + v[..., 3] / 4294967296.0).sum(1)
+    return np.stack([s, q], -1)
+
+
+@pytest.mark.parametrize("pg_prod,pg_cons,h,w,c0,c1,cmid", [(12, 12, 32, 32, 32, 0, 32), (54, 52, 32, 32, 16, 16, 64), (11, 14, 32, 32, 48, 0, 32), (22, 12, 16, 16, 64, 0, 32)])
+def test_moment_accumulators_producer_to_consumer(lib, pg_prod, pg_cons, h, w, c0, c1, cmid):
+    """Round 5: the producer convolution (conv_tile_kernel) adds its tiles' sums to per-channel integer accumulators with atomics and the CONSUMER folds
+    the 8 shards into its GroupNorm + FiLM + SiLU table - no norm_finalize launch.  (a) the accumulators hold the tensor's moments to ~2^-32 per tile sum
+    whatever the tiling; (b) the consumer (conv_tile_kernel, 8- and 4-wave forms; conv_small_kernel never gets one) reading them equals torch's norm -> act -> conv in fp64;
+    (c) the same bits as folding per-tile moments is NOT promised (different summation), the parity gate is."""
+    rng = np.random.default_rng(pg_prod * 100 + pg_cons)
+    n = 2
+    x0 = (rng.standard_normal((n, c0, h, w)) * 1.3).astype(np.float32)
+    x1 = (rng.standard_normal((n, c1, h, w)) * 0.7).astype(np.float32) if c1 else None
+    cin = c0 + c1
+    w1 = (rng.standard_normal((cmid, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b1 = rng.standard_normal(cmid).astype(np.float32)
+    nb = (cmid + 15) // 16
+    acc = np.zeros((n, 8, nb * 16, 4), np.int64)
+    lib.emu_set_acc_output(acc.ctypes.data_as(C.POINTER(C.c_longlong)))
+    tmb = 1 if 20 <= pg_prod < 30 else 2                     # (pg 2x: conv_small_kernel as the producer)
+    mid, stats = run_conv(lib, 0, 3, tmb, pg_prod, 0, "none", x0, x1, False, None, None, w1, b1, None, None, 1, 4, 0 if 20 <= pg_prod < 30 else 1)
+    sums = _acc_to_sums(acc)
+    mid64 = mid.astype(np.float64)
+    assert np.abs(sums[:, :cmid, 0] - mid64.sum(axis=(2, 3))).max() < 1e-3
+    assert np.abs(sums[:, :cmid, 1] - (mid64 ** 2).sum(axis=(2, 3))).max() < 3e-3
+    assert np.abs(sums[:, :cmid, 0] - stats[..., 0]).max() < 1e-3          # the per-tile moments are still written beside them
+    assert (acc[:, :, cmid:] == 0).all()                                    # padded channels: exact zeros
+    assert (acc != 0).any(axis=(0, 2, 3)).sum() >= min(8, 2)                # several shards were used
+    # consumer: GroupNorm(32 or 16) + FiLM + SiLU folded from the accumulators
+    groups = 16
+    gamma = (1 + 0.2 * rng.standard_normal(cmid)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(cmid)).astype(np.float32)
+    f0 = (0.3 * rng.standard_normal(2 * cmid)).astype(np.float32)
+    f1 = (0.3 * rng.standard_normal((n, 2 * cmid))).astype(np.float32)
+    cout = 32
+    w2 = (rng.standard_normal((cout, cmid, 3, 3)) / np.sqrt(cmid * 9)).astype(np.float32)
+    b2 = rng.standard_normal(cout).astype(np.float32)
+    hn = torch_act(_norm_ref(mid, cmid, groups, gamma, beta, f0, f1), "silu")
+    ref = F.conv2d(hn, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), padding=1).numpy()
+    lib.emu_set_fused_norm_acc(acc.ctypes.data_as(C.POINTER(C.c_longlong)), None, cmid, groups, C.c_float(1.0 / (h * w)), P(gamma), P(beta), P(f0), P(f1))
+    out, _ = run_conv(lib, 0, 3, 1 if 20 <= pg_cons < 30 else 2, pg_cons, 0, "silu", mid, None, False, None, None, w2, b2, None, None, 1, 4,
+                      1 if pg_cons < 20 or pg_cons >= 50 else 0)
+    assert np.abs(out - ref).max() < 5e-5, np.abs(out - ref).max()
 
 
 def test_small_conv_launch_plans(lib):

@@ -678,7 +678,7 @@ def test_per_op_timing_and_labels(poser1, full_io, golden_io):
     pose = torch.from_numpy(full_io["poses"][0]).to(dev)
     ref = poser1.pose(image, pose, image_changed=True).clone()
     info = poser1.op_info()
-    assert len(info) > 300 and not any(lbl == "(unlabelled)" for lbl, _ in info)
+    assert len(info) > 250 and not any(lbl == "(unlabelled)" for lbl, _ in info)       # (~278 since the moment accumulators replaced 54 finalize launches)
     conv_gflop = sum(g for lbl, g in info if lbl.startswith("conv"))
     print(f"sum of the convolution labels: {conv_gflop:.2f} GFLOP per cold frame")
     assert abs(conv_gflop - 645.4) < 0.02 * 645.4, conv_gflop           # 645.90 GFLOP cold incl. 0.4 of attention bmm + linears
@@ -692,7 +692,7 @@ def test_per_op_timing_and_labels(poser1, full_io, golden_io):
     assert len(ms_cold) == len(info) == len(ms_warm)
     assert all(m > 0 for m in ms_cold) and 2.0 < sum(ms_cold) < 60.0
     nd = sum(1 for m in ms_warm if m == 0.0)
-    assert 30 < nd < 80 and all(m == 0.0 for m in ms_warm[:nd]) and all(m > 0 for m in ms_warm[nd:])     # the decomposer ops were reused
+    assert 20 < nd < 80 and all(m == 0.0 for m in ms_warm[:nd]) and all(m > 0 for m in ms_warm[nd:])     # the decomposer ops were reused
     from tha4_amd import _capi
     with pytest.raises(_capi.Tha4Error, match="no timed pose call"):
         poser1.last_op_ms()
