@@ -53,7 +53,11 @@ struct Pending {           // transform a consumer applies while loading a tenso
   size_t scale_off = (size_t)-1, shift_off = (size_t)-1;   // workspace offsets of [n][cb*16] (written by norm_finalize_kernel)
   // ... or FUSED: no finalize launch; the consumer reduces the producer's per-tile moments itself (FusedNorm)
   bool fused = false;
-  bool acc = false;        // fused, from the producers' moment accumulators (stats_off[] are offsets in the accumulator arena, tiles[] = kMomentShards)
+  // ... from the producers' moment accumulators (round 5): `has_acc` - every source carries accumulators at acc_off[] (accumulator arena) besides its per-tile
+  // moments, the consumer takes whichever it can fold faster; `acc_only` - too many tiles for the per-tile route: the consumer must be a kernel that reads them
+  bool has_acc = false, acc_only = false;
+  size_t acc_off[2] = {0, 0};
+  int total_tiles = 0;
   size_t stats_off[2] = {0, 0};
   int tiles[2] = {0, 0};
   int channels = 0, groups = 0;
@@ -88,8 +92,9 @@ class FullModel {
   int* fault = nullptr;      // sticky numeric-fault flag (pinned host memory mapped into the device; set by the C ABI at create)
   void finalize_scratch() {
     if (std::getenv("THA4_DUMP_SCHEDULE"))
-      std::fprintf(stderr, "plan: %zu + %zu ops (decomposer + rest); normalisations: %d folded from per-tile moments, %d folded from moment accumulators, %d finalize launches; "
-                   "accumulator arena %zu KiB\n", ops_decomposer.size(), ops_rest.size(), n_norm_tiles, n_norm_acc, n_norm_finalize, acc_floats * sizeof(float) >> 10);
+      std::fprintf(stderr, "plan: %zu + %zu ops (decomposer + rest); normalisations: %d foldable from per-tile moments, %d from moment accumulators only, %d finalize launches; "
+                   "%d convolution launches fold accumulators; accumulator arena %zu KiB\n", ops_decomposer.size(), ops_rest.size(), n_norm_tiles, n_norm_acc, n_norm_finalize,
+                   n_conv_acc, acc_floats * sizeof(float) >> 10);
     while (info_decomposer.size() < ops_decomposer.size()) info_decomposer.push_back(OpInfo{"(unlabelled)", 0.0});
     while (info_rest.size() < ops_rest.size()) info_rest.push_back(OpInfo{"(unlabelled)", 0.0});
     partial_off = alloc_work(partial_floats);
@@ -120,9 +125,13 @@ class FullModel {
     return at;
   }
   MomentAcc* Acc(size_t off) const { return reinterpret_cast<MomentAcc*>(reinterpret_cast<float*>(dev_acc) + off); }
-  // Producer-side accumulation + consumer-side folding instead of a norm_finalize_kernel launch for tensors of more than THA4_FUSED_NORM_MAX_TILES tiles
-  // (round 5).  THA4_NO_MOMENT_ACC (tuning aid) restores the finalize launches.
-  bool acc_planned() const { return !exact_fp32 && !tune_env("THA4_NO_MOMENT_ACC") && !tune_env("THA4_NO_TILE_CONV"); }
+  // Producer-side accumulation + consumer-side folding instead of a norm_finalize_kernel launch (round 5).  MEASURED NEUTRAL TO NEGATIVE, off unless
+  // THA4_TUNING + THA4_MOMENT_ACC are set (parity-clean: the GPU suite passes with it on): replacing the 54 finalize launches of a batch-1 frame (tensors of
+  // more than 64 tiles) is +0.5 % / +-0.0 % on two boxes (profiles/r05_raw/c6_ab_moment_acc.txt, c7_ab_moment_acc.txt: 184.2 vs 183.3, 185.4 vs 185.4 frames/s) -
+  // every consumer workgroup now folds its own table (8 shards x 4 int64 per channel, fp64 arithmetic, two barriers: ~2-3 us on a single-round grid's critical
+  // path) where ONE 5.5 us launch did it for all of them, plus a memset of the arena per call; extending it to the 17-64-tile tensors (THA4_ACC_MIN_TILES=16:
+  // one load round instead of 3-8) costs 2.8 % (180.2 vs 185.4): 128-256 more device-scope atomics in the epilogue of every producer and a 6.7 MB arena to zero.
+  bool acc_planned() const { return !exact_fp32 && tune_env("THA4_MOMENT_ACC") && !tune_env("THA4_NO_TILE_CONV"); }
   template <class T = float> const T* P(size_t off) const { return reinterpret_cast<const T*>(dev_params + off); }
   float* Wk(size_t off) const { return reinterpret_cast<float*>(dev_work) + off; }
 
@@ -440,13 +449,13 @@ class FullModel {
       // the tile plan would split over two launches, not the 16-tap stride-2 convolutions (their 108-pixel window per 16
       // outputs makes staging dominate) and not average-pooled inputs (four dependent samples per staged item)
       bool want = kind == K_SAME1 ? tile_px <= max1x1 : (!tiled || plan.ksplit > 1);
-      if (fpend && fpend->acc) want = false;                // conv_small_kernel folds per-tile moments only (a tensor with accumulators has many tiles: never a small map)
+      if (fpend && fpend->acc_only) want = false;           // conv_small_kernel folds per-tile moments only (a tensor that NEEDS the accumulators has > 64 tiles: never a small map)
       if (!tune_env("THA4_SMALL_ALL_KINDS") && (kind == K_S2K4 || in_mode == IN_POOL2)) want = false;
       if (want && !tune_env("THA4_NO_SMALL_CONV")) {
         sp = plan_small_conv(g0, th, tw, nb, nq, 256, max_batch);
         small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
       }
-      if (!small && fpend && !fpend->acc && !tiled && !tune_env("THA4_NO_SMALL_CONV")) {
+      if (!small && fpend && !fpend->acc_only && !tiled && !tune_env("THA4_NO_SMALL_CONV")) {
         // a folded normalisation needs one of the two kernels that can evaluate it: take conv_small_kernel even if its grid
         // runs in several rounds (1x1 projections behind a GroupNorm when the schedule is built for 2 frames)
         sp = plan_small_conv(g0, th, tw, nb, nq, 1 << 30, max_batch);
@@ -500,9 +509,9 @@ class FullModel {
     if (want_stats) {
       out.stats_tiles = tiles * nclass;
       out.stats_off = alloc_work((size_t)out.stats_tiles * nb * 16 * 2);
-      // tensors with many tiles on handles built for one or two frames: the producer (conv_tile_kernel / conv_small_kernel) also feeds the moment accumulators, so that
-      // norm() needs no finalize launch (below).  Few tiles: the consumer folds the per-tile moments themselves, as before
-      if ((tiled || small) && acc_planned() && out.stats_tiles > fused_norm_max_tiles() && max_batch <= fused_norm_max_batch())
+      // tensors of more than a handful of tiles on handles built for one or two frames: the producer (conv_tile_kernel / conv_small_kernel) also feeds the moment
+      // accumulators, so that norm() needs no finalize launch and the consumer one round of loads (below).  Few tiles: the consumer folds the per-tile moments, as before
+      if ((tiled || small) && acc_planned() && out.stats_tiles > acc_min_tiles() / 2 && max_batch <= fused_norm_max_batch())
         out.acc_off = alloc_acc((size_t)kMomentShards * nb * 16 * (sizeof(MomentAcc) / sizeof(float)));
     }
     size_t bias_off = kNone;
@@ -613,6 +622,9 @@ class FullModel {
       }
       std::vector<Src> sv = srcs;
       const Pending fp = fpend ? *fpend : Pending();
+      // which moments the consumer folds: the accumulators when it must (too many tiles for the per-tile route) or when it can and they are fewer loads
+      const bool use_acc = fpend && (fpend->acc_only || (fpend->has_acc && !small && fpend->total_tiles > acc_min_tiles()));
+      if (fpend && use_acc) ++n_conv_acc;
       const FTensor outc = out;
       const bool has_res = residual != nullptr;
       const FTensor resc = has_res ? *residual : FTensor();
@@ -631,10 +643,10 @@ class FullModel {
           FusedNorm& fn = c.fnorm;
           fn.enabled = 1;
           for (int i = 0; i < 2; ++i) {
-            fn.stats[i] = !fp.tiles[i] ? nullptr : fp.acc ? reinterpret_cast<const float*>(Acc(fp.stats_off[i])) : Wk(fp.stats_off[i]);
-            fn.tiles[i] = fp.tiles[i];
+            fn.stats[i] = !fp.tiles[i] ? nullptr : use_acc ? reinterpret_cast<const float*>(Acc(fp.acc_off[i])) : Wk(fp.stats_off[i]);
+            fn.tiles[i] = !fp.tiles[i] ? 0 : use_acc ? kMomentShards : fp.tiles[i];
           }
-          fn.acc = fp.acc ? 1 : 0;
+          fn.acc = use_acc ? 1 : 0;
           fn.channels = fp.channels; fn.groups = fp.groups; fn.inv_count = fp.inv_count; fn.eps = 1e-5f;
           fn.gamma = P(fp.gamma_off); fn.beta = P(fp.beta_off);
           fn.film0 = fp.film0_off == kNone ? nullptr : P(fp.film0_off);
@@ -699,7 +711,10 @@ class FullModel {
     return out;
   }
 
-  int n_norm_finalize = 0, n_norm_tiles = 0, n_norm_acc = 0;      // normalisations by route (THA4_DUMP_SCHEDULE prints them)
+  int n_norm_finalize = 0, n_norm_tiles = 0, n_norm_acc = 0, n_conv_acc = 0;      // normalisations by route (THA4_DUMP_SCHEDULE prints them)
+  // a normalisation over more than this many tiles (all sources together) is folded from the moment accumulators when every source has them: the per-tile
+  // route reads 8 tiles per dependent round (17-64 tiles: 3-8 rounds), the accumulators are one round whatever the tile count
+  static int acc_min_tiles() { return tune_env("THA4_ACC_MIN_TILES") ? std::atoi(tune_env("THA4_ACC_MIN_TILES")) : 64; }
   static int fused_norm_max_tiles() { return tune_env("THA4_FUSED_NORM_MAX_TILES") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_TILES")) : 64; }
   static int fused_norm_max_batch() { return tune_env("THA4_FUSED_NORM_MAX_BATCH") ? std::atoi(tune_env("THA4_FUSED_NORM_MAX_BATCH")) : 2; }
   // Normalisation finalize over up to two concatenated tensors; returns the pending transform per source.
@@ -716,32 +731,28 @@ class FullModel {
     // (a batched call multiplies the consumers' workgroups, each of which would redo the reduction, while one finalize launch
     // serves all frames: fusing pays for max_batch <= 2 only - measured, profiles/r02_full_b1_reading.md)
     const int fuse_batch = fused_norm_max_batch();
-    if (total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !tune_env("THA4_NO_SMALL_CONV") && !tune_env("THA4_NO_TILE_CONV") &&
-        !exact_fp32) {
+    bool all_acc = srcs.size() <= 2 && max_batch <= fuse_batch && acc_planned() && !tune_env("THA4_NO_SMALL_CONV");
+    for (auto& t : srcs) all_acc = all_acc && t.acc_off != kNone;
+    const bool per_tile_ok = total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !tune_env("THA4_NO_SMALL_CONV") && !tune_env("THA4_NO_TILE_CONV") &&
+                             !exact_fp32;
+    // folded by the consumer: from the per-tile moments (few tiles), from the moment accumulators its producers fill with atomics (kMomentShards entries per
+    // channel: one round of loads whatever the tile count, no finalize launch), or - 17 to 64 tiles with accumulators - from whichever the consuming kernel reads
+    // faster (conv_small_kernel folds per-tile moments only; FullModel::conv decides)
+    if (per_tile_ok || all_acc) {
       Pending p;
       p.fused = true;
-      ++n_norm_tiles;
-      for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].stats_off; p.tiles[i] = srcs[i].stats_tiles; }
+      p.has_acc = all_acc;
+      p.acc_only = all_acc && !per_tile_ok;
+      p.total_tiles = total_tiles;
+      if (p.acc_only) ++n_norm_acc; else ++n_norm_tiles;
+      for (size_t i = 0; i < srcs.size(); ++i) {
+        p.stats_off[i] = srcs[i].stats_off; p.tiles[i] = srcs[i].stats_tiles;
+        p.acc_off[i] = all_acc ? srcs[i].acc_off : 0;
+      }
       p.channels = channels; p.groups = groups; p.inv_count = 1.0f / (float)(srcs[0].h * srcs[0].w);
       p.gamma_off = g_off; p.beta_off = b_off; p.film0_off = film0_off; p.film1_off = film1_off; p.film1_stride = film1_stride;
       for (auto& o : out) o = p;
       return out;
-    }
-    // many tiles, but every source carries moment accumulators its producer fills with atomics: folded by the consumer from kMomentShards entries per channel
-    {
-      bool all_acc = srcs.size() <= 2 && max_batch <= fuse_batch && acc_planned() && !tune_env("THA4_NO_SMALL_CONV");
-      for (auto& t : srcs) all_acc = all_acc && t.acc_off != kNone;
-      if (all_acc) {
-        Pending p;
-        p.fused = true;
-        p.acc = true;
-        ++n_norm_acc;
-        for (size_t i = 0; i < srcs.size(); ++i) { p.stats_off[i] = srcs[i].acc_off; p.tiles[i] = kMomentShards; }
-        p.channels = channels; p.groups = groups; p.inv_count = 1.0f / (float)(srcs[0].h * srcs[0].w);
-        p.gamma_off = g_off; p.beta_off = b_off; p.film0_off = film0_off; p.film1_off = film1_off; p.film1_stride = film1_stride;
-        for (auto& o : out) o = p;
-        return out;
-      }
     }
     ++n_norm_finalize;
     if (std::getenv("THA4_DUMP_SCHEDULE")) {
@@ -784,7 +795,7 @@ class FullModel {
   }
 
   FTensor affine_add(std::vector<Op>& ops, const FTensor& A, Pending pa, int act_a, const FTensor& B, Pending pb) {
-    if (pa.acc || pb.acc) {
+    if (pa.acc_only || pb.acc_only) {
       if (error.empty()) error = "internal: affine_add does not read moment accumulators";
       return FTensor();
     }

@@ -48,3 +48,22 @@ def test_warp_blend_tail_borders_on_device(lib, size):
 
 def test_upscaler_input_on_device(lib):
     T.test_upscaler_input_bilinear_edges_and_warp(lib)
+
+
+# ---- round 5 -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pg_prod,pg_cons,h,w,c0,c1,cmid", [(12, 12, 32, 32, 32, 0, 32), (54, 52, 32, 32, 16, 16, 64), (11, 14, 32, 32, 48, 0, 32), (22, 12, 16, 16, 64, 0, 32)])
+def test_moment_accumulators_on_device(lib, pg_prod, pg_cons, h, w, c0, c1, cmid):
+    """The producers' integer-atomic moment accumulators and the consumer folding them (a tuning-only plan option: measured neutral, csrc/full_net.h
+    acc_planned) with the REAL device atomics: the workgroups of the producing launch arrive in any order, the sums must not depend on it."""
+    T.test_moment_accumulators_producer_to_consumer(lib, pg_prod, pg_cons, h, w, c0, c1, cmid)
+
+
+@pytest.mark.parametrize("tiles", [1024, 1031, 72])
+def test_norm_finalize_many_tiles_on_device(lib, tiles):
+    T.test_norm_finalize_many_tiles_narrow_split(lib, tiles)
+
+
+def test_xcd_aware_order_on_device(lib):
+    """conv_tile_kernel on the 1-D XCD-aware grid (ConvArgs::xcd_remap) - the three remap cases are also members of T.CASES; here the launch counter
+    proves the device harness took the remapped grid for them."""
+    T.test_xcd_aware_order_is_taken_where_the_product_takes_it(lib)
