@@ -665,6 +665,7 @@ def student_extras(args, work, dev, world, fps, K, W, B):
             out["full_model"] = measure_full_b1(fw, dev, args.full_frames)
             fw.steady = True
             out["full_model"]["roofline"] = full_roofline(out["full_model"]["steady"]["fps"], GFLOP_FULL_STEADY, cold=False, batch1=True, work=fw)
+            out["full_model"]["two_frames_in_flight"] = measure_full_two_in_flight(dev, args.full_frames, fw)
             fw.poser.free()
             # the strict-precision number next to it: the same frames on the exact-fp32 plan (THA4_FULL_EXACT_FP32: every convolution on
             # v_mfma_f32_16x16x4_f32 with fp32 operands - no 22-bit operand split to argue about)
@@ -678,7 +679,6 @@ def student_extras(args, work, dev, world, fps, K, W, B):
                 ex[k].pop("frac_of_split_ceiling", None)
             ex["what"] = f"the same workload on the exact-fp32 plan (tha4_full_create_ex flags = THA4_FULL_EXACT_FP32), {nx} frames each"
             out["full_model"]["exact_fp32"] = ex
-            out["full_model"]["two_frames_in_flight"] = measure_full_two_in_flight(dev, args.full_frames)
         except Exception as e:
             out["full_model"] = {"error": repr(e)}
     if single and args.batched_steps > 0:
@@ -734,12 +734,13 @@ def measure_full_b1(fw, dev, frames):
     return res
 
 
-def measure_full_two_in_flight(dev, frames):
+def measure_full_two_in_flight(dev, frames, first):
     """NOT the configs[2] number (that is one pose() after the other on one stream): the same batch-1 frames through TWO handles on two
     streams, frame i on stream i % 2 - what a throughput caller (offline rendering, a second character) gets from a chip that a single
     batch-1 frame leaves latency-bound (a frame is a chain of ~320 dependent launches).  Host-side only: no kernel differs."""
     try:
-        works = [FullWork(dev, 0, 1, frames + 3, steady=True) for _ in range(2)]
+        first.steady = True
+        works = [first, FullWork(dev, 0, 1, frames + 3, steady=True)]          # (`first`: the handle of the configs[2] measurement - one weight pack less)
         streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
         with torch.no_grad():
             for k in range(2):
@@ -753,8 +754,7 @@ def measure_full_two_in_flight(dev, frames):
                     works[i % 2].step(3 + i)
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
-        for wk in works:
-            wk.poser.free()
+        works[1].poser.free()
         f = frames / dt
         return {"fps": round(f, 2), "frames": frames, "achieved_tflops": round(f * GFLOP_FULL_STEADY / 1e3, 2),
                 "what": "steady batch-1 frames alternating over two handles on two streams (two independent frames in flight); "

@@ -68,7 +68,7 @@ def _worker(rank, world, port, total, chunk, q):
         if rank == 0:
             gb = (world - 1) * n_per * 4 * 512 * 512 * 4 / 1e9
             print(f"[rccl gather] world {world}: {(world - 1) * n_per} remote fp32 frames ({gb:.2f} GB) into rank 0 in {dt * 1e3:.2f} ms = "
-                  f"{gb / dt:.1f} GB/s root ingest, {gb / dt / (world - 1):.1f} GB/s per sender", flush=True)
+                  f"{gb / dt:.1f} GB/s root ingest, {gb / dt / max(1, world - 1):.1f} GB/s per sender", flush=True)
             os.makedirs("gpurun_out", exist_ok=True)
             with open(f"gpurun_out/rccl_gather_rate_world{world}.txt", "a") as fh:
                 fh.write(f"world {world} remote_frames {(world - 1) * n_per} GB {gb:.3f} seconds {dt:.6f} root_ingest_GBps {gb / dt:.2f}\n")
