@@ -74,6 +74,10 @@ VARIANTS = {
     "no_bias_ahead": ["-DTHA4_BIAS_AHEAD=0"],                      # student streamed layers: scale + biases requested in the epilogue (behind the next chunk's fetch)
     "small_epi_late": ["-DTHA4_SMALL_PREFETCH_EPI(PG,POOL)=0"],    # conv_small_kernel: bias + activation codes requested after the partial-sum exchange (still together)
     "prio": ["-DTHA4_PHASE_PRIO=1"],     # s_setprio 1 in the VALU phases (sine / staging epilogues), 0 in the MFMA phases
+    # round 5 (profiles/r05_boundaries_reading.md, r05_full_b1_reading.md; the run-time switches of the round are environment variables read under THA4_TUNING=1,
+    # A/B them with tools/ab_full.py name=default@THA4_TUNING=1,VAR=1: THA4_SIDE_STREAM, THA4_MOMENT_ACC [+ THA4_ACC_MIN_TILES=16], THA4_NO_XCD_REMAP, THA4_NORM_TILE_SPLIT)
+    "identity_pixels": ["-DTHA4_IDENTITY_PIXELS=1"],               # pixel = MFMA column in the convolution windows (rounds 2-4: 22-30 % LDS bank-conflict cycles)
+    "norm8": ["-DTHA4_NORM_LOADS_IN_FLIGHT=8"],                    # norm_finalize_kernel with eight moment loads in flight (measured -0.5 %)
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["THA4_SWEEP_VARIANTS"].split(",")}
