@@ -481,6 +481,17 @@ class FullModel {
       const long min_wgs = tune_env("THA4_TILE_NW4_MIN_WGS") ? std::atol(tune_env("THA4_TILE_NW4_MIN_WGS")) : (max_batch == 1 ? 512 : 2 * 512);
       if (nw4 && (long)tiles4 * mtiles * max_batch < min_wgs) nw4 = false;
     }
+    // 1x1 convolutions on SMALL maps of a batched plan (round 5): conv_small_kernel refuses grids of several rounds, and these 32 launches of a batch-8 step
+    // (qkv / attention projections / skips at 16x16 and 32x32) used to fall back to the exact-fp32 conv_splitk_kernel (2 % of the step): with the frames of the
+    // batch there are enough pixel tiles for conv_point_kernel
+    if (!point && !small && !tiled && kind == K_SAME1 && in_mode == IN_DIRECT && !exact_fp32 && !tune_env("THA4_NO_POINT_CONV") && !tune_env("THA4_NO_POINT_SMALL_MAPS") &&
+        (!residual || res_mode == IN_DIRECT) && point_act_supported(act_in) && tile_px % 64 == 0) {
+      bool tensors = true;
+      for (auto& sx : srcs) tensors = tensors && !sx.vector;
+      pp = plan_point_conv(tile_px, nb, cbtot, max_batch, fpend != nullptr);
+      point = tensors && pp.ok;
+      if (point) { tmb = pp.tmb; mtiles = nb / tmb; }
+    }
     // fallbacks (1x1 convolutions): small maps (<= 32x32) one pixel group per workgroup with K split over its 4 waves
     // (conv_splitk_kernel), otherwise the exact-fp32 pixel-tiled kernel (conv_mfma_kernel)
     const bool splitk = !small && !tiled && !point && tile_px <= 1024 && tmb == 4 && cbtot * ntaps_k >= 8;
