@@ -625,8 +625,8 @@ __global__ void __launch_bounds__(NS* MS * 64) level2_16_kernel(StudentDev d) {
 // barrier.  Because a wave owns whole rows here, the k-slot permutation (see "Images" above) makes the C/D rows a
 // lane holds exactly its B fragment of the next layer: the activations never leave the wave's registers, LDS
 // carries weights only, and one A fragment read feeds PG pixel groups.
-template <int PG>
-THA4_DEV void put_rows(f16x8 (&xh)[kKG2][PG], f16x8 (&xl)[kKG2][PG], int pg, int b, const f32x4& v) {
+template <int KG, int PG>
+THA4_DEV void put_rows(f16x8 (&xh)[KG][PG], f16x8 (&xl)[KG][PG], int pg, int b, const f32x4& v) {
   f16x4 hi, lo;
   split4(v, hi, lo);
 #pragma unroll
@@ -634,6 +634,20 @@ THA4_DEV void put_rows(f16x8 (&xh)[kKG2][PG], f16x8 (&xl)[kKG2][PG], int pg, int
     xh[b >> 1][pg][(b & 1) * 4 + j] = hi[j];
     xl[b >> 1][pg][(b & 1) * 4 + j] = lo[j];
   }
+}
+
+// The optimiser SINKS pure per-value work (tap FMAs, sine, split) down to its first use: in the fully unrolled register-resident kernels that is
+// a later chunk's first MFMA of that K group - every tap load's result (or every accumulator of the previous layer) then stays live across the
+// chunks in between (level1_16r_kernel: 256 VGPRs + 158 AGPRs instead of ~180).  An empty volatile asm that "modifies" the finished rows pins the
+// layer's epilogue where it is written.
+template <int KG, int PG>
+THA4_DEV void pin_rows(f16x8 (&xh)[KG][PG], f16x8 (&xl)[KG][PG]) {
+#ifndef THA4_EMU
+#pragma unroll
+  for (int q = 0; q < KG; ++q)
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) asm volatile("" : "+v"(xh[q][pg]), "+v"(xl[q][pg]));
+#endif
 }
 
 // (Round 4, measured negative: the layer biases / scales of the weights-resident level 2 copied to LDS once per workgroup instead of three dependent
@@ -752,7 +766,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
     f16x8 xh[kKG2][PG], xl[kKG2][PG];
     THA4_PRIO_VALU();
     first16_up_to<G, kNB2>(d.z2 + (size_t)n * kNB2 * (256 * 256) * 16, 256, d.wx[3], d.wy[3], THA4_PB_FOLD ? pb : d.pbias + (size_t)n * kPbStride + kPbL2, X0, Y, px, py,
-                           [&](int pg, int b, const f32x4& v) { put_rows<PG>(xh, xl, pg, b, v); }, w);
+                           [&](int pg, int b, const f32x4& v) { put_rows<kKG2, PG>(xh, xl, pg, b, v); }, w);
     const float* bias = d.b_l2;
 #pragma unroll
     for (int layer = 0; layer < 2; ++layer) {
@@ -770,7 +784,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(acc[b][pg][j], inv, bb[j]));
-          put_rows<PG>(xh, xl, pg, b, v);
+          put_rows<kKG2, PG>(xh, xl, pg, b, v);
         }
       }
       bias += kNB2 * 16;
@@ -781,6 +795,496 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
     mma_resident<1, kKG2, PG>(w3, xh, xl, a1);
     THA4_PRIO_VALU();
     warp_blend_store<PG>(d, n, bias, d.s_l2[2], pix0, px, py, a1, w);
+  }
+}
+
+
+// ---- level 1, activations-in-registers variant (round 6) ------------------------------------------------
+// level1_16_kernel re-streams the level's 252 KiB of weight pieces for every 64-pixel workgroup (1024 workgroups: 258 MB of L2 -> LDS
+// traffic per frame) through a TWO-slot ring: one 12-KiB chunk in flight per workgroup, a barrier per chunk, and a round trip of every
+// activation through LDS per layer (store_block + a B-fragment read per chunk).  Here a wave owns whole rows (MS = 1) of PG pixel
+// groups, exactly like the weights-resident level 2: the k-slot permutation makes the C/D rows a lane holds its B fragment of the next
+// layer, so the activations never leave the wave's registers (192-channel layers: 48 accumulator + 48 operand VGPRs per pixel group),
+// LDS carries NOTHING but the weight ring - SLOTS x 24 KiB, SLOTS - 1 chunks in flight behind counted `s_waitcnt vmcnt` - and one
+// pass over the stream serves WAVES x PG x 16 pixels (8 x 2 x 16 = 256: one image row per workgroup, 256 workgroups per frame, 65 MB
+// of stream).  The stream is eleven 24-KiB chunks: six K groups x 12 blocks of the 180 -> 180 layer, three pairs of K groups x 6
+// blocks of the 180 -> 90 layer, and the z layer's three K groups x 6 blocks as {0, 1}, {2, padding}.
+// Biases and the pose-folded first-layer bias sit in LDS: no global load is issued between the first chunk's barrier and the z stores,
+// so the counted waits see ring copies only.
+// geometry of the kernels whose activations live in registers: a wave = a pixel slot that owns whole rows; no activation image in LDS
+template <int WAVES_, int PG_>
+struct GeoRegs {
+  static constexpr int NS = WAVES_, MS = 1, PG = PG_, ACTQ = 0;
+  static constexpr int WAVES = WAVES_, THREADS = WAVES_ * 64, PX = WAVES_ * PG_ * 16;
+};
+
+template <int WAVES, int PG, int SLOTS>
+struct Level1RCfg {
+  static constexpr int kChunkPieces = 12, kChunk = kChunkPieces * 2048;
+  static constexpr int kChunksA = kKG1, kChunksB = kKG1 / 2, kChunksZ = (kKG2 + 1) / 2;
+  static constexpr int kChunks = kChunksA + kChunksB + kChunksZ;                      // 11
+  static constexpr int kStreamPieces = kChunks * kChunkPieces;                        // 132 (126 + 6 of padding)
+  static constexpr int kCPW = 2 * kChunkPieces / WAVES;                               // 1-KiB copies per wave and chunk
+  static constexpr int kDepth = SLOTS - 1;                                            // chunks in flight
+  static constexpr int kPre = 2;                                                      // chunks requested before the first layer (the rest behind its tap loads)
+  static constexpr int kRing = SLOTS * kChunk;
+  static constexpr int kPbOff = kRing, kBiasOff = kPbOff + 3 * kNB1 * 16 * 4;         // floats: pb[192] | wx[192] | wy[192] | bias A[192] | bias B[96] | 1/S of the three layers (+ 1 pad)
+  static constexpr int kBiasFloats = (kNB1 + kNB2) * 16;
+  static constexpr int LDS = kBiasOff + (kBiasFloats + 4) * 4;
+  static constexpr int THREADS = WAVES * 64, PX = WAVES * PG * 16;
+  using G = GeoRegs<WAVES, PG>;
+  static_assert((2 * kChunkPieces) % WAVES == 0, "every wave must issue the same number of copies per chunk (counted waits)");
+  static_assert(kDepth >= kPre && kDepth * kCPW <= 16, "THA4_BARRIER_KEEP counts up to 16 copies");
+  static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
+  static_assert((256 * 256) % PX == 0, "a frame must be a whole number of workgroups");
+};
+
+// acc[b][pg] += W' x for one landed chunk: pieces [qq < CQ][NBC blocks] at wv (lane offset applied), x K groups Q0 .. Q0 + CQ - 1 in registers
+#ifndef THA4_REGS_GROUP_BLOCKS
+#define THA4_REGS_GROUP_BLOCKS 0     // blocks whose A fragments (hi + lo) are double-buffered in registers; 0: 2 for two pixel groups / wide layers, 3 otherwise
+#endif
+// (Q0, B0: first K group of x / first accumulator block of the chunk - constants once the chunk sequence is unrolled)
+template <int NBC, int CQ, int KG, int PG, int NBT>
+THA4_DEV void mma_chunk_regs(const char* wv, const f16x8 (&xh)[KG][PG], const f16x8 (&xl)[KG][PG], f32x4 (&acc)[NBT][PG], const int Q0, const int B0) {
+  constexpr int GB = NBC == 1 ? 1 : THA4_REGS_GROUP_BLOCKS ? THA4_REGS_GROUP_BLOCKS : ((PG >= 2 || KG * PG > 8) ? 2 : (NBC % 3 == 0 ? 3 : 2)), NGB = NBC / GB, T = CQ * NGB;
+  static_assert(NBC % GB == 0, "the block group must divide the chunk's blocks");
+  f16x8 ah[2][GB], al[2][GB];
+#pragma unroll
+  for (int b = 0; b < GB; ++b) {
+    ah[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048);
+    al[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048 + 1024);
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int qq = t / NGB, bo = B0 + (t % NGB) * GB;
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], xh[Q0 + qq][pg], acc[bo + b][pg]);
+    THA4_SCHED_FENCE();
+    if (t + 1 < T) {
+#pragma unroll
+      for (int b = 0; b < GB; ++b) {
+        const char* pc = wv + ((size_t)((t + 1) / NGB) * NBC + ((t + 1) % NGB) * GB + b) * 2048;
+        ah[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc);
+        al[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc + 1024);
+      }
+    }
+    THA4_SCHED_FENCE();
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], xl[Q0 + qq][pg], acc[bo + b][pg]);
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(al[t & 1][b], xh[Q0 + qq][pg], acc[bo + b][pg]);
+    THA4_SCHED_FENCE();
+  }
+}
+
+
+// First layer of a register-resident level (level1_16r_kernel): the x2-upsample taps of ALL pixel groups of the wave as one sequence of
+// batches of TB blocks (4 tap loads each), TWO batches in flight.  first16_up_to keeps two BLOCKS in flight - right for 16 waves per CU, but a
+// wave that owns whole rows of two pixel groups walks 24 dependent round trips to the z image that way (level 1: ~15 us of a 33-us launch).
+// wx, wy, pb: LDS copies.
+#ifndef THA4_TAP_BATCH
+#define THA4_TAP_BATCH 4
+#endif
+template <class G, int NB, int TB, class Sink>
+THA4_DEV void first16_up_batched(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb, const int (&X0)[G::PG], const int (&Y)[G::PG],
+                                 const float (&x)[G::PG], const float (&y)[G::PG], Sink&& sink, const WaveCtx& w) {
+  constexpr int PG = G::PG, KB = NB / TB, STEPS = PG * KB;
+  static_assert(NB % TB == 0, "the tap batch must divide the layer's blocks");
+  const int p = w.lane & 15, g4 = (w.lane >> 4) * 4;
+  const int npix = lowS * lowS;
+  unsigned o00[PG], o01[PG], o10[PG], o11[PG];
+  float w00[PG], w01[PG], w10[PG], w11[PG];
+#pragma unroll
+  for (int pg = 0; pg < PG; ++pg) {
+    int x0, x1, y0, y1;
+    float lx0, lx1, ly0, ly1;
+    up2_taps(X0[pg] + p, lowS, x0, x1, lx0, lx1);
+    up2_taps(Y[pg], lowS, y0, y1, ly0, ly1);
+    w00[pg] = ly0 * lx0; w01[pg] = ly0 * lx1; w10[pg] = ly1 * lx0; w11[pg] = ly1 * lx1;
+    o00[pg] = (unsigned)(z_offset(0, w.lane >> 4, y0 * lowS + x0, npix) * sizeof(float));
+    o01[pg] = (unsigned)(z_offset(0, w.lane >> 4, y0 * lowS + x1, npix) * sizeof(float));
+    o10[pg] = (unsigned)(z_offset(0, w.lane >> 4, y1 * lowS + x0, npix) * sizeof(float));
+    o11[pg] = (unsigned)(z_offset(0, w.lane >> 4, y1 * lowS + x1, npix) * sizeof(float));
+  }
+  struct Batch { f32x4 a[TB], bq[TB], c[TB], d[TB]; };
+  auto request = [&](int s) -> Batch {
+    const int pg = s / KB, b0 = (s % KB) * TB;
+    Batch t;
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const char* zb = reinterpret_cast<const char*>(zframe) + (size_t)(b0 + i) * npix * 16 * sizeof(float);      // wave-uniform
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      t.a[i] = THA4_HOOK_ZLOAD(zb + o00[pg], zero);
+      t.bq[i] = THA4_HOOK_ZLOAD(zb + o01[pg], zero);
+      t.c[i] = THA4_HOOK_ZLOAD(zb + o10[pg], zero);
+      t.d[i] = THA4_HOOK_ZLOAD(zb + o11[pg], zero);
+    }
+    return t;
+  };
+  auto consume = [&](int s, const Batch& t) {
+    const int pg = s / KB, b0 = (s % KB) * TB;
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int b = b0 + i;
+      const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
+      const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j]));                            // z and tables carry the sine's scale
+        v[j] = sin_u(fmaf(w00[pg], t.a[i][j], fmaf(w01[pg], t.bq[i][j], fmaf(w10[pg], t.c[i][j], fmaf(w11[pg], t.d[i][j], u)))));
+      }
+      sink(pg, b, v);
+    }
+  };
+  Batch cur = request(0);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    Batch nxt = cur;
+    if (s + 1 < STEPS) nxt = request(s + 1);
+    THA4_SCHED_FENCE();
+    consume(s, cur);
+    THA4_SCHED_FENCE();
+    cur = nxt;
+  }
+}
+
+template <int WAVES, int PG, int SLOTS>
+__global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
+  using Cfg = Level1RCfg<WAVES, PG, SLOTS>;
+  using G = typename Cfg::G;
+  constexpr int S = 256, NPIX = S * S, NC = Cfg::kChunks, DEPTH = Cfg::kDepth, CPW = Cfg::kCPW;
+  THA4_DYN_LDS(smem);
+  const WaveCtx w = wave_ctx<G>();
+  const char* gw = reinterpret_cast<const char*>(d.w_l1);
+  auto fetch = [&](int c) { fetch_pieces<2 * Cfg::kChunkPieces, WAVES>(gw + (size_t)c * Cfg::kChunk, smem + (c % SLOTS) * Cfg::kChunk, w.wave, w.lane); };
+#pragma unroll
+  for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos256, pix0, X0, Y, px, py);
+  float* pb = reinterpret_cast<float*>(smem + Cfg::kPbOff);
+  float* bias_lds = reinterpret_cast<float*>(smem + Cfg::kBiasOff);
+  pose_bias_to_lds<kNB1, WAVES * 64>(d, 2, n, pb);
+  for (int c = threadIdx.x; c < Cfg::kBiasFloats + 3; c += WAVES * 64) bias_lds[c] = c < Cfg::kBiasFloats ? d.b_l1[c] : d.s_l1[c - Cfg::kBiasFloats];
+  for (int c = threadIdx.x; c < 2 * kNB1 * 16; c += WAVES * 64) pb[kNB1 * 16 + c] = c < kNB1 * 16 ? d.wx[2][c] : d.wy[2][c - kNB1 * 16];
+  __syncthreads();                                             // (drains vmcnt: chunks 0 .. kPre - 1 have landed for every wave)
+  const int g4 = (w.lane >> 4) * 4;
+  f16x8 xh[kKG1][PG], xl[kKG1][PG];
+  THA4_PRIO_VALU();
+  first16_up_batched<G, kNB1, THA4_TAP_BATCH>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, pb + kNB1 * 16, pb + 2 * kNB1 * 16, pb, X0, Y, px, py,
+                                              [&](int pg, int b, const f32x4& v) { put_rows<kKG1, PG>(xh, xl, pg, b, v); }, w);
+  pin_rows<kKG1, PG>(xh, xl);
+  THA4_PRIO_MFMA();
+#pragma unroll
+  for (int c = Cfg::kPre; c < DEPTH; ++c) fetch(c);            // younger than every tap load: the taps' waits do not cover them
+  const char* ring = smem + w.lane * 16;
+  // chunk c: it has landed (for this wave: everything but the (chunks requested after it) x CPW newest copies; for the others: the barrier),
+  // and every wave is done with chunk c - 1, whose slot chunk c + DEPTH goes into
+#define THA4_L1R_CHUNK_TOP(c)                                                                  \
+  do {                                                                                         \
+    constexpr int newer_ = ((c) + DEPTH - 1 < NC - 1 ? (c) + DEPTH - 1 : NC - 1) - (c);        \
+    THA4_BARRIER_KEEP(newer_ * CPW);                                                           \
+    if ((c) + DEPTH < NC) fetch((c) + DEPTH);                                                  \
+  } while (0)
+  const float* scl = bias_lds + Cfg::kBiasFloats;              // (from LDS: a global load here would sit behind the ring copies in the in-order vmcnt queue)
+  {   // 180 -> 180, sine
+    f32x4 acc[kNB1][PG];
+    zero_acc<kNB1, PG>(acc);
+    THA4_L1R_CHUNK_TOP(0); mma_chunk_regs<kNB1, 1>(ring + (0 % SLOTS) * Cfg::kChunk, xh, xl, acc, 0, 0);
+    THA4_L1R_CHUNK_TOP(1); mma_chunk_regs<kNB1, 1>(ring + (1 % SLOTS) * Cfg::kChunk, xh, xl, acc, 1, 0);
+    THA4_L1R_CHUNK_TOP(2); mma_chunk_regs<kNB1, 1>(ring + (2 % SLOTS) * Cfg::kChunk, xh, xl, acc, 2, 0);
+    THA4_L1R_CHUNK_TOP(3); mma_chunk_regs<kNB1, 1>(ring + (3 % SLOTS) * Cfg::kChunk, xh, xl, acc, 3, 0);
+    THA4_L1R_CHUNK_TOP(4); mma_chunk_regs<kNB1, 1>(ring + (4 % SLOTS) * Cfg::kChunk, xh, xl, acc, 4, 0);
+    THA4_L1R_CHUNK_TOP(5); mma_chunk_regs<kNB1, 1>(ring + (5 % SLOTS) * Cfg::kChunk, xh, xl, acc, 5, 0);
+    THA4_PRIO_VALU();
+    const float inv = scl[0];
+#pragma unroll
+    for (int b = 0; b < kNB1; ++b) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + b * 16 + g4);
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(acc[b][pg][j], inv, bb[j]));
+        put_rows<kKG1, PG>(xh, xl, pg, b, v);
+      }
+    }
+    pin_rows<kKG1, PG>(xh, xl);
+    THA4_PRIO_MFMA();
+  }
+  f16x8 yh[kKG2][PG], yl[kKG2][PG];
+  {   // 180 -> 90, sine
+    f32x4 acc[kNB2][PG];
+    zero_acc<kNB2, PG>(acc);
+    THA4_L1R_CHUNK_TOP(6); mma_chunk_regs<kNB2, 2>(ring + (6 % SLOTS) * Cfg::kChunk, xh, xl, acc, 0, 0);
+    THA4_L1R_CHUNK_TOP(7); mma_chunk_regs<kNB2, 2>(ring + (7 % SLOTS) * Cfg::kChunk, xh, xl, acc, 2, 0);
+    THA4_L1R_CHUNK_TOP(8); mma_chunk_regs<kNB2, 2>(ring + (8 % SLOTS) * Cfg::kChunk, xh, xl, acc, 4, 0);
+    THA4_PRIO_VALU();
+    const float inv = scl[1];
+#pragma unroll
+    for (int b = 0; b < kNB2; ++b) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + (kNB1 + b) * 16 + g4);
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(acc[b][pg][j], inv, bb[j]));
+        put_rows<kKG2, PG>(yh, yl, pg, b, v);
+      }
+    }
+    pin_rows<kKG2, PG>(yh, yl);
+    THA4_PRIO_MFMA();
+  }
+  {   // z2 = c W20[:, :90] h1 (fp32) -> global z[n][b][g][pix][4]; the consumer is level 2's first (sine) layer
+    f32x4 acc[kNB2][PG];
+    zero_acc<kNB2, PG>(acc);
+    THA4_L1R_CHUNK_TOP(9); mma_chunk_regs<kNB2, 2>(ring + (9 % SLOTS) * Cfg::kChunk, yh, yl, acc, 0, 0);
+    THA4_L1R_CHUNK_TOP(10); mma_chunk_regs<kNB2, 1>(ring + (10 % SLOTS) * Cfg::kChunk, yh, yl, acc, 2, 0);
+    const float inv = scl[2];
+    float* zframe = d.z2 + (size_t)n * kNB2 * NPIX * 16;
+    const int p = w.lane & 15;
+#pragma unroll
+    for (int b = 0; b < kNB2; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(zframe + z_offset(b, 0, 0, NPIX)) +
+                                  (unsigned)(z_offset(0, w.lane >> 4, pix0[pg] + p, NPIX) * sizeof(float))) = acc[b][pg] * inv;
+  }
+#undef THA4_L1R_CHUNK_TOP
+}
+
+
+// ---- face + level 0 with the activations in registers (round 6) -------------------------------------------------------
+// front16_kernel at batch 1: 16 waves per 64-pixel workgroup, rows split over four waves per pixel slot, activations through LDS, 42 (level 0) /
+// 8 (face) chunk barriers with ONE chunk in flight - neither the matrix pipe (ablation: -1.6 us without MFMAs) nor the L2 -> LDS path
+// (tools/microbench/lds_stream.hip: 115 GB/s per CU against the 30 it draws) bounds it; the serial chain barrier -> fragment reads -> 9 MFMAs
+// -> barrier does.  Here a workgroup is FOUR waves, each owning whole rows of one pixel group (level 0: 96 operand + 96 accumulator VGPRs),
+// LDS carries the weight ring only (<= 80 KiB), so TWO workgroups share a CU: the grid is [level-0 workgroups | face workgroups] and the
+// dispatcher's breadth-first placement (tools/microbench/tg_id_probe.hip: workgroups b and b + 256 of a 512-workgroup grid share a CU) gives
+// every SIMD one level-0 wave (1512 MFMAs) and one face wave (684) that never synchronise with each other.
+template <int WAVES, int SLOTS, int CHUNK_PIECES>
+struct RingRegs {
+  static constexpr int kChunk = CHUNK_PIECES * 2048, kDepth = SLOTS - 1, kCPW = 2 * CHUNK_PIECES / WAVES, kBytes = SLOTS * kChunk;
+  static_assert((2 * CHUNK_PIECES) % WAVES == 0, "every wave must issue the same number of copies per chunk (counted waits)");
+  static_assert(kDepth * kCPW <= 16, "THA4_BARRIER_KEEP counts up to 16 copies");
+  const char* gw;
+  char* base;
+  int wave, lane;
+  THA4_DEV void fetch(int c) const { fetch_pieces<2 * CHUNK_PIECES, WAVES>(gw + (size_t)c * kChunk, base + (c % SLOTS) * kChunk, wave, lane); }
+  // chunk c of nc has landed for every wave and every wave is done with chunk c - 1; then chunk c + kDepth is requested into that slot
+  THA4_DEV void top(int c, int nc) const {
+    const int last = c + kDepth - 1 < nc - 1 ? c + kDepth - 1 : nc - 1;
+    THA4_BARRIER_KEEP((last - c) * kCPW);
+    if (c + kDepth < nc) fetch(c + kDepth);
+  }
+  THA4_DEV const char* at(int c) const { return base + (c % SLOTS) * kChunk + lane * 16; }
+};
+
+// one linear layer, x in registers: chunks of ONE K group x NBC output blocks, chunk index c0 + q (NB / NBC) + h
+template <int NB, int KG, int NBC, class Ring, int KGX, int PG>
+THA4_DEV void layer_regs(const Ring& ring, int c0, int nc, const f16x8 (&xh)[KGX][PG], const f16x8 (&xl)[KGX][PG], f32x4 (&acc)[NB][PG]) {
+  static_assert(NB % NBC == 0 && KG <= KGX, "bad chunking");
+#pragma unroll
+  for (int q = 0; q < KG; ++q)
+#pragma unroll
+    for (int h = 0; h < NB / NBC; ++h) {
+      const int c = c0 + q * (NB / NBC) + h;
+      ring.top(c, nc);
+      mma_chunk_regs<NBC, 1>(ring.at(c), xh, xl, acc, q, h * NBC);
+    }
+}
+
+// sine epilogue of a register-resident layer: x <- split(sin(acc / S + c b)), biases and 1/S from LDS
+template <int NB, int KG, int PG>
+THA4_DEV void sine_regs(const f32x4 (&acc)[NB][PG], const float* bias_lds, float inv, int g4, f16x8 (&xh)[KG][PG], f16x8 (&xl)[KG][PG]) {
+  THA4_PRIO_VALU();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + b * 16 + g4);
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(acc[b][pg][j], inv, bb[j]));
+      put_rows<KG, PG>(xh, xl, pg, b, v);
+    }
+  }
+  pin_rows<KG, PG>(xh, xl);
+  THA4_PRIO_MFMA();
+}
+
+// (wx, wy, pb: LDS copies - 2 x NB global loads per wave here would either all be in flight at once (4 VGPRs each) or serialise into NB round trips)
+template <class G, int NB, class Sink>
+THA4_DEV void first16_pos_to(const float* wx, const float* wy, const float* pb, const float (&x)[G::PG], const float (&y)[G::PG], Sink&& sink, const WaveCtx& w) {
+  constexpr int PG = G::PG;
+  const int g4 = (w.lane >> 4) * 4;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const f32x4 vx = *reinterpret_cast<const f32x4*>(wx + b * 16 + g4);
+    const f32x4 vy = *reinterpret_cast<const f32x4*>(wy + b * 16 + g4);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + b * 16 + g4);
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = sin_u(fmaf(vx[j], x[pg], fmaf(vy[j], y[pg], vb[j])));     // tables carry the sine's scale
+      sink(pg, b, v);
+    }
+  }
+}
+
+template <int NBC0, int SLOTS0, int SLOTSF>
+struct FrontRCfg {
+  static constexpr int WAVES = 4, PG = 1, THREADS = WAVES * 64, PX = WAVES * PG * 16;
+  using G = GeoRegs<WAVES, PG>;
+  // level 0: 360 -> 360 -> 180 (sine), then z1; chunks of one K group x NBC0 blocks
+  using Ring0 = RingRegs<WAVES, SLOTS0, NBC0>;
+  static constexpr int kChunksA = kKG0 * (kNB0 / NBC0), kChunksB = kKG0 * (kNB1 / NBC0), kChunksZ = kKG1 * (kNB1 / NBC0);
+  static constexpr int kChunks0 = kChunksA + kChunksB + kChunksZ;
+  static constexpr int kBias0 = (kNB0 + kNB1) * 16;                                            // floats: bias A | bias B, then 1/S x 3 (+ pad)
+  static constexpr int kPb0Off = Ring0::kBytes, kBias0Off = kPb0Off + 3 * kNB0 * 16 * 4, kLds0 = kBias0Off + (kBias0 + 4) * 4;     // pb | wx | wy, then the biases
+  // face: 7 x (128 -> 128, sine) + head 128 -> 4; chunks of one K group x 8 blocks (16 KiB), the head's 4 pieces padded to one chunk
+  using RingF = RingRegs<WAVES, SLOTSF, kNBF>;
+  static constexpr int kChunksF = 7 * kKGF + 1;
+  static constexpr int kStreamPiecesF = kChunksF * kNBF;                                      // 232 (228 + 4 of padding)
+  static constexpr int kBiasF = 7 * kNBF * 16 + 16;                                            // floats: 7 sine layers | head, then 1/S x 8
+  static constexpr int kPbFOff = RingF::kBytes, kBiasFOff = kPbFOff + 3 * kNBF * 16 * 4, kLdsF = kBiasFOff + (kBiasF + 8) * 4;
+  static constexpr int LDS = kLds0 > kLdsF ? kLds0 : kLdsF;
+  static_assert(LDS <= 80 * 1024, "two workgroups must share a CU");
+  static_assert(kNB0 % NBC0 == 0 && kNB1 % NBC0 == 0, "a chunk must be a whole number of blocks of every level-0 layer");
+};
+
+template <class Cfg>
+THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w) {
+  using G = typename Cfg::G;
+  using Ring = typename Cfg::Ring0;
+  constexpr int PG = Cfg::PG, S = 128, NPIX = S * S, NC = Cfg::kChunks0;
+  const Ring ring{reinterpret_cast<const char*>(d.w_l0), smem, w.wave, w.lane};
+  constexpr int PRE = Ring::kDepth < 2 ? Ring::kDepth : 2;
+#pragma unroll
+  for (int c = 0; c < PRE; ++c) ring.fetch(c);
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
+  float* pb = reinterpret_cast<float*>(smem + Cfg::kPb0Off);
+  float* bias_lds = reinterpret_cast<float*>(smem + Cfg::kBias0Off);
+  pose_bias_to_lds<kNB0, Cfg::THREADS>(d, 1, n, pb);
+  for (int c = threadIdx.x; c < Cfg::kBias0 + 3; c += Cfg::THREADS) bias_lds[c] = c < Cfg::kBias0 ? d.b_l0[c] : d.s_l0[c - Cfg::kBias0];
+  for (int c = threadIdx.x; c < 2 * kNB0 * 16; c += Cfg::THREADS) pb[kNB0 * 16 + c] = c < kNB0 * 16 ? d.wx[1][c] : d.wy[1][c - kNB0 * 16];
+  __syncthreads();                                             // (drains vmcnt: the first PRE chunks have landed for every wave)
+  const int g4 = (w.lane >> 4) * 4;
+  const float* scl = bias_lds + Cfg::kBias0;
+  f16x8 xh[kKG0][PG], xl[kKG0][PG];
+  THA4_PRIO_VALU();
+  first16_pos_to<G, kNB0>(pb + kNB0 * 16, pb + 2 * kNB0 * 16, pb, px, py, [&](int pg, int b, const f32x4& v) { put_rows<kKG0, PG>(xh, xl, pg, b, v); }, w);
+  pin_rows<kKG0, PG>(xh, xl);
+  THA4_PRIO_MFMA();
+#pragma unroll
+  for (int c = PRE; c < Ring::kDepth; ++c) ring.fetch(c);      // younger than the first layer's table loads: their waits do not cover these
+  {   // 360 -> 360, sine
+    f32x4 acc[kNB0][PG];
+    zero_acc<kNB0, PG>(acc);
+    layer_regs<kNB0, kKG0, Cfg::Ring0::kChunk / 2048>(ring, 0, NC, xh, xl, acc);
+    sine_regs<kNB0, kKG0, PG>(acc, bias_lds, scl[0], g4, xh, xl);
+  }
+  f16x8 yh[kKG1][PG], yl[kKG1][PG];
+  {   // 360 -> 180, sine
+    f32x4 acc[kNB1][PG];
+    zero_acc<kNB1, PG>(acc);
+    layer_regs<kNB1, kKG0, Cfg::Ring0::kChunk / 2048>(ring, Cfg::kChunksA, NC, xh, xl, acc);
+    sine_regs<kNB1, kKG1, PG>(acc, bias_lds + kNB0 * 16, scl[1], g4, yh, yl);
+  }
+  {   // z1 = c W10[:, :180] h0 (fp32) -> global z[n][b][g][pix][4]; the consumer is level 1's first (sine) layer
+    f32x4 acc[kNB1][PG];
+    zero_acc<kNB1, PG>(acc);
+    layer_regs<kNB1, kKG1, Cfg::Ring0::kChunk / 2048>(ring, Cfg::kChunksA + Cfg::kChunksB, NC, yh, yl, acc);
+    const float inv = scl[2];
+    float* zframe = d.z1 + (size_t)n * kNB1 * NPIX * 16;
+    const int p = w.lane & 15;
+#pragma unroll
+    for (int b = 0; b < kNB1; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(zframe + z_offset(b, 0, 0, NPIX)) +
+                                  (unsigned)(z_offset(0, w.lane >> 4, pix0[pg] + p, NPIX) * sizeof(float))) = acc[b][pg] * inv;
+  }
+}
+
+template <class Cfg>
+THA4_DEV void face_regs_body(const StudentDev& d, char* smem, const WaveCtx& w) {
+  using G = typename Cfg::G;
+  using Ring = typename Cfg::RingF;
+  constexpr int PG = Cfg::PG, S = kFaceSize, NPIX = S * S, NC = Cfg::kChunksF;
+  const Ring ring{reinterpret_cast<const char*>(d.w_face), smem, w.wave, w.lane};
+  constexpr int PRE = Ring::kDepth < 2 ? Ring::kDepth : 2;
+#pragma unroll
+  for (int c = 0; c < PRE; ++c) ring.fetch(c);
+  int pix0[PG], X0[PG], Y[PG];
+  float px[PG], py[PG];
+  const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
+  float* pb = reinterpret_cast<float*>(smem + Cfg::kPbFOff);
+  float* bias_lds = reinterpret_cast<float*>(smem + Cfg::kBiasFOff);
+  pose_bias_to_lds<kNBF, Cfg::THREADS>(d, 0, n, pb);
+  for (int c = threadIdx.x; c < Cfg::kBiasF + 8; c += Cfg::THREADS) bias_lds[c] = c < Cfg::kBiasF ? d.b_face[c] : d.s_face[c - Cfg::kBiasF];
+  for (int c = threadIdx.x; c < 2 * kNBF * 16; c += Cfg::THREADS) pb[kNBF * 16 + c] = c < kNBF * 16 ? d.wx[0][c] : d.wy[0][c - kNBF * 16];
+  __syncthreads();
+  const int g4 = (w.lane >> 4) * 4;
+  const float* scl = bias_lds + Cfg::kBiasF;
+  f16x8 xh[kKGF][PG], xl[kKGF][PG];
+  THA4_PRIO_VALU();
+  first16_pos_to<G, kNBF>(pb + kNBF * 16, pb + 2 * kNBF * 16, pb, px, py, [&](int pg, int b, const f32x4& v) { put_rows<kKGF, PG>(xh, xl, pg, b, v); }, w);
+  pin_rows<kKGF, PG>(xh, xl);
+  THA4_PRIO_MFMA();
+#pragma unroll
+  for (int c = PRE; c < Ring::kDepth; ++c) ring.fetch(c);
+#pragma unroll
+  for (int l = 0; l < 7; ++l) {
+    f32x4 acc[kNBF][PG];
+    zero_acc<kNBF, PG>(acc);
+    layer_regs<kNBF, kKGF, kNBF>(ring, l * kKGF, NC, xh, xl, acc);
+    sine_regs<kNBF, kKGF, PG>(acc, bias_lds + l * kNBF * 16, scl[l], g4, xh, xl);
+  }
+  // head: ONE block x 4 K groups = the first 4 pieces of the last chunk; rows 0..3 (the image channels) live in lane group 0
+  f32x4 a1[1][PG];
+  zero_acc<1, PG>(a1);
+  ring.top(NC - 1, NC);
+  mma_chunk_regs<1, kKGF>(ring.at(NC - 1), xh, xl, a1, 0, 0);
+  if (w.lane < 16) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + 7 * kNBF * 16);
+    const float inv = scl[7];
+    float* fo = d.face + (size_t)n * 4 * NPIX;
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      const f32x4 v = a1[0][pg] * inv + bb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fo[(size_t)j * NPIX + pix0[pg] + w.lane] = v[j];
+    }
+  }
+}
+
+template <int NBC0, int SLOTS0, int SLOTSF>
+__global__ void __launch_bounds__(256, 2) front16r_kernel(StudentDev d) {
+  warm_kernarg<(int)sizeof(StudentDev)>();
+  using Cfg = FrontRCfg<NBC0, SLOTS0, SLOTSF>;
+  THA4_DYN_LDS(smem);
+  WaveCtx w = wave_ctx<typename Cfg::G>();
+  const int nl0 = d.front_l0_blocks;
+  if ((int)blockIdx.x < nl0) {
+    w.nblk = nl0;
+    level0_regs_body<Cfg>(d, smem, w);
+  } else {
+    w.blk = blockIdx.x - nl0;
+    w.nblk = gridDim.x - nl0;
+    face_regs_body<Cfg>(d, smem, w);
   }
 }
 
@@ -824,16 +1328,34 @@ namespace cfg {
 #ifndef THA4_L2_RESIDENT
 #define THA4_L2_RESIDENT 1                  // 1: level2_16p_kernel, 0: streamed level2_16_kernel
 #endif
+#ifndef THA4_L1_REGS
+#define THA4_L1_REGS 1                      // 1: level1_16r_kernel (activations in registers, LDS = weight ring only; round 6), 0: level1_16_kernel
+#endif
+#ifndef THA4_FRONT_REGS
+#define THA4_FRONT_REGS 1                   // 1: front16r_kernel (face + level 0, activations in registers, two 4-wave workgroups per CU; round 6), 0: front16_kernel
+#endif
+#ifndef THA4_FRONT16R_CFG
+#define THA4_FRONT16R_CFG 12, 3, 4          // level-0 blocks per chunk (12: 24 KiB, 6: 12 KiB), level-0 ring slots, face ring slots (16 KiB)
+#endif
+#ifndef THA4_L116R_CFG
+#define THA4_L116R_CFG 8, 2, 6              // WAVES, pixel groups per wave, ring slots of 24 KiB
+#endif
 using L2P = Level2PCfg<THA4_L216P_CFG>;
 #define THA4_L216P_KERNEL v2::level2_16p_kernel<THA4_L216P_CFG>
 using FaceG = Face16Cfg<THA4_FACE16_CFG>::G;
 using L0G = Level016Cfg<THA4_L016_CFG>::G;
 using L1G = Level116Cfg<THA4_L116_CFG>::G;
 using L2G = Level216Cfg<THA4_L216_CFG>::G;
-constexpr int kL0HBA = Level016Cfg<THA4_L016_CFG>::kP1 == kNB0 ? 1 : kNB0 / Level016Cfg<THA4_L016_CFG>::kP1;
-constexpr int kL0HBB = Level016Cfg<THA4_L016_CFG>::kHBB;
-constexpr int kL1HBA = Level116Cfg<THA4_L116_CFG>::kHBA, kL1HBB = Level116Cfg<THA4_L116_CFG>::kHBB;
-constexpr int kFaceMS = FaceG::MS, kL0MS = L0G::MS, kL1MS = L1G::MS, kL2MS = L2G::MS;
+using FrontR = FrontRCfg<THA4_FRONT16R_CFG>;
+#define THA4_FRONT16R_KERNEL v2::front16r_kernel<THA4_FRONT16R_CFG>
+constexpr int kL0HBA = THA4_FRONT_REGS ? 1 : (Level016Cfg<THA4_L016_CFG>::kP1 == kNB0 ? 1 : kNB0 / Level016Cfg<THA4_L016_CFG>::kP1);
+constexpr int kL0HBB = THA4_FRONT_REGS ? 1 : Level016Cfg<THA4_L016_CFG>::kHBB;
+using L1R = Level1RCfg<THA4_L116R_CFG>;
+#define THA4_L116R_KERNEL v2::level1_16r_kernel<THA4_L116R_CFG>
+// (the register form reads whole K groups in block order: no row split, no block slices; its stream ends with 6 pieces of padding)
+constexpr int kL1HBA = THA4_L1_REGS ? 1 : Level116Cfg<THA4_L116_CFG>::kHBA, kL1HBB = THA4_L1_REGS ? 1 : Level116Cfg<THA4_L116_CFG>::kHBB;
+constexpr int kFaceMS = THA4_FRONT_REGS ? 1 : FaceG::MS, kL0MS = THA4_FRONT_REGS ? 1 : L0G::MS, kL1MS = THA4_L1_REGS ? 1 : L1G::MS, kL2MS = L2G::MS;
+constexpr int kL1Px = THA4_L1_REGS ? L1R::PX : L1G::PX, kL1Threads = THA4_L1_REGS ? L1R::THREADS : L1G::THREADS;
 #define THA4_FACE16_KERNEL v2::face16_kernel<THA4_FACE16_CFG>
 #define THA4_FRONT16_KERNEL v2::front16_kernel<THA4_FACE16_CFG, THA4_L016_CFG>
 #ifndef THA4_FRONT_MERGE
@@ -847,7 +1369,9 @@ constexpr int blocks_for(int batch, int side) { return batch * (side * side) / G
 // dynamic LDS of each launch.  The streamed kernels park their pose-folded bias vector in ring slot 1 (idle until the first
 // streamed layer prefetches into it); the weights-resident level 2 has no ring and appends it.
 constexpr int kFrontLds = FaceG::LDS > L0G::LDS ? FaceG::LDS : L0G::LDS;
-constexpr int kFaceLds = FaceG::LDS, kL0Lds = L0G::LDS, kL1Lds = L1G::LDS, kL2Lds = L2G::LDS, kL2PLds = L2P::LDS + pb_lds_bytes(kNB2);
+constexpr int kFrontRLds = FrontR::LDS;
+constexpr int kFrontPx = THA4_FRONT_REGS ? FrontR::PX : L0G::PX;          // pixels per workgroup of both nets in the front launch
+constexpr int kFaceLds = FaceG::LDS, kL0Lds = L0G::LDS, kL1Lds = L1G::LDS, kL1RLds = L1R::LDS, kL2Lds = L2G::LDS, kL2PLds = L2P::LDS + pb_lds_bytes(kNB2);
 static_assert(pb_lds_bytes(kNB0) <= L0G::SLOT && pb_lds_bytes(kNBF) <= FaceG::SLOT && pb_lds_bytes(kNB1) <= L1G::SLOT && pb_lds_bytes(kNB2) <= L2G::SLOT,
               "the bias vector must fit a ring slot");
 
@@ -900,12 +1424,14 @@ inline void pack_student16(const StudentWeightsView& v, const StudentPacked& p1,
   constexpr float W30 = kSineScale16;          // omega_0 in the unit the sine takes: turns (default) or radians
   for (int i = 1; i < 8; ++i) p.s_face.push_back(pack_layer16(v.face_sine[i].weight, kCF, 0, kCF, kCF, kNBF, kKGF, cfg::kFaceMS, 1, W30, p.w_face));
   p.s_face.push_back(pack_layer16(v.face_last.weight, kCF, 0, 4, kCF, 1, kKGF, 1, 1, 1.0f, p.w_face));
+  if (THA4_FRONT_REGS) p.w_face.resize((size_t)cfg::FrontR::kStreamPiecesF * 2048, 0);      // front16r_kernel's last chunk is the head's 4 pieces + padding
   p.s_l0.push_back(pack_layer16(v.body_sine[0][1].weight, kC0, 0, kC0, kC0, kNB0, kKG0, cfg::kL0MS, cfg::kL0HBA, W30, p.w_l0));
   p.s_l0.push_back(pack_layer16(v.body_sine[0][2].weight, kC0, 0, kC1, kC0, kNB1, kKG0, cfg::kL0MS, cfg::kL0HBB, W30, p.w_l0));
   p.s_l0.push_back(pack_layer16(v.body_sine[1][0].weight, kC1 + 2 + kPose, 0, kC1, kC1, kNB1, kKG1, cfg::kL0MS, 1, W30, p.w_l0));
   p.s_l1.push_back(pack_layer16(v.body_sine[1][1].weight, kC1, 0, kC1, kC1, kNB1, kKG1, cfg::kL1MS, cfg::kL1HBA, W30, p.w_l1));
   p.s_l1.push_back(pack_layer16(v.body_sine[1][2].weight, kC1, 0, kC2, kC1, kNB2, kKG1, cfg::kL1MS, cfg::kL1HBB, W30, p.w_l1));
   p.s_l1.push_back(pack_layer16(v.body_sine[2][0].weight, kC2 + 2 + kPose, 0, kC2, kC2, kNB2, kKG2, cfg::kL1MS, 1, W30, p.w_l1));
+  if (THA4_L1_REGS) p.w_l1.resize((size_t)cfg::L1R::kStreamPieces * 2048, 0);     // level1_16r_kernel's last chunk is K group 2 of the z layer + padding
   p.s_l2.push_back(pack_layer16(v.body_sine[2][1].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, W30, p.w_l2));
   p.s_l2.push_back(pack_layer16(v.body_sine[2][2].weight, kC2, 0, kC2, kC2, kNB2, kKG2, 1, 1, W30, p.w_l2));
   p.s_l2.push_back(pack_layer16(v.body_last.weight, kC2, 0, kHeadC, kC2, 1, kKG2, 1, 1, 1.0f, p.w_l2));

@@ -199,7 +199,7 @@ THA4_DEV void fetch_pieces(const char* g, char* l, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < (PIECES + WAVES - 1) / WAVES; ++i) {
     const int pc = i * WAVES + wave;
-    THA4_HOOK_FETCH(if (pc < PIECES) glds16(g + pc * 1024 + (unsigned)(lane * 16), l + pc * 1024));
+    THA4_HOOK_FETCH(if (PIECES % WAVES == 0 || pc < PIECES) glds16(g + pc * 1024 + (unsigned)(lane * 16), l + pc * 1024));      // (no branch on the wave id where every wave copies)
   }
 }
 

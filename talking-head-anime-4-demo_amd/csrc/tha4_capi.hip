@@ -262,9 +262,11 @@ int tha4_student_create_ex(const tha4_student_weights* weights, const tha4_posit
   if (e == hipSuccess) e = allow_lds(THA4_L1_KERNEL, cfg::L1G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_L2_KERNEL, cfg::L2G::LDS);
   if (e == hipSuccess) e = allow_lds(THA4_FRONT16_KERNEL, v2::cfg::kFrontLds);
+  if (e == hipSuccess) e = allow_lds(THA4_FRONT16R_KERNEL, v2::cfg::kFrontRLds);
   if (e == hipSuccess) e = allow_lds(THA4_FACE16_KERNEL, v2::cfg::kFaceLds);
   if (e == hipSuccess) e = allow_lds(THA4_L016_KERNEL, v2::cfg::kL0Lds);
   if (e == hipSuccess) e = allow_lds(THA4_L116_KERNEL, v2::cfg::kL1Lds);
+  if (e == hipSuccess) e = allow_lds(THA4_L116R_KERNEL, v2::cfg::kL1RLds);
   if (e == hipSuccess) e = allow_lds(THA4_L216_KERNEL, v2::cfg::kL2Lds);
   if (e == hipSuccess) e = allow_lds(THA4_L216P_KERNEL, v2::cfg::kL2PLds);
 #ifdef THA4_L2_HOOK
@@ -347,7 +349,12 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
     hipLaunchKernelGGL((THA4_L2_KERNEL), dim3(cfg::blocks_for<cfg::L2G>(batch, 512)), dim3(cfg::L2G::THREADS),
                        cfg::L2G::LDS, s, d);
   } else {
-    if (THA4_FRONT_MERGE) {
+    if (THA4_FRONT_REGS) {
+      // face + level 0 in one launch of 4-wave workgroups, two per CU (front16r_kernel): [level-0 workgroups | face workgroups]
+      if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
+      d.front_l0_blocks = batch * (128 * 128) / v2::cfg::FrontR::PX;
+      hipLaunchKernelGGL((THA4_FRONT16R_KERNEL), dim3(2 * d.front_l0_blocks), dim3(v2::cfg::FrontR::THREADS), v2::cfg::kFrontRLds, s, d);
+    } else if (THA4_FRONT_MERGE) {
       // face + level 0 in one launch (front16_kernel): timing slot 1 (face) is empty, slot 2 holds the merged kernel
       if (t) HIP_TRY(hipEventRecord(h->ev[2], s));
       d.front_l0_blocks = v2::cfg::blocks_for<v2::cfg::L0G>(batch, 128);
@@ -361,8 +368,11 @@ int tha4_student_pose(tha4_student* h, const float* image_dev, int64_t image_bat
                          v2::cfg::kL0Lds, s, d);
     }
     if (t) HIP_TRY(hipEventRecord(h->ev[3], s));
-    hipLaunchKernelGGL((THA4_L116_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L1G>(batch, 256)), dim3(v2::cfg::L1G::THREADS),
-                       v2::cfg::kL1Lds, s, d);
+    if (THA4_L1_REGS)
+      hipLaunchKernelGGL((THA4_L116R_KERNEL), dim3(batch * (256 * 256) / v2::cfg::L1R::PX), dim3(v2::cfg::L1R::THREADS), v2::cfg::kL1RLds, s, d);
+    else
+      hipLaunchKernelGGL((THA4_L116_KERNEL), dim3(v2::cfg::blocks_for<v2::cfg::L1G>(batch, 256)), dim3(v2::cfg::L1G::THREADS),
+                         v2::cfg::kL1Lds, s, d);
     if (t) HIP_TRY(hipEventRecord(h->ev[4], s));
 #ifdef THA4_L2_HOOK
     if (h->l2_function) {

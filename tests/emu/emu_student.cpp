@@ -114,9 +114,9 @@ int emu_student_grid_gen(int kernel, int gen) {
   if (gen == 2) {
     switch (kernel) {
       case 0: return cfg::posebias_blocks();
-      case 1: return v2::cfg::blocks_for<v2::cfg::FaceG>(1, 128);
-      case 2: return v2::cfg::blocks_for<v2::cfg::L0G>(1, 128);
-      case 3: return v2::cfg::blocks_for<v2::cfg::L1G>(1, 256);
+      case 1: return THA4_FRONT_REGS ? (128 * 128) / v2::cfg::FrontR::PX : v2::cfg::blocks_for<v2::cfg::FaceG>(1, 128);
+      case 2: return THA4_FRONT_REGS ? (128 * 128) / v2::cfg::FrontR::PX : v2::cfg::blocks_for<v2::cfg::L0G>(1, 128);
+      case 3: return (256 * 256) / v2::cfg::kL1Px;
       case 4: return THA4_L2_RESIDENT ? (512 * 512) / v2::cfg::L2P::PX : v2::cfg::blocks_for<v2::cfg::L2G>(1, 512);
     }
     return -1;
@@ -140,9 +140,18 @@ int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
     for (int b = first_block; b < first_block + nblocks; ++b) {
       switch (kernel) {
         case 0: emu::run_block(posebias_kernel, dim3(grid, 1), dim3(b, 0), kPoseBiasBlock, 0, e->dev); break;
-        case 1: emu::run_block(THA4_FACE16_KERNEL, dim3(grid), dim3(b), v2::cfg::FaceG::THREADS, v2::cfg::kFaceLds, e->dev); break;
-        case 2: emu::run_block(THA4_L016_KERNEL, dim3(grid), dim3(b), v2::cfg::L0G::THREADS, v2::cfg::kL0Lds, e->dev); break;
-        case 3: emu::run_block(THA4_L116_KERNEL, dim3(grid), dim3(b), v2::cfg::L1G::THREADS, v2::cfg::kL1Lds, e->dev); break;
+        case 1:      // (front16r_kernel: the face workgroups are the second half of the merged grid)
+          if (THA4_FRONT_REGS) { e->dev.front_l0_blocks = grid; emu::run_block(THA4_FRONT16R_KERNEL, dim3(2 * grid), dim3(grid + b), v2::cfg::FrontR::THREADS, v2::cfg::kFrontRLds, e->dev); }
+          else emu::run_block(THA4_FACE16_KERNEL, dim3(grid), dim3(b), v2::cfg::FaceG::THREADS, v2::cfg::kFaceLds, e->dev);
+          break;
+        case 2:
+          if (THA4_FRONT_REGS) { e->dev.front_l0_blocks = grid; emu::run_block(THA4_FRONT16R_KERNEL, dim3(2 * grid), dim3(b), v2::cfg::FrontR::THREADS, v2::cfg::kFrontRLds, e->dev); }
+          else emu::run_block(THA4_L016_KERNEL, dim3(grid), dim3(b), v2::cfg::L0G::THREADS, v2::cfg::kL0Lds, e->dev);
+          break;
+        case 3:
+          if (THA4_L1_REGS) emu::run_block(THA4_L116R_KERNEL, dim3(grid), dim3(b), v2::cfg::L1R::THREADS, v2::cfg::kL1RLds, e->dev);
+          else emu::run_block(THA4_L116_KERNEL, dim3(grid), dim3(b), v2::cfg::L1G::THREADS, v2::cfg::kL1Lds, e->dev);
+          break;
         case 4:
           if (THA4_L2_RESIDENT) emu::run_block(THA4_L216P_KERNEL, dim3(grid), dim3(b), v2::cfg::L2P::THREADS, v2::cfg::kL2PLds, e->dev);
           else emu::run_block(THA4_L216_KERNEL, dim3(grid), dim3(b), v2::cfg::L2G::THREADS, v2::cfg::kL2Lds, e->dev);
@@ -167,7 +176,7 @@ int emu_student_run(void* h, int kernel, int first_block, int nblocks) {
 // pixels [first, first+count) (row-major index at the kernel's resolution) covered by workgroup b
 void emu_student_block_pixels_gen(int kernel, int block, int gen, int* first, int* count) {
   if (gen == 2)
-    *count = kernel == 1 ? v2::cfg::FaceG::PX : kernel == 2 ? v2::cfg::L0G::PX : kernel == 3 ? v2::cfg::L1G::PX
+    *count = kernel == 1 ? (THA4_FRONT_REGS ? v2::cfg::FrontR::PX : v2::cfg::FaceG::PX) : kernel == 2 ? (THA4_FRONT_REGS ? v2::cfg::FrontR::PX : v2::cfg::L0G::PX) : kernel == 3 ? v2::cfg::kL1Px
              : (THA4_L2_RESIDENT ? v2::cfg::L2P::PX : v2::cfg::L2G::PX);
   else
     *count = kernel == 1 ? cfg::FaceG::PX : kernel == 2 ? cfg::L0G::PX : kernel == 3 ? cfg::L1G::PX : cfg::L2G::PX;

@@ -78,6 +78,12 @@ VARIANTS = {
     # A/B them with tools/ab_full.py name=default@THA4_TUNING=1,VAR=1: THA4_SIDE_STREAM, THA4_MOMENT_ACC [+ THA4_ACC_MIN_TILES=16], THA4_NO_XCD_REMAP, THA4_NORM_TILE_SPLIT)
     "identity_pixels": ["-DTHA4_IDENTITY_PIXELS=1"],               # pixel = MFMA column in the convolution windows (rounds 2-4: 22-30 % LDS bank-conflict cycles)
     "norm8": ["-DTHA4_NORM_LOADS_IN_FLIGHT=8"],                    # norm_finalize_kernel with eight moment loads in flight (measured -0.5 %)
+    # round 6: level 1 with the activations in registers (level1_16r_kernel<WAVES, PG, SLOTS>) against the LDS-activation form it replaced
+    "l1regs0": ["-DTHA4_L1_REGS=0"], "l1r816": ["-DTHA4_L116R_CFG=8,1,6"], "l1r413": ["-DTHA4_L116R_CFG=4,1,3"], "l1r824": ["-DTHA4_L116R_CFG=8,2,4"],
+    "l1r823": ["-DTHA4_L116R_CFG=8,2,3"],
+    # round 6: face + level 0 as two 4-wave register-resident workgroups per CU (front16r_kernel<level-0 blocks per chunk, level-0 slots, face slots>)
+    "frontregs0": ["-DTHA4_FRONT_REGS=0"], "fr664": ["-DTHA4_FRONT16R_CFG=6,6,4"], "fr1233": ["-DTHA4_FRONT16R_CFG=12,3,3"], "fr1232": ["-DTHA4_FRONT16R_CFG=12,3,2"],
+    "allregs0": ["-DTHA4_FRONT_REGS=0", "-DTHA4_L1_REGS=0"],
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["THA4_SWEEP_VARIANTS"].split(",")}
