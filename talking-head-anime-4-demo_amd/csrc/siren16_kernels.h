@@ -33,6 +33,29 @@
 namespace tha4 {
 namespace v2 {
 
+// In-kernel time stamps of the tuning builds (-DTHA4_STAMPS, tools/stamps_student.py): lane 0 of a chosen wave stores the shader clock into the (otherwise
+// unused) pose-bias workspace, 64 stamps per slot.  The product build compiles them out.
+#if defined(THA4_STAMPS) && !defined(THA4_EMU)
+#define THA4_STAMP(d, on, slot, k)                                                                                       \
+  do {                                                                                                                   \
+    if ((on) && (threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long*>((d).pbias)[(slot) * 64 + (k)] = clock64(); \
+  } while (0)
+// entry / exit of EVERY workgroup in the 100-MHz wall clock (comparable across XCDs): u64 [4 k .. 4 k + 3] of span slot k = min entry, max entry, min exit, max exit
+#define THA4_SPAN(d, k, exit_)                                                                                                        \
+  do {                                                                                                                               \
+    if (threadIdx.x == 0) {                                                                                                          \
+      unsigned long long* sp_ = reinterpret_cast<unsigned long long*>((d).pbias) + 320 + 4 * (k) + 2 * (exit_);                       \
+      const unsigned long long t_ = wall_clock64();                                                                                  \
+      atomicMin(sp_, t_);                                                                                                            \
+      atomicMax(sp_ + 1, t_);                                                                                                        \
+    }                                                                                                                                \
+  } while (0)
+#else
+#define THA4_STAMP(d, on, slot, k)
+#define THA4_SPAN(d, k, exit_)
+#endif
+
+
 // ---- host/device shared layout helpers ---------------------------------------------------------
 // order of the pieces of one K group in the weight stream when a chunk is 1/HB of the group's blocks and MS waves
 // split the rows: piece index of wave-local block bl of row split ms
@@ -733,6 +756,7 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   constexpr int S = kImg, STRIPS = S * S / (16 * PG);
   THA4_DYN_LDS(smem);
   const WaveCtx w = wave_ctx<G>();
+  THA4_SPAN(d, 3, 0);
   fetch_pieces<2 * Cfg::kPieces, WAVES>(reinterpret_cast<const char*>(d.w_l2), smem, w.wave, w.lane);
   // Strips are handed out dynamically: a wave that hits slow image gathers in its warp epilogue does not hold the
   // workgroup back (static assignment: the slowest wave finished ~22 k cycles after the mean).  Which wave computes a
@@ -844,45 +868,57 @@ struct Level1RCfg {
 #define THA4_REGS_GROUP_BLOCKS 0     // blocks whose A fragments (hi + lo) are double-buffered in registers; 0: 2 for two pixel groups / wide layers, 3 otherwise
 #endif
 // (Q0, B0: first K group of x / first accumulator block of the chunk - constants once the chunk sequence is unrolled)
+// The A fragments (hi + lo of GB blocks per step) go through a ring of THA4_REGS_PREFETCH + 1 register buffers: the reads of step t + PREFETCH are
+// issued at the top of step t.  With one step of look-ahead issued behind the step's first MFMAs (the form of mma_resident) a wave that is alone
+// with its chain - one or two waves per SIMD instead of level 2's four - covers 4 MFMAs (~70 cycles) of a ~200-cycle LDS round trip under load and
+// stalls at the top of EVERY step: front16r_kernel lost 2.4 us of 38 with its MFMAs removed (tools/runs_r06/gpu_r06_c3.sh).
+#ifndef THA4_REGS_PREFETCH
+#define THA4_REGS_PREFETCH 2
+#endif
 template <int NBC, int CQ, int KG, int PG, int NBT>
 THA4_DEV void mma_chunk_regs(const char* wv, const f16x8 (&xh)[KG][PG], const f16x8 (&xl)[KG][PG], f32x4 (&acc)[NBT][PG], const int Q0, const int B0) {
   constexpr int GB = NBC == 1 ? 1 : THA4_REGS_GROUP_BLOCKS ? THA4_REGS_GROUP_BLOCKS : ((PG >= 2 || KG * PG > 8) ? 2 : (NBC % 3 == 0 ? 3 : 2)), NGB = NBC / GB, T = CQ * NGB;
-  static_assert(NBC % GB == 0, "the block group must divide the chunk's blocks");
-  f16x8 ah[2][GB], al[2][GB];
-#pragma unroll
-  for (int b = 0; b < GB; ++b) {
-    ah[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048);
-    al[0][b] = *reinterpret_cast<const f16x8*>(wv + (size_t)b * 2048 + 1024);
-  }
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int qq = t / NGB, bo = B0 + (t % NGB) * GB;
+  constexpr int D = THA4_REGS_PREFETCH, NBUF = D + 1;
+  static_assert(NBC % GB == 0 && GB <= 3, "the block group must divide the chunk's blocks");
+  static_assert(2 * GB * D <= 15, "the reads in flight must fit the 4-bit lgkmcnt");
+  f16x8 ah[NBUF][GB], al[NBUF][GB];
+  // The fragment reads are inline asm and their waits hand-counted (lds_read16 / lds_wait, tha4_platform.h): with the ring's LDS-DMA in flight the
+  // compiler's own waits drain every outstanding read at each step.
+  auto load = [&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    static_for<0, GB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int off = ((t / NGB) * NBC + (t % NGB) * GB + b) * 2048;
+      lds_read16<off>(ah[t % NBUF][b], wv);
+      lds_read16<off + 1024>(al[t % NBUF][b], wv);
+    });
+  };
+  static_for<0, (D < T ? D : T)>(load);
+  static_for<0, T>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int qq = t / NGB, buf = t % NBUF;
+    const int bo = B0 + (t % NGB) * GB;
+    if constexpr (t + D < T) load(std::integral_constant<int, t + D>());
+    constexpr int newer = ((t + D < T ? t + D : T - 1) - t) * 2 * GB;           // reads of the steps behind this one that may stay in flight
+    if constexpr (GB == 1) lds_wait<newer>(ah[buf][0], al[buf][0]);
+    else if constexpr (GB == 2) lds_wait<newer>(ah[buf][0], al[buf][0], ah[buf][1], al[buf][1]);
+    else lds_wait<newer>(ah[buf][0], al[buf][0], ah[buf][1], al[buf][1], ah[buf][2], al[buf][2]);
+    THA4_SCHED_FENCE();
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], xh[Q0 + qq][pg], acc[bo + b][pg]);
-    THA4_SCHED_FENCE();
-    if (t + 1 < T) {
-#pragma unroll
-      for (int b = 0; b < GB; ++b) {
-        const char* pc = wv + ((size_t)((t + 1) / NGB) * NBC + ((t + 1) % NGB) * GB + b) * 2048;
-        ah[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc);
-        al[(t + 1) & 1][b] = *reinterpret_cast<const f16x8*>(pc + 1024);
-      }
-    }
-    THA4_SCHED_FENCE();
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[buf][b], xh[Q0 + qq][pg], acc[bo + b][pg]);
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[t & 1][b], xl[Q0 + qq][pg], acc[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[buf][b], xl[Q0 + qq][pg], acc[bo + b][pg]);
 #pragma unroll
     for (int b = 0; b < GB; ++b)
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(al[t & 1][b], xh[Q0 + qq][pg], acc[bo + b][pg]);
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(al[buf][b], xh[Q0 + qq][pg], acc[bo + b][pg]);
     THA4_SCHED_FENCE();
-  }
+  });
 }
-
 
 // First layer of a register-resident level (level1_16r_kernel): the x2-upsample taps of ALL pixel groups of the wave as one sequence of
 // batches of TB blocks (4 tap loads each), TWO batches in flight.  first16_up_to keeps two BLOCKS in flight - right for 16 waves per CU, but a
@@ -966,6 +1002,9 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
   const WaveCtx w = wave_ctx<G>();
   const char* gw = reinterpret_cast<const char*>(d.w_l1);
   auto fetch = [&](int c) { fetch_pieces<2 * Cfg::kChunkPieces, WAVES>(gw + (size_t)c * Cfg::kChunk, smem + (c % SLOTS) * Cfg::kChunk, w.wave, w.lane); };
+  const bool son = blockIdx.x == 0 && w.wave == 0;
+  THA4_SPAN(d, 2, 0);
+  THA4_STAMP(d, son, 3, 0);
 #pragma unroll
   for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
   int pix0[PG], X0[PG], Y[PG];
@@ -977,6 +1016,7 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
   for (int c = threadIdx.x; c < Cfg::kBiasFloats + 3; c += WAVES * 64) bias_lds[c] = c < Cfg::kBiasFloats ? d.b_l1[c] : d.s_l1[c - Cfg::kBiasFloats];
   for (int c = threadIdx.x; c < 2 * kNB1 * 16; c += WAVES * 64) pb[kNB1 * 16 + c] = c < kNB1 * 16 ? d.wx[2][c] : d.wy[2][c - kNB1 * 16];
   __syncthreads();                                             // (drains vmcnt: chunks 0 .. kPre - 1 have landed for every wave)
+  THA4_STAMP(d, son, 3, 2);
   const int g4 = (w.lane >> 4) * 4;
   f16x8 xh[kKG1][PG], xl[kKG1][PG];
   THA4_PRIO_VALU();
@@ -996,6 +1036,7 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
     if ((c) + DEPTH < NC) fetch((c) + DEPTH);                                                  \
   } while (0)
   const float* scl = bias_lds + Cfg::kBiasFloats;              // (from LDS: a global load here would sit behind the ring copies in the in-order vmcnt queue)
+  THA4_STAMP(d, son, 3, 3);
   {   // 180 -> 180, sine
     f32x4 acc[kNB1][PG];
     zero_acc<kNB1, PG>(acc);
@@ -1005,6 +1046,7 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
     THA4_L1R_CHUNK_TOP(3); mma_chunk_regs<kNB1, 1>(ring + (3 % SLOTS) * Cfg::kChunk, xh, xl, acc, 3, 0);
     THA4_L1R_CHUNK_TOP(4); mma_chunk_regs<kNB1, 1>(ring + (4 % SLOTS) * Cfg::kChunk, xh, xl, acc, 4, 0);
     THA4_L1R_CHUNK_TOP(5); mma_chunk_regs<kNB1, 1>(ring + (5 % SLOTS) * Cfg::kChunk, xh, xl, acc, 5, 0);
+    THA4_STAMP(d, son, 3, 4);
     THA4_PRIO_VALU();
     const float inv = scl[0];
 #pragma unroll
@@ -1020,6 +1062,7 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
     }
     pin_rows<kKG1, PG>(xh, xl);
     THA4_PRIO_MFMA();
+    THA4_STAMP(d, son, 3, 5);
   }
   f16x8 yh[kKG2][PG], yl[kKG2][PG];
   {   // 180 -> 90, sine
@@ -1028,6 +1071,7 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
     THA4_L1R_CHUNK_TOP(6); mma_chunk_regs<kNB2, 2>(ring + (6 % SLOTS) * Cfg::kChunk, xh, xl, acc, 0, 0);
     THA4_L1R_CHUNK_TOP(7); mma_chunk_regs<kNB2, 2>(ring + (7 % SLOTS) * Cfg::kChunk, xh, xl, acc, 2, 0);
     THA4_L1R_CHUNK_TOP(8); mma_chunk_regs<kNB2, 2>(ring + (8 % SLOTS) * Cfg::kChunk, xh, xl, acc, 4, 0);
+    THA4_STAMP(d, son, 3, 6);
     THA4_PRIO_VALU();
     const float inv = scl[1];
 #pragma unroll
@@ -1043,12 +1087,14 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
     }
     pin_rows<kKG2, PG>(yh, yl);
     THA4_PRIO_MFMA();
+    THA4_STAMP(d, son, 3, 7);
   }
   {   // z2 = c W20[:, :90] h1 (fp32) -> global z[n][b][g][pix][4]; the consumer is level 2's first (sine) layer
     f32x4 acc[kNB2][PG];
     zero_acc<kNB2, PG>(acc);
     THA4_L1R_CHUNK_TOP(9); mma_chunk_regs<kNB2, 2>(ring + (9 % SLOTS) * Cfg::kChunk, yh, yl, acc, 0, 0);
     THA4_L1R_CHUNK_TOP(10); mma_chunk_regs<kNB2, 1>(ring + (10 % SLOTS) * Cfg::kChunk, yh, yl, acc, 2, 0);
+    THA4_STAMP(d, son, 3, 8);
     const float inv = scl[2];
     float* zframe = d.z2 + (size_t)n * kNB2 * NPIX * 16;
     const int p = w.lane & 15;
@@ -1056,9 +1102,10 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
     for (int b = 0; b < kNB2; ++b)
 #pragma unroll
       for (int pg = 0; pg < PG; ++pg)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(zframe + z_offset(b, 0, 0, NPIX)) +
-                                  (unsigned)(z_offset(0, w.lane >> 4, pix0[pg] + p, NPIX) * sizeof(float))) = acc[b][pg] * inv;
+        store16_wt(reinterpret_cast<char*>(zframe + z_offset(b, 0, 0, NPIX)) + (unsigned)(z_offset(0, w.lane >> 4, pix0[pg] + p, NPIX) * sizeof(float)), acc[b][pg] * inv);
+    THA4_STAMP(d, son, 3, 9);
   }
+  THA4_SPAN(d, 2, 1);
 #undef THA4_L1R_CHUNK_TOP
 }
 
@@ -1089,17 +1136,126 @@ struct RingRegs {
   THA4_DEV const char* at(int c) const { return base + (c % SLOTS) * kChunk + lane * 16; }
 };
 
+struct StampCtx { const StudentDev* d; bool on; int slot; };
+
+// ---- the ring with EARLY barriers: one continuous fragment pipeline per layer (round 6) ------------------------------------------------
+// In-kernel stamps of the first register form (tools/stamps_student.py, profiles/r06_student_b1_reading.md): a 24-KiB chunk of level 0 took 0.47 us - 0.14 us
+// at its top (counted wait + barrier + a burst of six LDS-DMA issues at ~60 cycles each), ~0.07 us refilling the fragment pipeline behind the barrier, 0.26 us
+// of matrix work.  Here the barrier of chunk c + 1 is passed D steps BEFORE chunk c's last MFMAs - from then on the fragment reads run ahead across the
+// chunk boundary and the pipeline never drains inside a layer - and the LDS-DMA copies it releases are issued one or two per step under the MFMAs instead
+// of in a burst.  Price: the slot that is rewritten behind top(c) is the one of chunk c - 2 (chunk c - 1 is still being read), so of SLOTS slots one is in
+// use, one has landed and SLOTS - 2 are in flight or being requested.
+template <int WAVES, int SLOTS, int CHUNK_PIECES>
+struct RingEarly {
+  static constexpr int kChunk = CHUNK_PIECES * 2048, kCPW = 2 * CHUNK_PIECES / WAVES, kBytes = SLOTS * kChunk, kAhead = SLOTS - 2, kSlots = SLOTS;
+  static_assert((2 * CHUNK_PIECES) % WAVES == 0, "every wave must issue the same number of copies per chunk (counted waits)");
+  static_assert(SLOTS >= 3 && (SLOTS - 3) * kCPW <= 16, "THA4_BARRIER_KEEP_VM counts up to 16 copies");
+  const char* gw;
+  char* base;
+  int wave, lane;
+  // copies [i0, i1) of this wave's kCPW copies of chunk c
+  THA4_DEV void fetch_part(int c, int i0, int i1) const {
+    const char* g = gw + (size_t)c * kChunk;
+    char* l = base + (c % SLOTS) * kChunk;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      const int pc = i * WAVES + wave;
+      THA4_HOOK_FETCH(glds16(g + pc * 1024 + (unsigned)(lane * 16), l + pc * 1024));
+    }
+  }
+  THA4_DEV void fetch(int c) const { fetch_part(c, 0, kCPW); }
+  // chunk c of nc has landed for every wave (everything but the copies of the chunks requested behind it), and every wave has consumed chunk c - 2
+  THA4_DEV void wait_top(int c, int nc) const {
+    const int last = c + SLOTS - 3 < nc - 1 ? c + SLOTS - 3 : nc - 1;
+    THA4_BARRIER_KEEP_VM((last > c ? last - c : 0) * kCPW);
+  }
+  THA4_DEV const char* at(int c) const { return base + (c % SLOTS) * kChunk + lane * 16; }
+};
+
+#ifndef THA4_RING_SPREAD
+#define THA4_RING_SPREAD 1     // 1: the LDS-DMA copies a barrier releases are issued under the following steps' MFMAs; 0: in a burst behind the barrier
+#endif
+// One linear layer with x in registers as ONE software pipeline over all its chunks.  Chunks: CQ K groups x NBC output blocks (CQ > 1 only with NBC == NB),
+// global chunk index c0 + k.  acc: the layer's NB output blocks.
+template <int NB, int KG, int NBC, int CQ, class Ring, int KGX, int PG>
+THA4_DEV void layer_regs_e(const Ring& ring, const int c0, const int nc, const f16x8 (&xh)[KGX][PG], const f16x8 (&xl)[KGX][PG], f32x4 (&acc)[NB][PG],
+                           const StampCtx st = StampCtx{nullptr, false, 0}) {
+  static_assert(NB % NBC == 0 && KG <= KGX && (CQ == 1 || NBC == NB), "bad chunking");
+  constexpr int NCHQ = NB / NBC;
+  constexpr int GB = NBC == 1 ? 1 : THA4_REGS_GROUP_BLOCKS ? THA4_REGS_GROUP_BLOCKS : ((PG >= 2 || KGX * PG > 8) ? 2 : (NBC % 3 == 0 ? 3 : 2)), NGB = NBC / GB;
+  constexpr int T = CQ * NGB, G = KG * NGB * NCHQ, NCH = (G + T - 1) / T;
+  constexpr int D = THA4_REGS_PREFETCH < T ? THA4_REGS_PREFETCH : T, NBUF = D + 1;
+  constexpr int CPW = Ring::kCPW, CPS = THA4_RING_SPREAD ? (CPW + T - 1) / T : CPW;          // copies issued per step behind a barrier
+  static_assert(NBC % GB == 0 && GB <= 3 && 2 * GB * D <= 15, "fragment pipeline out of range");
+  f16x8 ah[NBUF][GB], al[NBUF][GB];
+  auto load = [&](auto gc) {
+    constexpr int g = decltype(gc)::value, k = g / T, t = g % T;
+    const char* wv = ring.at(c0 + k);
+    static_for<0, GB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int off = ((t / NGB) * NBC + (t % NGB) * GB + b) * 2048;
+      lds_read16<off>(ah[g % NBUF][b], wv);
+      lds_read16<off + 1024>(al[g % NBUF][b], wv);
+    });
+  };
+  ring.wait_top(c0, nc);
+  if (c0 + Ring::kAhead < nc) ring.fetch(c0 + Ring::kAhead);
+  static_for<0, (D < G ? D : G)>(load);
+  static_for<0, G>([&](auto gc) {
+    constexpr int g = decltype(gc)::value, k = g / T, t = g % T, buf = g % NBUF;
+    constexpr int q = CQ == 1 ? k / NCHQ : k * CQ + t / NGB;
+    constexpr int bo = (CQ == 1 ? (k % NCHQ) * NBC : 0) + (t % NGB) * GB;
+    constexpr int ktop = (g + D) / T;                                  // the newest chunk of this layer whose barrier has been passed once this step's is
+    if constexpr ((g + D) % T == 0 && ktop < NCH) {
+      THA4_STAMP(*st.d, st.on && c0 + ktop >= 20 && c0 + ktop < 24, st.slot, 16 + 3 * (c0 + ktop - 20));
+      ring.wait_top(c0 + ktop, nc);
+      THA4_STAMP(*st.d, st.on && c0 + ktop >= 20 && c0 + ktop < 24, st.slot, 17 + 3 * (c0 + ktop - 20));
+    }
+    if constexpr (g + D < G) load(std::integral_constant<int, g + D>());
+    constexpr int newer = ((g + D < G ? g + D : G - 1) - g) * 2 * GB;
+    if constexpr (GB == 1) lds_wait<newer>(ah[buf][0], al[buf][0]);
+    else if constexpr (GB == 2) lds_wait<newer>(ah[buf][0], al[buf][0], ah[buf][1], al[buf][1]);
+    else lds_wait<newer>(ah[buf][0], al[buf][0], ah[buf][1], al[buf][1], ah[buf][2], al[buf][2]);
+    THA4_SCHED_FENCE();
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[buf][b], xh[q][pg], acc[bo + b][pg]);
+    if constexpr (ktop >= 1 && ktop < NCH) {                            // this step's share of the copies the newest barrier released
+      constexpr int s0 = g - (ktop * T - D);
+      if (c0 + ktop + Ring::kAhead < nc) ring.fetch_part(c0 + ktop + Ring::kAhead, s0 * CPS < CPW ? s0 * CPS : CPW, (s0 + 1) * CPS < CPW ? (s0 + 1) * CPS : CPW);
+    }
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(ah[buf][b], xl[q][pg], acc[bo + b][pg]);
+#pragma unroll
+    for (int b = 0; b < GB; ++b)
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[bo + b][pg] = mfma16h(al[buf][b], xh[q][pg], acc[bo + b][pg]);
+    THA4_SCHED_FENCE();
+  });
+  // a short last chunk may leave copies of the newest barrier's chunk unissued: the next layer's counted wait expects them in the queue
+  if constexpr (NCH >= 2) {
+    constexpr int done = (G - ((NCH - 1) * T - D)) * CPS;
+    if (done < CPW && c0 + NCH - 1 + Ring::kAhead < nc) ring.fetch_part(c0 + NCH - 1 + Ring::kAhead, done, CPW);
+  }
+}
+
 // one linear layer, x in registers: chunks of ONE K group x NBC output blocks, chunk index c0 + q (NB / NBC) + h
 template <int NB, int KG, int NBC, class Ring, int KGX, int PG>
-THA4_DEV void layer_regs(const Ring& ring, int c0, int nc, const f16x8 (&xh)[KGX][PG], const f16x8 (&xl)[KGX][PG], f32x4 (&acc)[NB][PG]) {
+THA4_DEV void layer_regs(const Ring& ring, int c0, int nc, const f16x8 (&xh)[KGX][PG], const f16x8 (&xl)[KGX][PG], f32x4 (&acc)[NB][PG], const StampCtx st = StampCtx{nullptr, false, 0}) {
   static_assert(NB % NBC == 0 && KG <= KGX, "bad chunking");
 #pragma unroll
   for (int q = 0; q < KG; ++q)
 #pragma unroll
     for (int h = 0; h < NB / NBC; ++h) {
       const int c = c0 + q * (NB / NBC) + h;
+      if (c >= 10 && c < 14) THA4_STAMP(*st.d, st.on, st.slot, 16 + 3 * (c - 10));
       ring.top(c, nc);
+      if (c >= 10 && c < 14) THA4_STAMP(*st.d, st.on, st.slot, 17 + 3 * (c - 10));
       mma_chunk_regs<NBC, 1>(ring.at(c), xh, xl, acc, q, h * NBC);
+      if (c >= 10 && c < 14) THA4_STAMP(*st.d, st.on, st.slot, 18 + 3 * (c - 10));
     }
 }
 
@@ -1142,45 +1298,98 @@ THA4_DEV void first16_pos_to(const float* wx, const float* wy, const float* pb, 
   }
 }
 
-template <int NBC0, int SLOTS0, int SLOTSF>
+// Prologue of a register-resident workgroup: the pose-folded first-layer bias (same arithmetic and summation order as pose_bias_to_lds), the first
+// layer's position columns, and the streamed layers' biases + 1/S - everything the kernel reads per value - into LDS.  ALL global loads are requested
+// before the first result is needed (a thread folds up to RW channels at once: 45 loads each; the plain copies ride along): one memory round trip where the
+// loop-after-loop form paid three to four (stamps: 3.6 us of a 28-us level-0 workgroup).
+//   pb: [pose-folded bias W | wx W | wy W] floats, W = NB * 16;   bias_lds: [NBIAS biases | NSCL scales]
+template <int NB, int THREADS, int NBIAS, int NSCL>
+THA4_DEV void prologue_to_lds(const StudentDev& d, int net, int n, const float* bsrc, const float* ssrc, float* pb, float* bias_lds) {
+  constexpr int W = NB * 16, RW = (W + THREADS - 1) / THREADS, RB = (NBIAS + NSCL + THREADS - 1) / THREADS, RT = (2 * W + THREADS - 1) / THREADS;
+  const int tid = threadIdx.x;
+  float bv[RB], tv[RT], s[RW][3];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int c = tid + r * THREADS;
+    bv[r] = c < NBIAS ? bsrc[c] : (c < NBIAS + NSCL ? ssrc[c - NBIAS] : 0.0f);
+  }
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int c = tid + r * THREADS;
+    tv[r] = c < W ? d.wx[net][c] : (c < 2 * W ? d.wy[net][c - W] : 0.0f);
+  }
+  const float* pose = d.pose + (size_t)n * kPose;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int c = tid + r * THREADS, cc = c < W ? c : 0;
+    const float* wp = d.wpose[net] + cc;
+    s[r][0] = d.bias1[net][cc];
+    s[r][1] = 0.f;
+    s[r][2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < kPose; ++k) s[r][k % 3] = fmaf(wp[(size_t)k * W], pose[k], s[r][k % 3]);
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int c = tid + r * THREADS;
+    if (c < W) pb[c] = (s[r][0] + (s[r][1] + s[r][2])) * d.pb_scale;
+  }
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int c = tid + r * THREADS;
+    if (c < 2 * W) pb[W + c] = tv[r];
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int c = tid + r * THREADS;
+    if (c < NBIAS + NSCL) bias_lds[c] = bv[r];
+  }
+}
+
+template <int NBC0, int SLOTS0, int NBCF, int SLOTSF>
 struct FrontRCfg {
   static constexpr int WAVES = 4, PG = 1, THREADS = WAVES * 64, PX = WAVES * PG * 16;
   using G = GeoRegs<WAVES, PG>;
   // level 0: 360 -> 360 -> 180 (sine), then z1; chunks of one K group x NBC0 blocks
-  using Ring0 = RingRegs<WAVES, SLOTS0, NBC0>;
+  using Ring0 = RingEarly<WAVES, SLOTS0, NBC0>;
   static constexpr int kChunksA = kKG0 * (kNB0 / NBC0), kChunksB = kKG0 * (kNB1 / NBC0), kChunksZ = kKG1 * (kNB1 / NBC0);
   static constexpr int kChunks0 = kChunksA + kChunksB + kChunksZ;
   static constexpr int kBias0 = (kNB0 + kNB1) * 16;                                            // floats: bias A | bias B, then 1/S x 3 (+ pad)
   static constexpr int kPb0Off = Ring0::kBytes, kBias0Off = kPb0Off + 3 * kNB0 * 16 * 4, kLds0 = kBias0Off + (kBias0 + 4) * 4;     // pb | wx | wy, then the biases
-  // face: 7 x (128 -> 128, sine) + head 128 -> 4; chunks of one K group x 8 blocks (16 KiB), the head's 4 pieces padded to one chunk
-  using RingF = RingRegs<WAVES, SLOTSF, kNBF>;
-  static constexpr int kChunksF = 7 * kKGF + 1;
-  static constexpr int kStreamPiecesF = kChunksF * kNBF;                                      // 232 (228 + 4 of padding)
+  // face: 7 x (128 -> 128, sine) + head 128 -> 4; chunks of one K group x NBCF blocks, the head's 4 pieces (1 block x 4 K groups) padded to one chunk
+  using RingF = RingEarly<WAVES, SLOTSF, NBCF>;
+  static constexpr int kChunksLayerF = kKGF * (kNBF / NBCF);
+  static constexpr int kChunksF = 7 * kChunksLayerF + 1;
+  static constexpr int kStreamPiecesF = kChunksF * NBCF;
   static constexpr int kBiasF = 7 * kNBF * 16 + 16;                                            // floats: 7 sine layers | head, then 1/S x 8
   static constexpr int kPbFOff = RingF::kBytes, kBiasFOff = kPbFOff + 3 * kNBF * 16 * 4, kLdsF = kBiasFOff + (kBiasF + 8) * 4;
   static constexpr int LDS = kLds0 > kLdsF ? kLds0 : kLdsF;
   static_assert(LDS <= 80 * 1024, "two workgroups must share a CU");
-  static_assert(kNB0 % NBC0 == 0 && kNB1 % NBC0 == 0, "a chunk must be a whole number of blocks of every level-0 layer");
+  static_assert(kNB0 % NBC0 == 0 && kNB1 % NBC0 == 0 && kNBF % NBCF == 0 && NBCF >= kKGF, "a chunk must be a whole number of blocks of every layer (and hold the head's 4 pieces)");
 };
 
 template <class Cfg>
 THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w) {
   using G = typename Cfg::G;
   using Ring = typename Cfg::Ring0;
-  constexpr int PG = Cfg::PG, S = 128, NPIX = S * S, NC = Cfg::kChunks0;
+  constexpr int PG = Cfg::PG, S = 128, NPIX = S * S, NC = Cfg::kChunks0, NBC = Ring::kChunk / 2048;
   const Ring ring{reinterpret_cast<const char*>(d.w_l0), smem, w.wave, w.lane};
-  constexpr int PRE = Ring::kDepth < 2 ? Ring::kDepth : 2;
-#pragma unroll
-  for (int c = 0; c < PRE; ++c) ring.fetch(c);
+  const bool son = (w.blk == 0 && w.wave == 0) || (w.blk == 131 && w.wave == 3);
+  const StampCtx st{&d, son, w.blk == 0 ? 0 : 1};
+  THA4_STAMP(d, son, st.slot, 0);
   int pix0[PG], X0[PG], Y[PG];
   float px[PG], py[PG];
   const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
   float* pb = reinterpret_cast<float*>(smem + Cfg::kPb0Off);
   float* bias_lds = reinterpret_cast<float*>(smem + Cfg::kBias0Off);
-  pose_bias_to_lds<kNB0, Cfg::THREADS>(d, 1, n, pb);
-  for (int c = threadIdx.x; c < Cfg::kBias0 + 3; c += Cfg::THREADS) bias_lds[c] = c < Cfg::kBias0 ? d.b_l0[c] : d.s_l0[c - Cfg::kBias0];
-  for (int c = threadIdx.x; c < 2 * kNB0 * 16; c += Cfg::THREADS) pb[kNB0 * 16 + c] = c < kNB0 * 16 ? d.wx[1][c] : d.wy[1][c - kNB0 * 16];
-  __syncthreads();                                             // (drains vmcnt: the first PRE chunks have landed for every wave)
+  // the prologue's latency-bound loads go out BEFORE the ring's first burst (48 KiB per workgroup, every workgroup of the chip at once): queued behind it
+  // they took 2.3 us; the ring's first chunks have the whole first layer to land
+  prologue_to_lds<kNB0, Cfg::THREADS, Cfg::kBias0, 3>(d, 1, n, d.b_l0, d.s_l0, pb, bias_lds);
+  THA4_STAMP(d, son, st.slot, 1);
+#pragma unroll
+  for (int c = 0; c < Ring::kAhead; ++c) ring.fetch(c);        // (top(c) requests chunk c + kAhead)
+  THA4_BARRIER_LDS();                                          // (the tables are in LDS for every wave; the ring copies stay in flight)
+  THA4_STAMP(d, son, st.slot, 2);
   const int g4 = (w.lane >> 4) * 4;
   const float* scl = bias_lds + Cfg::kBias0;
   f16x8 xh[kKG0][PG], xl[kKG0][PG];
@@ -1188,25 +1397,29 @@ THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w
   first16_pos_to<G, kNB0>(pb + kNB0 * 16, pb + 2 * kNB0 * 16, pb, px, py, [&](int pg, int b, const f32x4& v) { put_rows<kKG0, PG>(xh, xl, pg, b, v); }, w);
   pin_rows<kKG0, PG>(xh, xl);
   THA4_PRIO_MFMA();
-#pragma unroll
-  for (int c = PRE; c < Ring::kDepth; ++c) ring.fetch(c);      // younger than the first layer's table loads: their waits do not cover these
+  THA4_STAMP(d, son, st.slot, 3);
   {   // 360 -> 360, sine
     f32x4 acc[kNB0][PG];
     zero_acc<kNB0, PG>(acc);
-    layer_regs<kNB0, kKG0, Cfg::Ring0::kChunk / 2048>(ring, 0, NC, xh, xl, acc);
+    layer_regs_e<kNB0, kKG0, NBC, 1>(ring, 0, NC, xh, xl, acc, st);
+    THA4_STAMP(d, son, st.slot, 4);
     sine_regs<kNB0, kKG0, PG>(acc, bias_lds, scl[0], g4, xh, xl);
+    THA4_STAMP(d, son, st.slot, 5);
   }
   f16x8 yh[kKG1][PG], yl[kKG1][PG];
   {   // 360 -> 180, sine
     f32x4 acc[kNB1][PG];
     zero_acc<kNB1, PG>(acc);
-    layer_regs<kNB1, kKG0, Cfg::Ring0::kChunk / 2048>(ring, Cfg::kChunksA, NC, xh, xl, acc);
+    layer_regs_e<kNB1, kKG0, NBC, 1>(ring, Cfg::kChunksA, NC, xh, xl, acc);
+    THA4_STAMP(d, son, st.slot, 6);
     sine_regs<kNB1, kKG1, PG>(acc, bias_lds + kNB0 * 16, scl[1], g4, yh, yl);
+    THA4_STAMP(d, son, st.slot, 7);
   }
   {   // z1 = c W10[:, :180] h0 (fp32) -> global z[n][b][g][pix][4]; the consumer is level 1's first (sine) layer
     f32x4 acc[kNB1][PG];
     zero_acc<kNB1, PG>(acc);
-    layer_regs<kNB1, kKG1, Cfg::Ring0::kChunk / 2048>(ring, Cfg::kChunksA + Cfg::kChunksB, NC, yh, yl, acc);
+    layer_regs_e<kNB1, kKG1, NBC, 1>(ring, Cfg::kChunksA + Cfg::kChunksB, NC, yh, yl, acc);
+    THA4_STAMP(d, son, st.slot, 8);
     const float inv = scl[2];
     float* zframe = d.z1 + (size_t)n * kNB1 * NPIX * 16;
     const int p = w.lane & 15;
@@ -1214,8 +1427,8 @@ THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w
     for (int b = 0; b < kNB1; ++b)
 #pragma unroll
       for (int pg = 0; pg < PG; ++pg)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(zframe + z_offset(b, 0, 0, NPIX)) +
-                                  (unsigned)(z_offset(0, w.lane >> 4, pix0[pg] + p, NPIX) * sizeof(float))) = acc[b][pg] * inv;
+        store16_wt(reinterpret_cast<char*>(zframe + z_offset(b, 0, 0, NPIX)) + (unsigned)(z_offset(0, w.lane >> 4, pix0[pg] + p, NPIX) * sizeof(float)), acc[b][pg] * inv);
+    THA4_STAMP(d, son, st.slot, 9);
   }
 }
 
@@ -1223,20 +1436,20 @@ template <class Cfg>
 THA4_DEV void face_regs_body(const StudentDev& d, char* smem, const WaveCtx& w) {
   using G = typename Cfg::G;
   using Ring = typename Cfg::RingF;
-  constexpr int PG = Cfg::PG, S = kFaceSize, NPIX = S * S, NC = Cfg::kChunksF;
+  constexpr int PG = Cfg::PG, S = kFaceSize, NPIX = S * S, NC = Cfg::kChunksF, NBC = Ring::kChunk / 2048;
   const Ring ring{reinterpret_cast<const char*>(d.w_face), smem, w.wave, w.lane};
-  constexpr int PRE = Ring::kDepth < 2 ? Ring::kDepth : 2;
-#pragma unroll
-  for (int c = 0; c < PRE; ++c) ring.fetch(c);
+  const bool son = w.blk == 0 && w.wave == 0;
+  THA4_STAMP(d, son, 2, 0);
   int pix0[PG], X0[PG], Y[PG];
   float px[PG], py[PG];
   const int n = slot_pixels<G, S>(w, d.pos128, pix0, X0, Y, px, py);
   float* pb = reinterpret_cast<float*>(smem + Cfg::kPbFOff);
   float* bias_lds = reinterpret_cast<float*>(smem + Cfg::kBiasFOff);
-  pose_bias_to_lds<kNBF, Cfg::THREADS>(d, 0, n, pb);
-  for (int c = threadIdx.x; c < Cfg::kBiasF + 8; c += Cfg::THREADS) bias_lds[c] = c < Cfg::kBiasF ? d.b_face[c] : d.s_face[c - Cfg::kBiasF];
-  for (int c = threadIdx.x; c < 2 * kNBF * 16; c += Cfg::THREADS) pb[kNBF * 16 + c] = c < kNBF * 16 ? d.wx[0][c] : d.wy[0][c - kNBF * 16];
-  __syncthreads();
+  prologue_to_lds<kNBF, Cfg::THREADS, Cfg::kBiasF, 8>(d, 0, n, d.b_face, d.s_face, pb, bias_lds);
+#pragma unroll
+  for (int c = 0; c < Ring::kAhead; ++c) ring.fetch(c);
+  THA4_BARRIER_LDS();
+  THA4_STAMP(d, son, 2, 2);
   const int g4 = (w.lane >> 4) * 4;
   const float* scl = bias_lds + Cfg::kBiasF;
   f16x8 xh[kKGF][PG], xl[kKGF][PG];
@@ -1244,20 +1457,19 @@ THA4_DEV void face_regs_body(const StudentDev& d, char* smem, const WaveCtx& w) 
   first16_pos_to<G, kNBF>(pb + kNBF * 16, pb + 2 * kNBF * 16, pb, px, py, [&](int pg, int b, const f32x4& v) { put_rows<kKGF, PG>(xh, xl, pg, b, v); }, w);
   pin_rows<kKGF, PG>(xh, xl);
   THA4_PRIO_MFMA();
-#pragma unroll
-  for (int c = PRE; c < Ring::kDepth; ++c) ring.fetch(c);
+  THA4_STAMP(d, son, 2, 3);
 #pragma unroll
   for (int l = 0; l < 7; ++l) {
     f32x4 acc[kNBF][PG];
     zero_acc<kNBF, PG>(acc);
-    layer_regs<kNBF, kKGF, kNBF>(ring, l * kKGF, NC, xh, xl, acc);
+    layer_regs_e<kNBF, kKGF, NBC, 1>(ring, l * Cfg::kChunksLayerF, NC, xh, xl, acc);
     sine_regs<kNBF, kKGF, PG>(acc, bias_lds + l * kNBF * 16, scl[l], g4, xh, xl);
+    THA4_STAMP(d, son, 2, 4 + l);
   }
   // head: ONE block x 4 K groups = the first 4 pieces of the last chunk; rows 0..3 (the image channels) live in lane group 0
   f32x4 a1[1][PG];
   zero_acc<1, PG>(a1);
-  ring.top(NC - 1, NC);
-  mma_chunk_regs<1, kKGF>(ring.at(NC - 1), xh, xl, a1, 0, 0);
+  layer_regs_e<1, kKGF, 1, kKGF>(ring, NC - 1, NC, xh, xl, a1);
   if (w.lane < 16) {
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + 7 * kNBF * 16);
     const float inv = scl[7];
@@ -1269,15 +1481,17 @@ THA4_DEV void face_regs_body(const StudentDev& d, char* smem, const WaveCtx& w) 
       for (int j = 0; j < 4; ++j) fo[(size_t)j * NPIX + pix0[pg] + w.lane] = v[j];
     }
   }
+  THA4_STAMP(d, son, 2, 12);
 }
 
-template <int NBC0, int SLOTS0, int SLOTSF>
+template <int NBC0, int SLOTS0, int NBCF, int SLOTSF>
 __global__ void __launch_bounds__(256, 2) front16r_kernel(StudentDev d) {
   warm_kernarg<(int)sizeof(StudentDev)>();
-  using Cfg = FrontRCfg<NBC0, SLOTS0, SLOTSF>;
+  using Cfg = FrontRCfg<NBC0, SLOTS0, NBCF, SLOTSF>;
   THA4_DYN_LDS(smem);
   WaveCtx w = wave_ctx<typename Cfg::G>();
   const int nl0 = d.front_l0_blocks;
+  THA4_SPAN(d, (int)blockIdx.x < nl0 ? 0 : 1, 0);
   if ((int)blockIdx.x < nl0) {
     w.nblk = nl0;
     level0_regs_body<Cfg>(d, smem, w);
@@ -1286,6 +1500,7 @@ __global__ void __launch_bounds__(256, 2) front16r_kernel(StudentDev d) {
     w.nblk = gridDim.x - nl0;
     face_regs_body<Cfg>(d, smem, w);
   }
+  THA4_SPAN(d, (int)blockIdx.x < nl0 ? 0 : 1, 1);
 }
 
 // ---- launch configuration ------------------------------------------------------------------------------
@@ -1335,7 +1550,7 @@ namespace cfg {
 #define THA4_FRONT_REGS 1                   // 1: front16r_kernel (face + level 0, activations in registers, two 4-wave workgroups per CU; round 6), 0: front16_kernel
 #endif
 #ifndef THA4_FRONT16R_CFG
-#define THA4_FRONT16R_CFG 12, 3, 4          // level-0 blocks per chunk (12: 24 KiB, 6: 12 KiB), level-0 ring slots, face ring slots (16 KiB)
+#define THA4_FRONT16R_CFG 6, 6, 8, 4        // level 0: blocks per chunk (6: 12 KiB), ring slots; face: blocks per chunk (8: 16 KiB), ring slots
 #endif
 #ifndef THA4_L116R_CFG
 #define THA4_L116R_CFG 8, 2, 6              // WAVES, pixel groups per wave, ring slots of 24 KiB

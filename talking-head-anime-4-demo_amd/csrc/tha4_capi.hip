@@ -427,6 +427,14 @@ int tha4_student_set_weights(tha4_student* h, const tha4_student_weights* weight
 int tha4_student_debug_read(tha4_student* h, int which, int frame, float* host_out) {
   if (!h || !host_out) return fail(THA4_ERR_INVALID_ARGUMENT, "handle/host_out must not be NULL");
   if (frame < 0 || frame >= h->max_batch) return fail(THA4_ERR_INVALID_ARGUMENT, "frame out of range");
+#ifdef THA4_STAMPS      // tuning builds: which == 2 reads the in-kernel time stamps (THA4_STAMP, siren16_kernels.h) out of the pose-bias workspace
+  if (which == 2) {
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, h->dev.pbias, (size_t)kPbStride * sizeof(float), hipMemcpyDeviceToHost));
+    return THA4_OK;
+  }
+#endif
   if (which != 0 && which != 1) return fail(THA4_ERR_INVALID_ARGUMENT, "which must be 0 (z1) or 1 (z2)");
   const size_t per = which == 0 ? (size_t)kNB1 * 128 * 128 * 16 : (size_t)kNB2 * 256 * 256 * 16;
   const float* src = (which == 0 ? h->dev.z1 : h->dev.z2) + (size_t)frame * per;
@@ -435,6 +443,15 @@ int tha4_student_debug_read(tha4_student* h, int which, int frame, float* host_o
   HIP_TRY(hipMemcpy(host_out, src, per * sizeof(float), hipMemcpyDeviceToHost));
   return THA4_OK;
 }
+
+#ifdef THA4_STAMPS
+extern "C" int tha4_student_debug_write(tha4_student* h, const void* host_in) {      // tuning builds: preset the stamp workspace (min / max fields)
+  DeviceGuard guard(h->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h->dev.pbias, host_in, (size_t)kPbStride * sizeof(float), hipMemcpyHostToDevice));
+  return THA4_OK;
+}
+#endif
 
 float tha4_student_hand_off_scale(const tha4_student* h) { return h ? h->dev.pb_scale : 0.0f; }
 

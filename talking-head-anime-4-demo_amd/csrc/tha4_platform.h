@@ -14,6 +14,8 @@
 #define THA4_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #endif
 
+#include <type_traits>
+
 #define THA4_DEV __device__ __forceinline__
 
 // instruction-scheduling fence: nothing moves across it (software pipelining by hand, and caps on loads in flight)
@@ -91,6 +93,24 @@
       THA4_BARRIER_KEEP_CASE(13) THA4_BARRIER_KEEP_CASE(14) THA4_BARRIER_KEEP_CASE(15) THA4_BARRIER_KEEP_CASE(16) \
       default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;                  \
     }                                                                                                             \
+  } while (0)
+#endif
+
+// The same with the wave's own LDS reads left in flight (no lgkmcnt wait): for rings whose slots are only rewritten a whole chunk after their last
+// read was CONSUMED (an MFMA needed it), so that outstanding reads at the barrier can only belong to chunks nobody overwrites yet.
+#ifdef THA4_EMU
+#define THA4_BARRIER_KEEP_VM(keep) __syncthreads()
+#else
+#define THA4_BARRIER_KEEP_VM_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); break;
+#define THA4_BARRIER_KEEP_VM(keep)                                                                                            \
+  do {                                                                                                                        \
+    switch (keep) {                                                                                                           \
+      THA4_BARRIER_KEEP_VM_CASE(1) THA4_BARRIER_KEEP_VM_CASE(2) THA4_BARRIER_KEEP_VM_CASE(3) THA4_BARRIER_KEEP_VM_CASE(4)     \
+      THA4_BARRIER_KEEP_VM_CASE(5) THA4_BARRIER_KEEP_VM_CASE(6) THA4_BARRIER_KEEP_VM_CASE(7) THA4_BARRIER_KEEP_VM_CASE(8)     \
+      THA4_BARRIER_KEEP_VM_CASE(9) THA4_BARRIER_KEEP_VM_CASE(10) THA4_BARRIER_KEEP_VM_CASE(11) THA4_BARRIER_KEEP_VM_CASE(12)  \
+      THA4_BARRIER_KEEP_VM_CASE(13) THA4_BARRIER_KEEP_VM_CASE(14) THA4_BARRIER_KEEP_VM_CASE(15) THA4_BARRIER_KEEP_VM_CASE(16) \
+      default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;                                          \
+    }                                                                                                                         \
   } while (0)
 #endif
 
@@ -247,3 +267,67 @@ THA4_DEV void split_pair(float a, float b, float m1, _Float16& ha, _Float16& hb,
 }
 
 }  // namespace tha4
+
+// ---- hand-counted LDS fragment reads --------------------------------------------------------------------------------------------------
+// With an LDS-DMA (global_load_lds) in flight, or behind an inline-asm barrier, the compiler's s_waitcnt insertion waits for EVERY outstanding LDS
+// read in front of the first use of ANY of them (lgkmcnt(0) where lgkmcnt(8) was meant; /tmp-sized reproducer in profiles/r06_student_b1_reading.md):
+// a register-level look-ahead of the A fragments then hides nothing.  lds_read16 issues the ds_read_b128 from inline asm - the compiler neither
+// tracks nor waits for it - and lds_wait<N>() is the explicit `s_waitcnt lgkmcnt(N)`: LDS operations of a wave return in order, so "at most N newer
+// reads outstanding" means every older one has landed.  OFF must be a constant expression (static_for below).  Compiler-issued LDS operations
+// around these stay correct: their own waits can only become stricter by the extra outstanding reads.
+#ifdef THA4_EMU
+template <int OFF>
+THA4_DEV void lds_read16(tha4::f16x8& dst, const char* base) { dst = *reinterpret_cast<const tha4::f16x8*>(base + OFF); }
+template <int N>
+THA4_DEV void lds_wait(tha4::f16x8&, tha4::f16x8&) {}
+template <int N>
+THA4_DEV void lds_wait(tha4::f16x8&, tha4::f16x8&, tha4::f16x8&, tha4::f16x8&) {}
+template <int N>
+THA4_DEV void lds_wait(tha4::f16x8&, tha4::f16x8&, tha4::f16x8&, tha4::f16x8&, tha4::f16x8&, tha4::f16x8&) {}
+#else
+template <int OFF>
+THA4_DEV void lds_read16(tha4::f16x8& dst, const char* base) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 takes a 16-bit offset");
+  const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)base;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// (the fragments the wait is FOR are in/out operands: whatever consumes them is ordered behind the wait by data dependence, not by the goodwill of a scheduler)
+template <int N>
+THA4_DEV void lds_wait(tha4::f16x8& a, tha4::f16x8& b) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+THA4_DEV void lds_wait(tha4::f16x8& a, tha4::f16x8& b, tha4::f16x8& c, tha4::f16x8& d) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+THA4_DEV void lds_wait(tha4::f16x8& a, tha4::f16x8& b, tha4::f16x8& c, tha4::f16x8& d, tha4::f16x8& e, tha4::f16x8& f) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
+}
+#endif
+// 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc1): the line leaves the XCD's L2 as it is written instead of waiting dirty for the kernel
+// boundary.  For hand-off images whose reader is the NEXT kernel on other XCDs (z1 / z2 of the student, 12.6 / 25.2 MB per frame): a plain store leaves
+// them dirty and the boundary then costs bytes / ~6 TB/s on top of its ~1.5 us (MI355X_MICROARCH.md, "boundary" and "publish-large" rows).
+#ifndef THA4_Z_WRITE_THROUGH
+#define THA4_Z_WRITE_THROUGH 1
+#endif
+THA4_DEV void store16_wt(void* p, const tha4::f32x4& v) {
+#if defined(THA4_EMU) || !THA4_Z_WRITE_THROUGH
+  *reinterpret_cast<tha4::f32x4*>(p) = v;
+#else
+  // (s_nop 1: a store of more than 8 bytes reads its data registers a few cycles after issue - the compiler pads its own stores against a following
+  //  overwrite of those registers, but cannot see this one)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (the index is a constant expression inside f)
+template <int I, int N, class F>
+THA4_DEV void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}

@@ -82,8 +82,14 @@ VARIANTS = {
     "l1regs0": ["-DTHA4_L1_REGS=0"], "l1r816": ["-DTHA4_L116R_CFG=8,1,6"], "l1r413": ["-DTHA4_L116R_CFG=4,1,3"], "l1r824": ["-DTHA4_L116R_CFG=8,2,4"],
     "l1r823": ["-DTHA4_L116R_CFG=8,2,3"],
     # round 6: face + level 0 as two 4-wave register-resident workgroups per CU (front16r_kernel<level-0 blocks per chunk, level-0 slots, face slots>)
-    "frontregs0": ["-DTHA4_FRONT_REGS=0"], "fr664": ["-DTHA4_FRONT16R_CFG=6,6,4"], "fr1233": ["-DTHA4_FRONT16R_CFG=12,3,3"], "fr1232": ["-DTHA4_FRONT16R_CFG=12,3,2"],
+    "frontregs0": ["-DTHA4_FRONT_REGS=0"], "fr6649": ["-DTHA4_FRONT16R_CFG=6,6,4,9"], "fr12384": ["-DTHA4_FRONT16R_CFG=12,3,8,4"], "fr6584": ["-DTHA4_FRONT16R_CFG=6,5,8,4"],
+    "zwt0": ["-DTHA4_Z_WRITE_THROUGH=0"],         # plain instead of write-through (sc1) stores of the z1 / z2 hand-off images
+    "spread0": ["-DTHA4_RING_SPREAD=0"],          # the LDS-DMA copies a ring barrier releases in a burst behind it instead of one per step under the MFMAs
     "allregs0": ["-DTHA4_FRONT_REGS=0", "-DTHA4_L1_REGS=0"],
+    "cwait": ["-DTHA4_NEVER_BUILT_HERE"],                                           # (a copy of an earlier build kept for a same-box A/B: never rebuilt by `build`)
+    "stamps": ["-DTHA4_STAMPS"],                                                  # in-kernel time stamps (tools/stamps_student.py)
+    "pf1": ["-DTHA4_REGS_PREFETCH=1"], "pf3": ["-DTHA4_REGS_PREFETCH=3"],        # A-fragment look-ahead of the register-resident kernels in steps (default 2)
+    "l1r423": ["-DTHA4_L116R_CFG=4,2,3"], "tap3": ["-DTHA4_TAP_BATCH=3"], "tap6": ["-DTHA4_TAP_BATCH=6"],
 }
 if os.environ.get("THA4_SWEEP_VARIANTS"):      # comma-separated subset
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["THA4_SWEEP_VARIANTS"].split(",")}

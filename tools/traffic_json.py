@@ -16,7 +16,7 @@ import os
 from collections import defaultdict
 
 STUDENT = {"posebias_kernel": "posebias", "face16_kernel": "face", "level0_16_kernel": "level0", "level1_16_kernel": "level1",
-           "level2_16p_kernel": "level2", "level2_16_kernel": "level2", "front16_kernel": "front"}
+           "level2_16p_kernel": "level2", "level2_16_kernel": "level2", "front16_kernel": "front", "front16r_kernel": "front", "level1_16r_kernel": "level1"}
 
 
 def per_kernel(d, counter):
