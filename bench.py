@@ -42,6 +42,9 @@ from tha4_amd.weights import split_flat_weights  # noqa: E402
 # Algorithmic work of the reference's forward passes as written (SURVEY.md §8d, 2*MAC), per 512x512 frame and per
 # kernel of the student implementation.
 GFLOP_FRAME = 37.885
+# HBM bytes a launch of each student kernel cannot avoid in this design, per frame: fp32 hand-off images z1 [192 ch x 128^2] = 12.58 MB and
+# z2 [96 ch x 256^2] = 25.17 MB, the 128^2 face patch, the frame in and the posed frame out (4.19 MB each), the kernel's packed weights once
+ALGO_BYTES_KERNEL = {"front": 12.58e6 + 0.26e6 + 1.50e6, "level1": 12.58e6 + 25.17e6 + 0.26e6, "level2": 25.17e6 + 2 * 4.19e6 + 0.26e6 + 0.08e6}
 GFLOP_KERNEL = {"face": 3.947, "level0": 6.924, "level1": 11.726, "level2": 15.288}
 # What the student kernels actually execute after pose folding + commuting the x2 upsample with the next level's
 # first layer: stated separately, never used for `roofline.achieved`.
@@ -121,11 +124,19 @@ def roofline_evidence(roofline, dom, gflop_launch, event_ms, B):
     ev = {}
     short = dom.split(" ")[0]
     traffic = roofline.get("traffic")
-    if traffic:
-        ai = gflop_launch * 1e9 / traffic
+    # the roof the kernel sits under follows from its ALGORITHMIC intensity: as-written FLOP of the launch / the HBM bytes the launch cannot avoid in this
+    # design (its hand-off images, the frame in and out, its weights once).  The counted traffic (2-4x that: re-fetched upsample rows across XCDs) is
+    # reported beside it - it prices waste, it does not move the kernel to the other roof (at 1.3 TB/s of 8 the HBM roof is 6x away)
+    algo = ALGO_BYTES_KERNEL.get(short)
+    ev["ridge_flop_per_byte"] = round(PEAK_F16_MFMA_TFLOPS * 1e12 / 8.0e12, 1)
+    if algo:
+        ai = gflop_launch * 1e9 / (algo * B)
+        ev["algorithmic_bytes"] = int(algo * B)
         ev["arithmetic_intensity_flop_per_byte"] = round(ai, 1)
-        ev["ridge_flop_per_byte"] = round(PEAK_F16_MFMA_TFLOPS * 1e12 / 8.0e12, 1)
         ev["bound"] = "mfma" if ai >= ev["ridge_flop_per_byte"] else "hbm"
+    if traffic:
+        ev["counted_intensity_flop_per_byte"] = round(gflop_launch * 1e9 / traffic, 1)
+        ev["hbm_frac_counted"] = round(traffic / (event_ms * 1e-3) / 8.0e12, 4)
     rp = roofline.get("kernel_ms_rocprof") or {}
     ms = (rp.get("avg_ms") or {}).get(dom)
     if ms:
@@ -151,6 +162,19 @@ def roofline_evidence(roofline, dom, gflop_launch, event_ms, B):
     else:
         ev["limiter"] = "unknown: no PMC capture committed for this kernel (tools/pmc_json.py)"
     return ev
+
+
+def exchange_identity(backend):
+    """What the multi-rank exchange ran on, for a reader who only has the JSON line: library version and every environment variable that steers it."""
+    out = {"backend": backend, "torch": torch.__version__,
+           "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "TORCH_NCCL_", "HSA_", "GLOO_", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE"))}}
+    if backend == "nccl":
+        try:
+            out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:             # noqa: BLE001
+            out["rccl_version"] = f"unavailable: {e}"
+        out["devices"] = torch.cuda.device_count()
+    return out
 
 
 def cpu_model_string():
@@ -295,6 +319,8 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
     cuda = dev.type == "cuda"
     if variant is None:
         variant = "none" if args.no_gather else ("rgba8" if args.rgba8_gather else "fp32")
+    if not hasattr(work, "exchange_log"):
+        work.exchange_log = {}
     gather = world > 1 and variant != "none"
     rgba8 = variant == "rgba8"
     if rehearse is None:
@@ -345,8 +371,12 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
                     step(0, out=blk[f:f + B])
                 return blk
 
-            if rehearse:
+            if rehearse:          # timed from outside the region: the first one of a run carries RCCL's connection set-up
+                barrier()
+                tr = time.perf_counter()
                 FrameShardedStream(rehearsal_fn, total=(chunk + B) * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True).run()
+                barrier()
+                work.exchange_log.setdefault(variant, {}).setdefault("rehearsal_s", []).append(round(time.perf_counter() - tr, 4))
             if return_frames:              # tests: archive the whole (short) stream on rank 0
                 stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True,
                                             schedule=schedule)
@@ -360,7 +390,7 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
                     work.delivered += hi - lo
 
                 stream = FrameShardedStream(frame_fn, total=K * B * world, frame_shape=shape, dtype=dtype, device=dev, chunk=chunk, gather=True,
-                                            on_chunk=consume, ring_slots=3, schedule=schedule)
+                                            on_chunk=consume, ring_slots=3, schedule=schedule, record_rounds=True)
                 work.ring_bytes = stream.ring_bytes()
                 gathered = None
             barrier()
@@ -372,6 +402,10 @@ def measure(work, args, dev, rank, world, K, W, B, dist, return_frames=False, fr
                 frames = gathered
             elif rank == 0 and work.delivered != K * B * world:
                 raise RuntimeError(f"gather delivered {work.delivered} of {K * B * world} frames")
+            if not return_frames:      # what THIS form of the exchange held and did (the next variant's region overwrites work.ring_bytes / .delivered)
+                log = work.exchange_log.setdefault(variant, {})
+                log["ring_bytes"], log["delivered"] = work.ring_bytes, work.delivered
+                log["rounds"] = stream.round_report()          # the last region of the variant (outside the clock: it synchronises)
             del gathered
         else:
             barrier()
@@ -386,22 +420,28 @@ def run_regions(work, args, dev, rank, world, K, W, B, dist):
     """The timed regions of one bench run: `value`'s region, its `--repeats`, and - N > 1 - the same K steps under each form of the
     exchange.  Returns (elapsed of the first region, frames/s of the repeats, per-variant dict or None, name of the primary form).
     Shared by the real run and `--stub-gloo` (tests)."""
+    per_rank = {}                          # variant -> the ranks' own seconds of its last region (first-contact diagnostics, N > 1)
+
     def region(**kw):                      # one timed region: this rank's seconds -> maximum over ranks
         e = measure(work, args, dev, rank, world, K, W, B, dist, **kw)
         if world > 1:
-            t = torch.tensor([e], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e = float(t.item())
+            t = torch.zeros(world, dtype=torch.float64, device=dev)
+            t[rank] = e
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            es = [float(x) for x in t.tolist()]
+            per_rank[kw.get("variant") or primary] = es
+            e = max(es)
         return e
 
+    primary = "none" if args.no_gather else ("rgba8" if args.rgba8_gather else "fp32")
     elapsed = region()
+    primary_rank_seconds = list(per_rank.get(primary, []))
     # `value` is the region above; the SAME K steps are timed `--repeats` more times so that a short region (20 steps of the student
     # stream = 2.5 ms) carries its own spread.  Same barriers, maximum over ranks per repeat.
     rep_fps = [K * B * world / region(fresh=False) for _ in range(max(0, args.repeats))]
     # N > 1: the same K steps under each form of the exchange - fp32 frames (what Poser.pose() returns: the default and `value`),
     # RGBA8 frames (display epilogue fused into the composing kernel: a quarter of the bytes) and no exchange at all - so that a
     # scaling figure below target is attributable to the gather (xGMI / root ingest) or to the compute path (round-4 review)
-    primary = "none" if args.no_gather else ("rgba8" if args.rgba8_gather else "fp32")
     variants = None
     if world > 1:
         variants = {}
@@ -416,6 +456,16 @@ def run_regions(work, args, dev, rank, world, K, W, B, dist):
             variants[v] = {"fps": round(K * B * world / e, 2), "per_gpu_fps": round(K * B / e, 2), "regions": len(es),
                            "root_ingest_GBps": round((world - 1) * K * B * frame_bytes / e / 1e9, 2),
                            "per_sender_GBps": round(K * B * frame_bytes / e / 1e9, 2)}
+            rs = primary_rank_seconds if v == primary else per_rank.get(v, [])
+            if rs:                         # every rank's OWN clock over its K steps (the line's time is their maximum): a slow rank / a slow link shows here
+                rf = [K * B / x for x in rs]
+                variants[v]["per_rank_fps"] = {"min": round(min(rf), 2), "max": round(max(rf), 2), "slowest_rank": int(np.argmin(rf)), "all": [round(x, 2) for x in rf],
+                                               "what": "first region for the primary form, last region otherwise"}
+            log = getattr(work, "exchange_log", {}).get(v, {})
+            if v != "none":                # rank 0's view of the exchange, round by round (events on the gather's side stream)
+                variants[v]["root_ring_bytes"] = log.get("ring_bytes")
+                variants[v]["rehearsal_s"] = log.get("rehearsal_s")
+                variants[v]["rounds"] = log.get("rounds")
     return elapsed, rep_fps, variants, primary
 
 
@@ -493,14 +543,15 @@ def main():
                          "all": [round(v, 2) for v in rep_fps]} if rep_fps else None)}
         par = {"frames_per_gpu": K * B, "batch": B, "parallelism": f"frame-parallel x{world}",
                "gather": ("rgba8 (display epilogue fused into the composing kernel)" if args.rgba8_gather else "fp32") if gather else False}
-        if gather:
-            par["gather_root_ring_bytes"] = getattr(work, "ring_bytes", None)
+        if gather:                        # the PRIMARY form's ring (each variant's own is in gather_variants[v].root_ring_bytes)
+            par["gather_root_ring_bytes"] = getattr(work, "exchange_log", {}).get(primary, {}).get("ring_bytes", getattr(work, "ring_bytes", None))
         if variants is not None:
             sched = getattr(work, "gather_schedule", None)
             par["gather_schedule"] = ({"frames_per_round": sched, "rounds": len(sched),
                                        "unoverlapped_tail_fraction": round(sched[-1] / max(1, K * B), 4),
                                        "what": "frames of every rank per gather round; round c's exchange runs on a side stream under round c+1's compute, "
                                                "only the last round's is exposed (sharding.tapered_schedule)"} if sched else None)
+            result["exchange"] = exchange_identity("nccl")
             result["gather_variants"] = dict(variants, value_is=primary,
                                              what="median of the timed regions of the same K steps under each form of the exchange to rank 0 (whole-job frames/s); "
                                                   "root_ingest_GBps = bytes arriving at rank 0 from the other ranks / region time; `value` is the "
@@ -568,12 +619,13 @@ def stub_gloo_main(args, rank, world):
                           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 5), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
                           "gather_variants": dict(variants, value_is=primary) if variants else None,
+                          "exchange": exchange_identity("gloo") if world > 1 else None,
                           "config": {"workload": "stub (tests/test_bench_launch_gloo.py)", "frames_per_gpu": K * B, "batch": B,
                                      "parallelism": f"frame-parallel x{world}",
                                      "gather": ("rgba8" if args.rgba8_gather else "fp32") if gather else False,
                                      "gather_schedule": sched if world > 1 else None,
-                                     "gather_root_ring_bytes": getattr(work, "ring_bytes", None) if gather else None,
-                                     "delivered": getattr(work, "delivered", None) if gather else None}}), flush=True)
+                                     "gather_root_ring_bytes": getattr(work, "exchange_log", {}).get(primary, {}).get("ring_bytes") if gather else None,
+                                     "delivered": getattr(work, "exchange_log", {}).get(primary, {}).get("delivered") if gather else None}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

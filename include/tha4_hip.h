@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THA4_ABI_VERSION 5
+#define THA4_ABI_VERSION 6
 
 typedef enum tha4_status {
   THA4_OK = 0,
@@ -203,8 +203,19 @@ int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image
  *                         activate; tha4_full_numeric_status reports a violation): ~2.5-3x faster, within 1e-3 of this plan on
  *                         every tested parameter set.  This is the plan to re-create the handle with when THA4_ERR_NUMERIC_RANGE
  *                         is reported for weights / inputs that are legitimate in fp32 (the reference computes in plain fp32,
- *                         mode_07.py:137-315 loads whatever the .pt files hold). */
+ *                         mode_07.py:137-315 loads whatever the .pt files hold).
+ *   THA4_FULL_EXACT_DECOMPOSER (ABI v6)  the MIXED plan: only the eyebrow decomposer (eyebrow_decomposer_00.py:46-64; network 0) on the exact-fp32
+ *                         kernels, everything else on the default fp16 hi/lo plan.  Attribution of the split's share of the posed frame's
+ *                         error (fp64 oracle, profiles/parity_r06/): the decomposer carries ~90 % of it (its outputs are thresholded layers the
+ *                         four later networks all consume), the two U-Nets < 3 %.  The reference caches the decomposer's outputs while the
+ *                         image is unchanged (mode_07.py:56-67) and so does this library: the flag costs nothing per steady frame and one
+ *                         slower decomposer pass per new image.  Ignored (implied) with THA4_FULL_EXACT_FP32.
+ *   THA4_FULL_EXACT_DECOMPOSER_OUTER (ABI v6)  the same for the decomposer's first, down-sampling, up-sampling and head convolutions only; the eleven
+ *                         512 -> 512 convolutions of its 16x16 bottleneck (a fifth of its share of the error, most of its launches) stay on the
+ *                         default plan.  Ignored (implied) with either flag above. */
 #define THA4_FULL_EXACT_FP32 1u
+#define THA4_FULL_EXACT_DECOMPOSER 2u
+#define THA4_FULL_EXACT_DECOMPOSER_OUTER 4u
 int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
                         int num_networks, uint32_t flags, tha4_full** out);
 /* The flags the handle was created with. */

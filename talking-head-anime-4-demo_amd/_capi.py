@@ -15,9 +15,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtha4_hip.so")
 
-THA4_ABI_VERSION = 5
+THA4_ABI_VERSION = 6
 STUDENT_EXACT_FP32 = 1
 FULL_EXACT_FP32 = 1
+FULL_EXACT_DECOMPOSER = 2
+FULL_EXACT_DECOMPOSER_OUTER = 4
 
 c_float_p = C.POINTER(C.c_float)
 

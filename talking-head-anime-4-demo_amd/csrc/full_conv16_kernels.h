@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
       if (!inside[pg]) continue;                            // ragged tile: position outside the map
       if (THA4_HOOK_TILE_EPILOGUE_BYPASS && acc[b][pg][0] != 1.2345e33f) continue;     // tuning builds only
       const f32x4 v = acc[b][pg];
-      *reinterpret_cast<f32x4*>(a.out + offs[b][pg]) = v;
+      store16_out(a.out + offs[b][pg], v);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ssum[b][j] += v[j]; ssq[b][j] = fmaf(v[j], v[j], ssq[b][j]); }
     }

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(kPointThreads) conv_point_kernel(ConvArgs a) {
     for (int pg = 0; pg < PG; ++pg) {
       if (!inside[pg]) continue;                           // ragged last tile
       const f32x4 v = acc[b][pg];
-      *reinterpret_cast<f32x4*>(a.out + offs[b][pg]) = v;
+      store16_out<(THA4_POINT_OUT_WT != 0)>(a.out + offs[b][pg], v);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ssum[b][j] += v[j]; ssq[b][j] = fmaf(v[j], v[j], ssq[b][j]); }
     }

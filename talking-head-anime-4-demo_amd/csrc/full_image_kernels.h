@@ -64,6 +64,20 @@ struct ImgArgs {
   float rgba8_bg[3];
 };
 
+// NCHW outputs the caller did not ask for and no later stage reads are null (round 6; tha4_full_pose_ex: Poser.pose() wants ONE of the 33): their stores are
+// skipped - a wave-uniform branch on a kernel-argument pointer.  (Rounds 1-5 wrote all 33 into scratch: 11 of the 15 output planes of the upscaler's tail,
+// 15.7 MB per frame, for a caller that reads the posed frame only.)
+THA4_DEV void put(float* plane, size_t off, float v) {
+  if (plane) plane[off] = v;
+}
+// one pixel's 16 channels of a C16 tensor as four 16-byte stores (a lane's 64 bytes are contiguous: a wave writes 4 KiB runs)
+THA4_DEV void put_c16(float* co, const f32x4& v0, const f32x4& v1, const f32x4& v2, const f32x4& v3) {
+  reinterpret_cast<f32x4*>(co)[0] = v0;
+  reinterpret_cast<f32x4*>(co)[1] = v1;
+  reinterpret_cast<f32x4*>(co)[2] = v2;
+  reinterpret_cast<f32x4*>(co)[3] = v3;
+}
+
 // the head block of a network (16 floats per pixel, padded channels are exact zeros) must be finite: a staged operand beyond
 // the fp16 range, or a NaN from the weights, that no normalisation saw on its way here ends up in it
 THA4_DEV void check_head_finite(const float* h, int* fault) {
@@ -112,23 +126,24 @@ __global__ void __launch_bounds__(256) decomposer_tail_kernel(ImgArgs a) {
   check_head_finite(h, a.fault);
   const float bga = h[0], eba = h[5];
   float* co = a.c16_out + ((size_t)n * P + idx) * 16;
+  f32x4 vbg, veb;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float im = img[((size_t)c * 512 + 64 + y) * 512 + 192 + x];
     const float bgc = h[1 + c], ebc = h[6 + c];
     const float bg = bgc * bga + im * (1.0f - bga);
     const float eb = im * eba + ebc * (1.0f - eba);      // apply_color_change(alpha, image, colour): swapped (:55)
-    a.out[0][((size_t)n * 4 + c) * P + idx] = eb;
-    a.out[2][((size_t)n * 4 + c) * P + idx] = ebc;
-    a.out[3][((size_t)n * 4 + c) * P + idx] = bg;
-    a.out[5][((size_t)n * 4 + c) * P + idx] = bgc;
-    co[c] = bg;
-    co[4 + c] = eb;
+    vbg[c] = bg;
+    veb[c] = eb;
+    put(a.out[0], ((size_t)n * 4 + c) * P + idx, eb);
+    put(a.out[2], ((size_t)n * 4 + c) * P + idx, ebc);
+    put(a.out[3], ((size_t)n * 4 + c) * P + idx, bg);
+    put(a.out[5], ((size_t)n * 4 + c) * P + idx, bgc);
   }
-  a.out[1][(size_t)n * P + idx] = eba;
-  a.out[4][(size_t)n * P + idx] = bga;
-#pragma unroll
-  for (int c = 8; c < 16; ++c) co[c] = 0.0f;
+  put(a.out[1], (size_t)n * P + idx, eba);
+  put(a.out[4], (size_t)n * P + idx, bga);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  put_c16(co, vbg, veb, z, z);
 }
 
 // stage 2 tail (eyebrow_morphing_combiner_00.py:47-72).  head rows: 0-1 grid | 2 alpha | 3-6 colour | 7 combine_alpha.
@@ -156,16 +171,16 @@ __global__ void __launch_bounds__(256) combiner_tail_kernel(ImgArgs a) {
   for (int c = 0; c < 4; ++c) {
     const float b = bg[(size_t)c * P + idx];
     const size_t o = ((size_t)n * 4 + c) * P + idx;
-    a.out[0][o] = c < 3 ? morphed[c] * ca + b * (1.0f - ca) : b;      // apply_rgb_change keeps the image's alpha
-    a.out[2][o] = c < 3 ? morphed[c] * a2 + b * (1.0f - a2) : b;
-    a.out[3][o] = morphed[c];
-    a.out[5][o] = h[3 + c];
-    a.out[6][o] = warped[c];
+    put(a.out[0], o, c < 3 ? morphed[c] * ca + b * (1.0f - ca) : b);      // apply_rgb_change keeps the image's alpha
+    put(a.out[2], o, c < 3 ? morphed[c] * a2 + b * (1.0f - a2) : b);
+    put(a.out[3], o, morphed[c]);
+    put(a.out[5], o, h[3 + c]);
+    put(a.out[6], o, warped[c]);
   }
-  a.out[1][(size_t)n * P + idx] = ca;
-  a.out[4][(size_t)n * P + idx] = al;
-  a.out[7][((size_t)n * 2 + 0) * P + idx] = gxc;
-  a.out[7][((size_t)n * 2 + 1) * P + idx] = gyc;
+  put(a.out[1], (size_t)n * P + idx, ca);
+  put(a.out[4], (size_t)n * P + idx, al);
+  put(a.out[7], ((size_t)n * 2 + 0) * P + idx, gxc);
+  put(a.out[7], ((size_t)n * 2 + 1) * P + idx, gyc);
 }
 
 // stage 3 input (mode_07.py:85-90): image[:, :, 32:224, 160:352] with [32:160, 32:160] <- combiner output `sel`.
@@ -178,15 +193,16 @@ __global__ void __launch_bounds__(256) face_input_kernel(ImgArgs a) {
   const float* img = a.image + (size_t)n * a.image_stride;
   const bool in_eb = (unsigned)(y - 32) < 128u && (unsigned)(x - 32) < 128u;
   float* co = a.c16_out + ((size_t)n * P + idx) * 16;
+  f32x4 vv;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float v = in_eb ? a.in0[((size_t)n * 4 + c) * 128 * 128 + (size_t)(y - 32) * 128 + (x - 32)]
                           : img[((size_t)c * 512 + 32 + y) * 512 + 160 + x];
-    a.out[0][((size_t)n * 4 + c) * P + idx] = v;
-    co[c] = v;
+    put(a.out[0], ((size_t)n * 4 + c) * P + idx, v);
+    vv[c] = v;
   }
-#pragma unroll
-  for (int c = 4; c < 16; ++c) co[c] = 0.0f;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  put_c16(co, vv, z, z, z);
 }
 
 // stage 3 tail (face_morpher_08.py:158-193).  head rows: 0-1 grid | 2-5 iris colour | 6 iris alpha | 7-10 eye colour | 11 eye alpha.
@@ -209,16 +225,16 @@ __global__ void __launch_bounds__(256) face_tail_kernel(ImgArgs a) {
     const float im1 = icc * ia + im0 * (1.0f - ia);
     const float o = ecc * ea + im1 * (1.0f - ea);
     const size_t off = ((size_t)n * 4 + c) * P + idx;
-    a.out[0][off] = o;
-    a.out[2][off] = ecc;
-    a.out[3][off] = im1;
-    a.out[5][off] = icc;
-    a.out[6][off] = im0;
+    put(a.out[0], off, o);
+    put(a.out[2], off, ecc);
+    put(a.out[3], off, im1);
+    put(a.out[5], off, icc);
+    put(a.out[6], off, im0);
   }
-  a.out[1][(size_t)n * P + idx] = ea;
-  a.out[4][(size_t)n * P + idx] = ia;
-  a.out[7][((size_t)n * 2 + 0) * P + idx] = gxc;
-  a.out[7][((size_t)n * 2 + 1) * P + idx] = gyc;
+  put(a.out[1], (size_t)n * P + idx, ea);
+  put(a.out[4], (size_t)n * P + idx, ia);
+  put(a.out[7], ((size_t)n * 2 + 0) * P + idx, gxc);
+  put(a.out[7], ((size_t)n * 2 + 1) * P + idx, gyc);
 }
 
 // mode_07.py:93-103: face_morphed_full = image with [32:224, 160:352] <- face output (in0, [B][4][192][192]);
@@ -234,7 +250,7 @@ __global__ void __launch_bounds__(256) paste_face_kernel(ImgArgs a) {
   for (int c = 0; c < 4; ++c) {
     const float v = in_face ? a.in0[((size_t)n * 4 + c) * 192 * 192 + (size_t)(y - 32) * 192 + (x - 160)]
                             : img[((size_t)c * S + y) * S + x];
-    a.out[0][((size_t)n * 4 + c) * P + idx] = v;
+    put(a.out[0], ((size_t)n * 4 + c) * P + idx, v);
   }
 }
 
@@ -246,17 +262,18 @@ __global__ void __launch_bounds__(256) half_image_kernel(ImgArgs a) {
   if (idx >= P) return;
   const int y = idx / S, x = idx % S;
   float* co = a.c16_out + ((size_t)n * P + idx) * 16;
+  f32x4 vv;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float* pl = a.in0 + ((size_t)n * 4 + c) * 512 * 512;
     const float t0 = 0.5f * pl[(size_t)(2 * y) * 512 + 2 * x] + 0.5f * pl[(size_t)(2 * y) * 512 + 2 * x + 1];
     const float t1 = 0.5f * pl[(size_t)(2 * y + 1) * 512 + 2 * x] + 0.5f * pl[(size_t)(2 * y + 1) * 512 + 2 * x + 1];
     const float v = 0.5f * t0 + 0.5f * t1;
-    a.out[0][((size_t)n * 4 + c) * P + idx] = v;
-    co[c] = v;
+    put(a.out[0], ((size_t)n * 4 + c) * P + idx, v);
+    vv[c] = v;
   }
-#pragma unroll
-  for (int c = 4; c < 16; ++c) co[c] = 0.0f;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  put_c16(co, vv, z, z, z);
 }
 
 // U-Net tail of the body morpher (S=256) and the upscaler (S=512) (morpher_00.py:53-66, upscaler_02.py:85-96).
@@ -281,9 +298,9 @@ __global__ void __launch_bounds__(256) unet_tail_kernel(ImgArgs a) {
     const float d = h[c];
     const size_t off = ((size_t)n * 4 + c) * P + idx;
     merged[c] = d * al + w * (1.0f - al);
-    a.out[0][off] = merged[c];
-    a.out[2][off] = w;
-    a.out[4][off] = d;
+    put(a.out[0], off, merged[c]);
+    put(a.out[2], off, w);
+    put(a.out[4], off, d);
   }
   if (a.rgba8) {            // display epilogue on the values in registers: one packed 4-byte store per pixel
     const float a01 = fminf(fmaxf((merged[3] + 1.0f) * 0.5f, 0.0f), 1.0f);
@@ -294,9 +311,9 @@ __global__ void __launch_bounds__(256) unet_tail_kernel(ImgArgs a) {
     o.w = display_channel(merged[3], 3, a01, a.rgba8_has_bg != 0, 0.0f);
     reinterpret_cast<uchar4*>(a.rgba8)[(size_t)n * P + idx] = o;
   }
-  a.out[1][(size_t)n * P + idx] = al;
-  a.out[3][((size_t)n * 2 + 0) * P + idx] = gxc;
-  a.out[3][((size_t)n * 2 + 1) * P + idx] = gyc;
+  put(a.out[1], (size_t)n * P + idx, al);
+  put(a.out[3], ((size_t)n * 2 + 0) * P + idx, gxc);
+  put(a.out[3], ((size_t)n * 2 + 1) * P + idx, gyc);
 }
 
 // upscaler input (mode_07.py:108-118, upscaler_02.py:78-83): in0 = rest (face_morphed_full) NCHW 512^2,
@@ -313,16 +330,15 @@ __global__ void __launch_bounds__(256) upscaler_input_kernel(ImgArgs a) {
   const float gxc = up2_sample(grid, 256, x, y), gyc = up2_sample(grid + 256 * 256, 256, x, y);
   const float gx = axis_pos(x, S) + gxc, gy = axis_pos(y, S) + gyc;
   float* co = a.c16_out + ((size_t)n * P + idx) * 16;
+  f32x4 v0, v1, v2;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    co[c] = rest[(size_t)c * P + idx];
-    co[4 + c] = up2_sample(merged + (size_t)c * 256 * 256, 256, x, y);
-    co[8 + c] = sample_border(rest, S, S, c, gx, gy);
+    v0[c] = rest[(size_t)c * P + idx];
+    v1[c] = up2_sample(merged + (size_t)c * 256 * 256, 256, x, y);
+    v2[c] = sample_border(rest, S, S, c, gx, gy);
   }
-  co[12] = gxc;
-  co[13] = gyc;
-  co[14] = 0.0f;
-  co[15] = 0.0f;
+  const f32x4 v3 = {gxc, gyc, 0.0f, 0.0f};
+  put_c16(co, v0, v1, v2, v3);
 }
 
 }  // namespace tha4

@@ -78,6 +78,11 @@ class FullModel {
   // v_mfma_f32_16x16x4_f32 on fp32 operands, no fp16 hi/lo staging and therefore no 65504 operand limit), every normalisation
   // through norm_finalize_kernel.  The plan a caller falls back to when the numeric-range guard of the default plan trips.
   bool exact_fp32 = false;
+  // THA4_FULL_EXACT_DECOMPOSER (round 6): the mixed plan - exact_fp32 is raised while network 0 is planned and lowered again behind it.
+  // exact_decomposer_outer (THA4_FULL_EXACT_DECOMPOSER_OUTER): the same for every convolution of network 0 EXCEPT the eleven 512 -> 512 convolutions of
+  // its 16x16 bottleneck (they carry a fifth of the decomposer's share of the error and most of its launches)
+  bool exact_decomposer = false, exact_decomposer_outer = false;
+  bool bottleneck_on_split = false;      // planning state: inside network 0 of an "outer" mixed plan
 
   // ---- arenas -------------------------------------------------------------------------------
   std::vector<char> host_params;     // packed parameters, uploaded once
@@ -139,7 +144,7 @@ class FullModel {
   struct Frame {            // per-call bindings
     const float* image; long long image_stride; const float* pose; int batch; hipStream_t stream;
     hipStream_t side;       // second stream of the handle for independent side branches (null: everything on `stream`)
-    float* out[33];         // NCHW outputs in the reference order (never null: unrequested ones point into scratch)
+    float* out[33];         // NCHW outputs in the reference order; null = not requested and read by no later stage (the kernels skip its stores)
     unsigned char* rgba8; int rgba8_has_bg; float rgba8_bg[3];    // fused display epilogue of out[0] (tha4_display) or null
   };
   using Op = std::function<void(const Frame&)>;
@@ -207,6 +212,10 @@ class FullModel {
     note(ops, "side-stream join");
   }
   size_t scratch_out[33];   // workspace offsets used for outputs the caller did not ask for
+  // outputs of the 33-entry list that a later stage of the pipeline reads back (build() below): the combiner image the face morpher's input is pasted from
+  // (19 + sel), the face morpher's output_image (11 -> paste_face), face_morphed_full (5 -> half image, upscaler input, the upscaler's warp source), the
+  // body morpher's merged image and grid (6, 9 -> upscaler input).  Everything else is a leaf: unrequested, it is not written at all.
+  bool read_by_later_stage(int i) const { return i == 5 || i == 6 || i == 9 || i == 11 || i == 19 + sel_index; }
   int out_ch[33], out_size[33];
 
   // ---- weights --------------------------------------------------------------------------------
@@ -850,6 +859,10 @@ class FullModel {
     }
     std::vector<Src> s0 = {src_tensor(x, 512, px)};
     if (pose_count > 0) s0.push_back(src_vector(pose_vec_off, (pose_count + 15) / 16, pose_count));
+    // "outer" mixed plan: the bottleneck (convolutions AND the normalisations between them) on the default fp16 hi/lo plan.  The normalisation in front of it
+    // was planned exact (a finalize launch: every kernel can consume its scale / shift vectors), the one tensor leaving it is a plain sum (affine_add)
+    struct Lower { bool& f; bool saved; ~Lower() { f = saved; } } lower{exact_fp32, exact_fp32};
+    if (bottleneck_on_split) exact_fp32 = false;
     x = conv(ops, K_SAME3, s0, IN_DIRECT, ACT_RELU, W("bottleneck_blocks.0.0.weight"), nullptr, 512, true);
     px = norm(ops, {x}, 512, 0, W("bottleneck_blocks.0.1.weight"), W("bottleneck_blocks.0.1.bias"))[0];
     int act_x = ACT_RELU;       // x is "raw + pending IN/ReLU" after block 0, a plain tensor after every ResnetBlock
@@ -863,6 +876,7 @@ class FullModel {
       px = Pending();
       act_x = ACT_NONE;
     }
+    exact_fp32 = lower.saved;
     for (int i = 0; i < 3; ++i) {
       const std::string b = "upsample_blocks." + std::to_string(i);
       x = conv(ops, K_CONVT, {src_tensor(x, c, px)}, IN_DIRECT, act_x, W(b + ".0.weight"), nullptr, c / 2, true);
@@ -1107,6 +1121,10 @@ class FullModel {
 
     // 1. eyebrow decomposer (its outputs are cached by the caller while the image is unchanged, mode_07.py:56-67)
     {
+      struct Raise { bool& f; bool saved; ~Raise() { f = saved; } } raise{exact_fp32, exact_fp32};      // mixed plan: this network only on the exact-fp32 kernels
+      struct Flag { bool& f; ~Flag() { f = false; } } lower{bottleneck_on_split};
+      bottleneck_on_split = !exact_fp32 && !exact_decomposer && exact_decomposer_outer;
+      exact_fp32 = exact_fp32 || exact_decomposer || exact_decomposer_outer;
       auto& ops = ops_decomposer;
       FTensor x = new_tensor(1, 128, 128);
       image_op(ops, crop_eyebrow_kernel, 128 * 128, [=](const Frame&, ImgArgs& a) { a.c16_out = Wk(x.off); });

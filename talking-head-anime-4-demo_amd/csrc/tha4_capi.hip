@@ -520,7 +520,7 @@ int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image
 int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
                         int num_networks, uint32_t flags, tha4_full** out) {
   if (!weights || !out) return fail(THA4_ERR_INVALID_ARGUMENT, "weights/out must not be NULL");
-  if (flags & ~(uint32_t)THA4_FULL_EXACT_FP32) return fail(THA4_ERR_INVALID_ARGUMENT, "unknown flag bits");
+  if (flags & ~(uint32_t)(THA4_FULL_EXACT_FP32 | THA4_FULL_EXACT_DECOMPOSER | THA4_FULL_EXACT_DECOMPOSER_OUTER)) return fail(THA4_ERR_INVALID_ARGUMENT, "unknown flag bits");
   if (num_networks != 3 && num_networks != 5) return fail(THA4_ERR_INVALID_ARGUMENT, "num_networks must be 5 (mode_07) or 3 (mode_12)");
   *out = nullptr;
   if (max_batch < 1 || max_batch > 256) return fail(THA4_ERR_INVALID_ARGUMENT, "max_batch must be in [1, 256]");
@@ -553,6 +553,8 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
   }
   auto* h = new tha4_full();
   h->device = device;
+  h->model.exact_decomposer = (flags & THA4_FULL_EXACT_DECOMPOSER) != 0;
+  h->model.exact_decomposer_outer = (flags & THA4_FULL_EXACT_DECOMPOSER_OUTER) != 0;
   if (!h->model.build(nets, max_batch, eyebrow_morphed_image_index, num_networks, (flags & THA4_FULL_EXACT_FP32) != 0)) {
     // a planner failure ("internal: ...") is ours, not a property of the caller's state_dicts: say so
     const bool internal = h->model.error.rfind("internal:", 0) == 0;
@@ -639,7 +641,10 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
   for (int k = 0; k < 3; ++k) f.rgba8_bg[k] = f.rgba8_has_bg ? display->background_rgb[k] : 0.0f;
   HIP_TRY(h->order.enter(f.stream));
   bool want_dec[6];
-  for (int i = 0; i < 33; ++i) f.out[i] = outputs_dev[i] ? outputs_dev[i] : m.Wk(m.scratch_out[i]);
+  // an output the caller did not ask for is written to scratch only if a LATER STAGE reads it (FullModel::read_by_later_stage); otherwise its pointer stays
+  // null and the image kernels skip its stores (round 6: Poser.pose() asks for one of the 33)
+  static const bool write_all = tune_env("THA4_WRITE_ALL_OUTPUTS") != nullptr;      // tuning aid (A/B): rounds 1-5 wrote every output
+  for (int i = 0; i < 33; ++i) f.out[i] = outputs_dev[i] ? outputs_dev[i] : ((write_all || m.read_by_later_stage(i)) ? m.Wk(m.scratch_out[i]) : nullptr);
   for (int i = 0; i < 6; ++i) want_dec[i] = outputs_dev[27 + i] != nullptr;
   // THA4_FAULT_STATUS_ONLY: the call is never refused, but while a fault is pending (raised and not yet polled through
   // tha4_full_numeric_status) the persistent decomposer outputs may be the faulted call's: they are recomputed, not reused.
@@ -752,7 +757,10 @@ void tha4_full_destroy(tha4_full* h) {
 
 int tha4_full_max_batch(const tha4_full* h) { return h ? h->model.max_batch : THA4_ERR_INVALID_ARGUMENT; }
 int tha4_full_num_networks(const tha4_full* h) { return h ? h->model.num_networks : THA4_ERR_INVALID_ARGUMENT; }
-int tha4_full_flags(const tha4_full* h) { return h ? (h->model.exact_fp32 ? THA4_FULL_EXACT_FP32 : 0) : THA4_ERR_INVALID_ARGUMENT; }
+int tha4_full_flags(const tha4_full* h) {
+  return h ? (int)((h->model.exact_fp32 ? THA4_FULL_EXACT_FP32 : 0u) | (h->model.exact_decomposer ? THA4_FULL_EXACT_DECOMPOSER : 0u) |
+                  (h->model.exact_decomposer_outer ? THA4_FULL_EXACT_DECOMPOSER_OUTER : 0u)) : THA4_ERR_INVALID_ARGUMENT;
+}
 
 int tha4_display_rgba8(const float* frames_dev, int batch, int height, int width, const float* background_rgb,
                        uint8_t* out_dev, void* stream) {

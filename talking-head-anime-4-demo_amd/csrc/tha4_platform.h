@@ -323,6 +323,24 @@ THA4_DEV void store16_wt(void* p, const tha4::f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #endif
 }
+// The same switch for the full model's large feature maps (conv_tile_kernel's output stores, 17 - 34 MB per launch at 256x256 / 512x512): the
+// norm_finalize launches behind them wait 10 - 12 us for the L2 write-back of those lines at the kernel boundary (profiles/r05_full_b1_reading.md).
+// Same-box A/B (tools/runs_r06/gpu_r06_c15.sh, two rounds): steady 184.6 -> 187.3 frames/s, cold 161.4 -> 163.5, batch 8 321.7 -> 324.3: on.
+#ifndef THA4_TILE_OUT_WT
+#define THA4_TILE_OUT_WT 1
+#endif
+#ifndef THA4_POINT_OUT_WT
+#define THA4_POINT_OUT_WT 1
+#endif
+template <bool WT = (THA4_TILE_OUT_WT != 0)>
+THA4_DEV void store16_out(float* p, const tha4::f32x4& v) {
+#if defined(THA4_EMU)
+  *reinterpret_cast<tha4::f32x4*>(p) = v;
+#else
+  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<tha4::f32x4*>(p) = v;
+#endif
+}
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (the index is a constant expression inside f)
 template <int I, int N, class F>
 THA4_DEV void static_for(F&& f) {

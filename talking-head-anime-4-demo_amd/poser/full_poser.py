@@ -20,6 +20,7 @@ synchronisation per frame exactly like mode_07.py:56-61) - for callers that re-u
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional
 
 import numpy as np
@@ -33,6 +34,26 @@ OUT_CHANNELS = [4, 1, 4, 2, 4, 4, 4, 1, 4, 2, 4, 4, 1, 4, 4, 1, 4, 4, 2, 4, 1, 4
 OUT_SIZE = [512] * 6 + [256] * 5 + [192] * 8 + [128] * 14
 
 
+DEFAULT_EXACT_DECOMPOSER = "outer"
+
+
+def _decomposer_mode(v):
+    """Normalise the `exact_decomposer` argument: False / None / "" / "0" -> False, True / "all" / "1" -> "all", "outer" -> "outer"."""
+    if v in (None, False, "", "0", "false", "off", "none", 0):
+        return False
+    if v in (True, "all", "1", "true", "on", 1):
+        return "all"
+    if v == "outer":
+        return "outer"
+    raise ValueError(f"exact_decomposer must be False, True / 'all' or 'outer', not {v!r}")
+
+
+def default_exact_decomposer():
+    """The library default of the mixed plan; `THA4_EXACT_DECOMPOSER=0|outer|all` in the environment overrides it (A/B measurements)."""
+    v = os.environ.get("THA4_EXACT_DECOMPOSER")
+    return DEFAULT_EXACT_DECOMPOSER if v is None or v == "" else _decomposer_mode(v)
+
+
 class HipFullPoser(Poser):
     def __init__(self,
                  state_dict_loaders: Dict[str, Callable[[], Dict[str, np.ndarray]]],
@@ -42,8 +63,14 @@ class HipFullPoser(Poser):
                  default_output_index: int = 0,
                  max_batch: int = 1,
                  dtype: torch.dtype = torch.float,
-                 exact_fp32: bool = False):
+                 exact_fp32: bool = False,
+                 exact_decomposer: Optional[bool] = None):
         self.state_dict_loaders = state_dict_loaders
+        #: THA4_FULL_EXACT_DECOMPOSER, the MIXED plan (round 6): only the eyebrow decomposer on the exact-fp32 kernels.  It carries ~90 % of the
+        #: split plan's share of the posed frame's error (profiles/parity_r06/split_attribution*.txt) and its outputs are cached while the
+        #: image is unchanged (mode_07.py:56-67): no cost per steady frame.  None = the library default (`default_exact_decomposer()`).
+        #: True / "all": the whole decomposer; "outer": every convolution of it except the 16x16 bottleneck (THA4_FULL_EXACT_DECOMPOSER_OUTER); False: none.
+        self.exact_decomposer = _decomposer_mode(default_exact_decomposer() if exact_decomposer is None else exact_decomposer)
         #: THA4_FULL_EXACT_FP32: every convolution on the exact-fp32 kernels (fp32's own operand range; ~2.5-3x slower).  The plan to
         #: fall back to when `check_numeric_range()` / `pose()` report THA4_ERR_NUMERIC_RANGE for weights that are fine in fp32:
         #: `poser.set_exact_fp32(True)` re-plans the handle on the next call.
@@ -151,6 +178,13 @@ class HipFullPoser(Poser):
             self._destroy_handle()
         return self
 
+    def set_exact_decomposer(self, on: bool = True) -> "HipFullPoser":
+        """Switch the mixed plan (eyebrow decomposer on the exact-fp32 kernels) on or off; the native handle is re-created lazily by the next call."""
+        if _decomposer_mode(on) != self.exact_decomposer:
+            self.exact_decomposer = _decomposer_mode(on)
+            self._destroy_handle()
+        return self
+
     def free(self):
         self._destroy_handle()
         self._state_dicts = None
@@ -239,7 +273,9 @@ class HipFullPoser(Poser):
         weights, keep = _capi.build_full_weights(self._state_dicts)
         handle = C.c_void_p()
         st = self._lib.tha4_full_create_ex(C.byref(weights), self.eyebrow_morphed_image_index, dev, self._max_batch,
-                                           self.num_networks, _capi.FULL_EXACT_FP32 if self.exact_fp32 else 0, C.byref(handle))
+                                           self.num_networks, (_capi.FULL_EXACT_FP32 if self.exact_fp32 else 0) |
+                                           {"all": _capi.FULL_EXACT_DECOMPOSER, "outer": _capi.FULL_EXACT_DECOMPOSER_OUTER, "": 0}[self.exact_decomposer or ""],
+                                           C.byref(handle))
         _capi.check(self._lib, st, "tha4_full_create_ex")
         del keep
         self._handle = handle

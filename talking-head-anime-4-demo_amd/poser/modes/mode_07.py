@@ -38,7 +38,7 @@ def create_poser(device: torch.device,
                  module_file_names: Optional[Dict[str, str]] = None,
                  eyebrow_morphed_image_index: int = EYEBROW_IMAGE_NO_COMBINE_ALPHA_INDEX,
                  default_output_index: int = 0,
-                 max_batch: int = 1, exact_fp32: bool = False) -> HipFullPoser:
+                 max_batch: int = 1, exact_fp32: bool = False, exact_decomposer: Optional[bool] = None) -> HipFullPoser:
     if module_file_names is None:
         module_file_names = {}
     for net in Network:
@@ -46,15 +46,15 @@ def create_poser(device: torch.device,
             module_file_names[net.name] = f"data/tha4/{net.name}.pt"
     loaders = {net.name: (lambda n=net.name: _weights.load_state_dict_file(module_file_names[n])) for net in Network}
     return HipFullPoser(loaders, device, get_pose_parameters().get_pose_parameter_groups(), eyebrow_morphed_image_index,
-                        default_output_index, max_batch, exact_fp32=exact_fp32)
+                        default_output_index, max_batch, exact_fp32=exact_fp32, exact_decomposer=exact_decomposer)
 
 
 def create_poser_from_state_dicts(device: torch.device, state_dicts: Dict[str, Dict[str, np.ndarray]],
                                   eyebrow_morphed_image_index: int = EYEBROW_IMAGE_NO_COMBINE_ALPHA_INDEX,
-                                  default_output_index: int = 0, max_batch: int = 1, exact_fp32: bool = False) -> HipFullPoser:
+                                  default_output_index: int = 0, max_batch: int = 1, exact_fp32: bool = False, exact_decomposer: Optional[bool] = None) -> HipFullPoser:
     """Same poser from in-memory state_dicts keyed by the Network names (numpy or torch values)."""
     conv = {n: {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
             for n, sd in state_dicts.items()}
     loaders = {net.name: (lambda n=net.name: conv[n]) for net in Network}
     return HipFullPoser(loaders, device, get_pose_parameters().get_pose_parameter_groups(), eyebrow_morphed_image_index,
-                        default_output_index, max_batch, exact_fp32=exact_fp32)
+                        default_output_index, max_batch, exact_fp32=exact_fp32, exact_decomposer=exact_decomposer)

@@ -38,9 +38,9 @@ DECLARED_OUTPUT_LENGTH = 5 + 5 + 8      # mode_12.py:200 (the list itself has 8 
 LIST_LENGTH = 8 + 8 + 6
 
 
-def _make(loaders, device, eyebrow_morphed_image_index, default_output_index, max_batch, exact_fp32=False) -> HipFullPoser:
+def _make(loaders, device, eyebrow_morphed_image_index, default_output_index, max_batch, exact_fp32=False, exact_decomposer=None) -> HipFullPoser:
     p = HipFullPoser(loaders, device, get_pose_parameters().get_pose_parameter_groups(), eyebrow_morphed_image_index,
-                     default_output_index, max_batch, exact_fp32=exact_fp32)
+                     default_output_index, max_batch, exact_fp32=exact_fp32, exact_decomposer=exact_decomposer)
     p.num_networks = 3
     p.first_output = 11                 # face_morpher outputs are entries 11..18 of the mode_07 list (include/tha4_hip.h)
     p.list_length = LIST_LENGTH
@@ -52,20 +52,20 @@ def create_poser(device: torch.device,
                  module_file_names: Optional[Dict[str, str]] = None,
                  eyebrow_morphed_image_index: int = EYEBROW_IMAGE_NO_COMBINE_ALPHA_INDEX,
                  default_output_index: int = 0,
-                 max_batch: int = 1, exact_fp32: bool = False) -> HipFullPoser:
+                 max_batch: int = 1, exact_fp32: bool = False, exact_decomposer: Optional[bool] = None) -> HipFullPoser:
     if module_file_names is None:
         module_file_names = {}
     for net in Network:
         if net.name not in module_file_names:
             module_file_names[net.name] = f"data/tha4/{net.name}.pt"
     loaders = {net.name: (lambda n=net.name: _weights.load_state_dict_file(module_file_names[n])) for net in Network}
-    return _make(loaders, device, eyebrow_morphed_image_index, default_output_index, max_batch, exact_fp32)
+    return _make(loaders, device, eyebrow_morphed_image_index, default_output_index, max_batch, exact_fp32, exact_decomposer)
 
 
 def create_poser_from_state_dicts(device: torch.device, state_dicts: Dict[str, Dict[str, np.ndarray]],
                                   eyebrow_morphed_image_index: int = EYEBROW_IMAGE_NO_COMBINE_ALPHA_INDEX,
-                                  default_output_index: int = 0, max_batch: int = 1, exact_fp32: bool = False) -> HipFullPoser:
+                                  default_output_index: int = 0, max_batch: int = 1, exact_fp32: bool = False, exact_decomposer: Optional[bool] = None) -> HipFullPoser:
     conv = {n.name: {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dicts[n.name].items()}
             for n in Network}
     loaders = {net.name: (lambda n=net.name: conv[n]) for net in Network}
-    return _make(loaders, device, eyebrow_morphed_image_index, default_output_index, max_batch, exact_fp32)
+    return _make(loaders, device, eyebrow_morphed_image_index, default_output_index, max_batch, exact_fp32, exact_decomposer)

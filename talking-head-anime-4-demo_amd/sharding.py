@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Sequence, Tuple
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -67,7 +69,7 @@ class FrameShardedStream:
                  dtype: torch.dtype, device: torch.device, chunk: int = 32,
                  group: Optional[dist.ProcessGroup] = None, gather: bool = True,
                  on_chunk: Optional[Callable[[int, int, torch.Tensor], None]] = None, ring_slots: int = 3,
-                 force_collective: bool = False, schedule: Optional[Sequence[int]] = None):
+                 force_collective: bool = False, schedule: Optional[Sequence[int]] = None, record_rounds: bool = False):
         """``on_chunk(lo, hi, frames)`` switches the root from an ARCHIVE of the whole stream (``allocate_result``:
         ``total`` frames on rank 0 - 2000 steps x 32 frames x 8 ranks would be 2 TB) to a STREAM: rank 0 owns a ring of
         ``ring_slots`` buffers of one gather round each (``world x chunk`` frames: 3 x 8 x 32 x 4 MiB = 3 GiB) and hands
@@ -83,6 +85,10 @@ class FrameShardedStream:
         destination - even in a one-rank group: the only way a 1-GPU box executes RCCL at all (it refuses two ranks on one
         device)."""
         self.frame_fn = frame_fn
+        # record_rounds: time every gather round where it executes (events on the side stream; wall clock on CPU tensors) for round_report() -
+        # first-contact diagnostics of an exchange nobody has measured on N > 1 GPUs
+        self.record_rounds = bool(record_rounds)
+        self._round_marks = []
         self.on_chunk = on_chunk
         self.ring_slots = max(2, int(ring_slots))
         self.total = int(total)
@@ -122,7 +128,26 @@ class FrameShardedStream:
             n *= d
         return self.ring_slots * self.world * self.chunk * n * torch.empty((), dtype=self.dtype).element_size()
 
+    def round_report(self) -> list:
+        """Per gather round of the last ``run(record_rounds=True)``: frames this rank contributed / all ranks delivered, whether it was
+        one collective (``full``) or exact-size point-to-point transfers, and the milliseconds the exchange (+ the consumer callback)
+        took on this rank's side stream.  Synchronises the device.  On rank 0 ``GBps`` is the rate of bytes ARRIVING from the other ranks."""
+        if self.device.type == "cuda" and self._round_marks:
+            torch.cuda.synchronize(self.device)
+        n = 1
+        for d in self.frame_shape:
+            n *= d
+        fb = n * torch.empty((), dtype=self.dtype).element_size()
+        out = []
+        for m in self._round_marks:
+            ms = m["t0"].elapsed_time(m["t1"]) if m.get("cuda") else 1e3 * (m["t1"] - m["t0"])
+            arriving = (m["all"] - m["own"]) * fb
+            out.append({"round": m["round"], "frames_this_rank": m["own"], "frames_all_ranks": m["all"], "full": m["full"], "ms": round(ms, 4),
+                        "GBps": round(arriving / max(ms, 1e-6) / 1e6, 2) if self.rank == 0 else round(m["own"] * fb / max(ms, 1e-6) / 1e6, 2)})
+        return out
+
     def run(self, result: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        self._round_marks = []
         sizes = all_shard_sizes(self.total, self.world)
         if self.schedule is not None:
             if sum(self.schedule) < max(sizes):
@@ -184,6 +209,14 @@ class FrameShardedStream:
                 if block is not None:
                     block.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+                mark = None
+                if self.record_rounds:
+                    mark = {"round": c, "own": b - a, "all": sum(rb - ra for ra, rb in spans), "full": full_round, "cuda": side is not None}
+                    if side is not None:
+                        mark["t0"] = torch.cuda.Event(enable_timing=True)
+                        mark["t0"].record(side)
+                    else:
+                        mark["t0"] = time.perf_counter()
                 if self.rank == 0:
                     if streaming:        # this round's slot of the ring: rank r's rows at [r * chunk, r * chunk + its count)
                         slot = ring[c % self.ring_slots]
@@ -211,6 +244,13 @@ class FrameShardedStream:
                     for r, (ra, rb) in enumerate(spans):
                         if rb > ra:
                             self.on_chunk(ra, rb, dest[r])
+                if mark is not None:
+                    if side is not None:
+                        mark["t1"] = torch.cuda.Event(enable_timing=True)
+                        mark["t1"].record(side)
+                    else:
+                        mark["t1"] = time.perf_counter()
+                    self._round_marks.append(mark)
         if side is not None:
             torch.cuda.current_stream(self.device).wait_stream(side)
         return result

@@ -321,7 +321,7 @@ if torch.cuda.is_available():
 sd = {net: {k: np.zeros(s, np.float32) for k, s in d.items()} for net, d in synthetic.full_param_shapes().items()}
 ws, keep = _capi.build_full_weights(sd)
 lib = _capi.load_library()
-for flags in (0, 1):
+for flags in (0, 1, 2, 4):
     h = C.c_void_p()
     st = lib.tha4_full_create_ex(C.byref(ws), 2, 0, 256, 5, flags, C.byref(h))
     print("RESULT", flags, st, lib.tha4_last_error().decode())
@@ -333,7 +333,7 @@ for flags in (0, 1):
     lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
     if lines == ["RESULT skipped"]:
         pytest.skip("a device is visible: the plan-only route needs none (the device tests create real handles)")
-    assert len(lines) == 2, r.stdout
+    assert len(lines) == 4, r.stdout          # default, exact-fp32 and the two mixed (THA4_FULL_EXACT_DECOMPOSER[_OUTER]) plans
     for l in lines:
         assert " -3 " in l and "launch plan was printed" in l, l          # THA4_ERR_NO_DEVICE after a complete plan
     assert "conv #" in r.stderr and "out of range" not in r.stderr

@@ -285,10 +285,20 @@ def test_norm_finalize_instance_and_group(lib):
     assert np.abs(got - ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("split", [1, 0])
 @pytest.mark.parametrize("tiles", [1024, 1031, 300, 72])
-def test_norm_finalize_many_tiles_narrow_split(lib, tiles):
+def test_norm_finalize_many_tiles_narrow_split(lib, tiles, split):
     """Round 5: with many tiles per channel (a 512x512 map: 1024+) the finalize launch takes few channels per workgroup (down to one GroupNorm group, at
-    least 4) so that a thread walks about one round of eight tiles - main loop, conditional tail and the group reduction over a narrow range."""
+    least 4) so that a thread walks about one round of eight tiles - main loop, conditional tail and the group reduction over a narrow range.
+    `split` = 1: that tile-aware split (the product's THA4_NORM_TILE_SPLIT tuning option); 0: the SHIPPED split on the same many-tile tensors."""
+    lib.emu_set_norm_tile_split(split)
+    try:
+        _norm_many_tiles(lib, tiles)
+    finally:
+        lib.emu_set_norm_tile_split(0)
+
+
+def _norm_many_tiles(lib, tiles):
     rng = np.random.default_rng(tiles)
     n, C_ = 1, 32
     px = tiles * 4

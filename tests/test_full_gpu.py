@@ -523,7 +523,8 @@ def test_failed_call_does_not_poison_the_decomposer_cache(weights, full_io, gold
     import copy
     bad = copy.deepcopy(weights)
     bad["eyebrow_decomposer"]["body.downsample_blocks.0.1.weight"] = bad["eyebrow_decomposer"]["body.downsample_blocks.0.1.weight"] * 2e5
-    q = mode_07.create_poser_from_state_dicts(dev, bad, max_batch=1)
+    # (exact_decomposer=False: the fault is an fp16-range overflow INSIDE the decomposer - on the mixed default plan that network computes in fp32 and has none)
+    q = mode_07.create_poser_from_state_dicts(dev, bad, max_batch=1, exact_decomposer=False)
     img = torch.from_numpy(a_np).to(dev)
     q.pose(img, pose)                                                  # faults inside the decomposer; returns OK (no sync)
     with pytest.raises(_capi.Tha4Error, match="numeric fault"):
@@ -539,7 +540,8 @@ def test_exact_fp32_plan_vs_reference_fixture_and_split_plan(weights, poser1, fu
     dev = torch.device("cuda:0")
     p = mode_07.create_poser_from_state_dicts(dev, weights, max_batch=1, exact_fp32=True)
     p.get_modules()
-    assert p._lib.tha4_full_flags(p._handle) == 1 and poser1._lib.tha4_full_flags(poser1._handle) == 0
+    dflag = {"all": 2, "outer": 4, False: 0}
+    assert p._lib.tha4_full_flags(p._handle) == 1 | dflag[p.exact_decomposer] and poser1._lib.tha4_full_flags(poser1._handle) == dflag[poser1.exact_decomposer]
     image = torch.from_numpy(golden_io["image_f32"]).to(dev)
     report, apart = [], 0.0
     for i in range(2):
@@ -626,22 +628,33 @@ def test_mode_07_create_poser_from_pt_files_on_device(weights, poser1, full_io, 
 SUB7 = slice(3, None, 7)
 
 
-@pytest.mark.parametrize("exact", [False, True])
-def test_midgain_set_all_33_outputs_vs_reference_fixture(exact, golden_io):
+@pytest.mark.parametrize("plan", ["default", "split", "mixed_all", "exact"])
+def test_midgain_set_all_33_outputs_vs_reference_fixture(plan, golden_io):
     """Round-4 review, task 6: with the standard synthetic set output 0 is ~ half the warped input whatever the U-Nets compute
     (alpha 0.50 +- 0.015, direct +-0.07) and the adversarial set is gated loosely; here alpha spans [0.13, 0.91], direct is +-0.28 and
     the unmodified reference agrees with its own fp64 run to 1.7e-4 - every one of the 33 outputs is gated at 1e-3 (2.5e-3 on the
     warped images) against the reference's fp32 run, on both plans (fp16 hi/lo split and exact fp32), at batch 1 (lambda_00 image,
-    two poses, decomposer cache) and on a dense batch of 8 distinct images (the batch-8 launch plan)."""
+    two poses, decomposer cache) and on a dense batch of 8 distinct images (the batch-8 launch plan).
+    Round-5 review, task 4: four plans - "default" (since round 6 the "outer" MIXED plan: the eyebrow decomposer's convolutions outside its 16x16
+    bottleneck on the exact-fp32 kernels, the rest fp16 hi/lo; the decomposer carries ~90 % of the split's share of the error, profiles/parity_r06/),
+    "mixed_all" (the whole decomposer exact), "split" (everything fp16 hi/lo: the default of rounds 1-5, now opt-out) and "exact".  On the batch of 8
+    every output that is not a `*_warped` image - the POSED FRAME first of all - is gated at 1e-3 FLAT on the default, mixed and exact plans (rounds
+    4-5: max(1e-3, 3 x the reference's own fp32-vs-fp64 distance) = 2.0e-3 on the posed frame); the pure split plan sits AT 1e-3 there (9.99e-4 /
+    1.008e-3 on two boxes; the reference's own distance is 6.6e-4) and keeps a 1.25e-3 gate on that one output."""
     from oracle.student_oracle import synthetic_image
     import json
+    exact = plan == "exact"
+    kw = dict(exact_fp32=exact, exact_decomposer={"default": None, "split": False, "mixed_all": True, "exact": False}[plan])
+    from tha4_amd.poser.full_poser import default_exact_decomposer
+    want_mode = {"default": default_exact_decomposer(), "split": False, "mixed_all": "all", "exact": False}[plan]
     z = _npz("full_midgain_io.npz")
     noise8 = json.load(open(os.path.join(GOLDEN, "full_midgain_noise.json")))["b8_fp32_vs_fp64_maxabs"]
     w = fo.synth_full_weights(int(z["seed"]), head_gains=tuple(float(x) for x in z["head_gains"]))
     dev = torch.device("cuda:0")
     report = []
     # batch 1
-    p = mode_07.create_poser_from_state_dicts(dev, w, max_batch=1, exact_fp32=exact)
+    p = mode_07.create_poser_from_state_dicts(dev, w, max_batch=1, **kw)
+    assert p.exact_decomposer == want_mode
     image = torch.from_numpy(golden_io["image_f32"]).to(dev)
     for i in range(2):
         outs = p.get_posing_outputs(image, torch.from_numpy(z["b1_poses"][i]).to(dev), image_changed=(i == 0))
@@ -651,17 +664,22 @@ def test_midgain_set_all_33_outputs_vs_reference_fixture(exact, golden_io):
     p.check_numeric_range()
     p.free()
     # batch 8, distinct images
-    p = mode_07.create_poser_from_state_dicts(dev, w, max_batch=8, exact_fp32=exact)
+    p = mode_07.create_poser_from_state_dicts(dev, w, max_batch=8, **kw)
+    p.get_modules()
+    assert p._lib.tha4_full_flags(p._handle) == (1 if exact else 0) | {"all": 2, "outer": 4, False: 0}[want_mode]
     images = torch.from_numpy(np.stack([synthetic_image(seed=int(s)) for s in z["b8_image_seeds"]])).to(dev)
     outs = p.get_posing_outputs(images, torch.from_numpy(z["b8_poses"]).to(dev))
     for k in range(33):
         got = outs[k].cpu().numpy()[:, :, SUB7, SUB7]
-        # (random band-limited images: the reference's own fp32 scatter is 6.6e-4 on the posed frame here - gate = max(1e-3, 3 x its fp32-vs-fp64 distance))
-        report.append((f"b8 {fo.OUTPUT_NAMES[k]}", float(np.abs(got - z[f"b8_ref32_sub7_out{k}"]).max()), _tol(fo.OUTPUT_NAMES[k], noise8[fo.OUTPUT_NAMES[k]])))
+        name = fo.OUTPUT_NAMES[k]
+        # random band-limited images: the reference's own fp32 scatter is 6.6e-4 on the posed frame here.  `*_warped` (informational):
+        # max(2.5e-3, 3 x the reference's fp32-vs-fp64 distance); everything else 1e-3 flat (the non-default pure split plan: 1.25e-3 on the posed frame)
+        tol = _tol(name, noise8[name]) if "warped" in name else (1.25e-3 if (plan == "split" and name == "up_merged") else 1e-3)
+        report.append((f"b8 {name}", float(np.abs(got - z[f"b8_ref32_sub7_out{k}"]).max()), tol))
     p.check_numeric_range()
     p.free()
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/full_midgain_parity_report_{'exact' if exact else 'split'}.txt", "w") as fh:
+    with open(f"gpurun_out/full_midgain_parity_report_{plan}.txt", "w") as fh:
         fh.write("\n".join(f"{n:40s} {e:.3e} (tol {t:.1e})" for n, e, t in report) + "\n")
     bad = [r for r in report if r[1] > r[2]]
     assert not bad, bad

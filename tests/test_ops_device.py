@@ -58,9 +58,10 @@ def test_moment_accumulators_on_device(lib, pg_prod, pg_cons, h, w, c0, c1, cmid
     T.test_moment_accumulators_producer_to_consumer(lib, pg_prod, pg_cons, h, w, c0, c1, cmid)
 
 
+@pytest.mark.parametrize("split", [1, 0])
 @pytest.mark.parametrize("tiles", [1024, 1031, 72])
-def test_norm_finalize_many_tiles_on_device(lib, tiles):
-    T.test_norm_finalize_many_tiles_narrow_split(lib, tiles)
+def test_norm_finalize_many_tiles_on_device(lib, tiles, split):
+    T.test_norm_finalize_many_tiles_narrow_split(lib, tiles, split)
 
 
 def test_xcd_aware_order_on_device(lib):

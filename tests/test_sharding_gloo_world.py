@@ -252,6 +252,23 @@ def test_bench_py_gpus_8_launched_like_the_driver_under_gloo(extra):
     for v in ("fp32", "rgba8", "none"):
         assert gv[v]["fps"] > 0 and gv[v]["regions"] >= 1
     assert gv["none"]["root_ingest_GBps"] == 0
+    # first-contact diagnostics (round-5 review, task 7): a below-target N = 8 result must be diagnosable from the line alone
+    ex = j["exchange"]
+    assert ex["backend"] == "gloo" and "torch" in ex and ex["env"].get("GLOO_SOCKET_IFNAME") == "lo"
+    frame_bytes = {"fp32": 4 * 512 * 512 * 4, "rgba8": 512 * 512 * 4}
+    for v in ("fp32", "rgba8", "none"):
+        pr = gv[v]["per_rank_fps"]
+        assert len(pr["all"]) == 8 and pr["min"] == min(pr["all"]) and pr["max"] == max(pr["all"]) and 0 <= pr["slowest_rank"] < 8
+        assert pr["min"] * 8 >= gv[v]["fps"] * 0.5                     # the line's clock is the slowest rank's (median of regions vs one region: loose)
+    for v in ("fp32", "rgba8"):
+        rounds = gv[v]["rounds"]
+        assert [r["frames_this_rank"] for r in rounds] == j["config"]["gather_schedule"]      # rank 0's share of every round of the taper
+        assert all(r["frames_all_ranks"] == 8 * r["frames_this_rank"] and r["ms"] > 0 and r["GBps"] > 0 for r in rounds)
+        assert abs(rounds[0]["GBps"] - 7 * rounds[0]["frames_this_rank"] * frame_bytes[v] / rounds[0]["ms"] / 1e6) <= 0.02 * rounds[0]["GBps"] + 0.01
+        assert gv[v]["root_ring_bytes"] == 3 * 8 * max(j["config"]["gather_schedule"]) * frame_bytes[v]       # each form reports ITS ring
+        assert len(gv[v]["rehearsal_s"]) >= 1 and all(x > 0 for x in gv[v]["rehearsal_s"])
+    if "--no-gather" not in extra:
+        assert j["config"]["gather_root_ring_bytes"] == gv[gv["value_is"]]["root_ring_bytes"]
     # ... and the gather rounds end on a taper: whole calls, never increasing, the exposed last round <= max(one call, 5 %)
     sched = j["config"]["gather_schedule"]
     assert sum(sched) == K * B and all(x % B == 0 for x in sched) and sched == sorted(sched, reverse=True)

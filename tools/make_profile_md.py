@@ -28,6 +28,9 @@ def student():
     shutil.copy(os.path.join(G, "ps_kernel_stats.csv"), os.path.join(P, f"{tag}_student_b1_kernel_stats.csv"))
     if os.path.exists(os.path.join(G, "student_b1_traffic.json")):
         shutil.copy(os.path.join(G, "student_b1_traffic.json"), os.path.join(P, f"{tag}_student_b1_traffic.json"))
+    for b in (1, 32):                                                    # SQ summary bench.py quotes (tools/pmc_json.py, round 6)
+        if os.path.exists(os.path.join(G, f"student_b{b}_pmc.json")):
+            shutil.copy(os.path.join(G, f"student_b{b}_pmc.json"), os.path.join(P, f"{tag}_student_b{b}_pmc.json"))
     md = [f"# {tag} - student path, batch 1 stream (`bench.py --steps 200 --warmup 50 --profile-frames 5 --full-frames 0 --d2h-frames 0 --exact-frames 0`), MI355X",
           f"Source: `tools/profile_{tag}.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes; FETCH_SIZE and WRITE_SIZE each in",
           "its own pass: together they abort rocprofv3 on this image).  Kernels: generation 2 (fp16 hi/lo split MFMA), weights-resident",

@@ -18,6 +18,10 @@
 //   4 persistent, sc1 stores, hierarchical counters, acquire fence
 //   5 persistent, sc1 stores AND sc1 loads, hierarchical counters, no fence at all
 //   6 = 0 + weight stream        7 = 5 + weight stream, requested behind the barrier        8 = 5 + weight stream, next layer's first unit requested BEFORE the barrier
+//   9 = 6 + L2 WARM-UP of the next layer's weights (round-5 review, task 3a): each workgroup touches one dword per 128-B line of ITS eighth of the next
+//       layer's slice for its output block (36 KiB = 288 lines; the 8 pixel tiles of an output block share an XCD, so the whole 288-KiB slice is in that
+//       XCD's L2 when the next launch asks for it) right behind its own first requests; the values are never used (one compare at the end of the kernel)
+//  10 = 9 with the warm-up loads issued in FRONT of the layer's own first requests (in-order vmcnt: do they delay the layer's own data?)
 // Prints us per layer and the number of stale values seen.  Every spin is bounded (a stuck barrier sets a flag and the kernel leaves).
 //   hipcc --offload-arch=gfx950 -O3 tools/microbench/stretch_barrier.hip -o tools/microbench/stretch_barrier
 #include <hip/hip_runtime.h>
@@ -108,8 +112,14 @@ __device__ __forceinline__ float use_unit(const WUnit& w) {
 
 template <int MODE>
 __device__ __forceinline__ void layer_body(const Params& p, int L, int b, WUnit& wpre) {
-  constexpr bool kSc1St = MODE >= 3 && MODE != 6, kSc1Ld = MODE == 5 || MODE >= 7;
+  constexpr bool kSc1St = MODE >= 3 && MODE != 6 && MODE < 9, kSc1Ld = MODE == 5 || MODE == 7 || MODE == 8;
   constexpr bool kW = MODE >= 6;
+  constexpr bool kWarm = MODE >= 9;
+  float warm = 0.f;
+  // the next layer's slice for this output block: [L + 1][bo][16 units][9 taps][512 floats] = 288 KiB; this workgroup's eighth = 288 lines of 128 B
+  const float* warm_ptr = p.weights + ((((size_t)(L + 1) * 32 + (b & 31)) * 16) * 9) * 512 + ((size_t)(b >> 5) * 288 + (threadIdx.x < 288 ? threadIdx.x : 0)) * 32;
+  const bool do_warm = kWarm && L + 1 < p.layers && threadIdx.x < 288;
+  if (MODE == 10 && do_warm) warm = *warm_ptr;
   WUnit w1;
   if (kW && MODE != 8) load_unit(p, L, b & 31, threadIdx.x >> 6, w1);        // first unit: requested with the window (top of the layer)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -147,6 +157,7 @@ __device__ __forceinline__ void layer_body(const Params& p, int L, int b, WUnit&
       w[i] = *reinterpret_cast<const f32x4*>(in + ((size_t)cb * kPx + gpx) * 16 + q * 4);
     }
   }
+  if (MODE == 9 && do_warm) warm = *warm_ptr;               // behind the layer's own first requests (moments, window, first weight unit)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -172,13 +183,14 @@ __device__ __forceinline__ void layer_body(const Params& p, int L, int b, WUnit&
     if (lane < 8) st16(so + ((size_t)tile * 512 + bo * 16) * 2 + lane * 4, v, kSc1St);
   }
   if (MODE == 8 && L + 1 < p.layers) load_unit(p, L + 1, b & 31, threadIdx.x >> 6, wpre);   // next layer's first unit, in front of the barrier
+  if (kWarm && warm == 12345.678f) p.sink[threadIdx.x] = warm;                              // (the only use of the warm-up values: nothing waits for them before this)
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) stretch_kernel(Params p) {
   const int b = blockIdx.x;
   WUnit wpre;
-  if (MODE == 0 || MODE == 6) { layer_body<MODE>(p, p.first_layer, b, wpre); return; }
+  if (MODE == 0 || MODE == 6 || MODE >= 9) { layer_body<MODE>(p, p.first_layer, b, wpre); return; }
   // census: workgroups per XCD (established behind one flat, fenced barrier)
   const int xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 15;
   __shared__ int s_nx, s_nxcd;
@@ -226,7 +238,7 @@ void run(int layers, int reps) {
     hipMemset(p.ctr, 0, 32 * 32 * 4); hipMemset(p.errors, 0, 8);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    if (MODE == 0 || MODE == 6) {
+    if (MODE == 0 || MODE == 6 || MODE >= 9) {
       for (int L = 0; L < layers; ++L) { p.first_layer = L; stretch_kernel<MODE><<<kWGs, kThreads>>>(p); }
     } else {
       stretch_kernel<MODE><<<kWGs, kThreads>>>(p);
@@ -244,7 +256,8 @@ void run(int layers, int reps) {
   static const char* names[] = {"0 one launch per layer", "1 persistent, release fence + flat counter + acquire", "2 persistent, release fence + XCD counters + acquire",
                                 "3 persistent, sc1 stores + flat counter + acquire", "4 persistent, sc1 stores + XCD counters + acquire",
                                 "5 persistent, sc1 stores + sc1 loads + XCD counters, no fence", "6 = 0 + 288 KiB weight stream per workgroup",
-                                "7 = 5 + weight stream requested behind the barrier", "8 = 5 + next layer's first unit requested before the barrier"};
+                                "7 = 5 + weight stream requested behind the barrier", "8 = 5 + next layer's first unit requested before the barrier",
+                                "9 = 6 + next layer's weights warmed into L2 (behind own requests)", "10 = 6 + next layer's weights warmed into L2 (in front)"};
   std::printf("%-62s  %7.2f us / layer  (%d layers, best of %d)  stale values %llu%s\n", names[MODE], best * 1000.f / layers, layers, reps, errs_total,
               timeout ? "  BARRIER TIMED OUT" : "");
   for (int i = 0; i < 2; ++i) { hipFree(p.act[i]); hipFree(p.stats[i]); }
@@ -262,5 +275,8 @@ int main(int argc, char** argv) {
   run<6>(layers, reps);
   run<7>(layers, reps);
   run<8>(layers, reps);
+  run<9>(layers, reps);
+  run<10>(layers, reps);
+  run<6>(layers, reps);
   return 0;
 }

@@ -29,18 +29,20 @@ from oracle import full_oracle as fo                          # noqa: E402
 from oracle.student_oracle import synthetic_image             # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-STATE = {"net": None, "active": set(), "seen": {}}
+STATE = {"net": None, "active": set(), "seen": {}, "fine": False, "which": "both"}
 
 
-def split22(t, scaled):
-    """v -> hi + lo as the kernels stage it (fp32 -> two fp16 halves), returned in the dtype of t."""
+def split22(t, scaled, pre=1.0):
+    """v -> hi + lo as the kernels stage it (fp32 -> two fp16 halves), returned in the dtype of t.  pre: power of two applied before the split
+    (activations: what-if for a pre-scaled staging that keeps the low halves of small activations out of the fp16 subnormal range)."""
     x = t.to(torch.float32)
-    s = 1.0
+    s = pre
+    x = x * s
     if scaled:
         mx = float(x.abs().max())
         if mx > 0.0:
             s = 2.0 ** np.floor(np.log2(16384.0 / mx))
-        x = x * s
+            x = x * s
     hi = x.to(torch.float16)
     lo = (x - hi.to(torch.float32)).to(torch.float16)
     return ((hi.to(torch.float64) + lo.to(torch.float64)) / s).to(t.dtype)
@@ -49,7 +51,12 @@ def split22(t, scaled):
 def conv_class(net, x, w, transposed):
     h = x.shape[-1] * (2 if transposed else 1)
     if net in ("dec", "comb", "face"):
-        return "encdec (decomposer + combiner + face morpher)"
+        if not STATE["fine"]:
+            return "encdec (decomposer + combiner + face morpher)"
+        cin = w.shape[0] if transposed else w.shape[1]
+        co = w.shape[1] if transposed else w.shape[0]
+        role = "first conv" if cin <= 8 else ("heads" if co <= 4 else ("bottleneck <= 32x32" if h <= 32 else "down / up convs"))
+        return f"{net}: {role}"
     cout = w.shape[1] if transposed else w.shape[0]
     if cout == 7:
         return f"{net}: last convolution"
@@ -68,14 +75,20 @@ def install():
         c = conv_class(STATE["net"], x, w, False)
         STATE["seen"][c] = STATE["seen"].get(c, 0) + 1
         if c in STATE["active"]:
-            x, w = split22(x, False), split22(w, True)
+            if STATE["which"] != "weights":
+                x = split22(x, False, STATE.get("act_pre", 1.0))
+            if STATE["which"] != "activations":
+                w = split22(w, True)
         return real_conv(x, w, *a, **k)
 
     def conv_transpose2d(x, w, *a, **k):
         c = conv_class(STATE["net"], x, w, True)
         STATE["seen"][c] = STATE["seen"].get(c, 0) + 1
         if c in STATE["active"]:
-            x, w = split22(x, False), split22(w, True)
+            if STATE["which"] != "weights":
+                x = split22(x, False, STATE.get("act_pre", 1.0))
+            if STATE["which"] != "activations":
+                w = split22(w, True)
         return real_convt(x, w, *a, **k)
 
     F.conv2d, F.conv_transpose2d = conv2d, conv_transpose2d
@@ -93,7 +106,11 @@ def main():
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--frames", type=int, default=8, help="frames of the fixture's batch of 8 to evaluate")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "parity_r06", "split_attribution.txt"))
+    ap.add_argument("--act-scale-log2", type=int, default=None, help="what-if: only the row 'ALL encoder-decoder classes, activations only' with the activations "
+                                                                     "multiplied by 2^k before the split (and divided after)")
+    ap.add_argument("--fine", action="store_true", help="split the encoder-decoder class by network and layer role, and by operand (weights / activations)")
     args = ap.parse_args()
+    STATE["fine"] = args.fine
     torch.set_num_threads(args.threads)
     z = np.load(os.path.join(GOLDEN, "full_midgain_io.npz"))
     w = fo.synth_full_weights(int(z["seed"]), head_gains=tuple(float(x) for x in z["head_gains"]))
@@ -103,8 +120,9 @@ def main():
     names = ("up_merged", "up_warped", "up_direct", "up_alpha", "up_grid", "body_merged", "body_grid", "face_0")
     idx = [fo.OUTPUT_NAMES.index(n) for n in names]
 
-    def run(active):
+    def run(active, which="both"):
         STATE["active"] = set(active)
+        STATE["which"] = which
         STATE["seen"] = {}
         t0 = time.time()
         outs = fo.full_forward_torch(w, images, poses, "float64")
@@ -116,9 +134,16 @@ def main():
              "# max |output - unperturbed fp64 output| per class;  convolutions of the class in one forward pass in brackets",
              f"{'class':52s} " + " ".join(f"{n:>11s}" for n in names)]
     print("\n".join(lines), flush=True)
-    for active in [(c,) for c in classes] + [tuple(classes)]:
-        got, dt = run(active)
-        label = "ALL classes" if len(active) > 1 else f"{active[0]} [{STATE['seen'][active[0]]}]"
+    todo = [((c,), "both") for c in classes] + [(tuple(classes), "both")]
+    if args.fine:
+        enc = [c for c in classes if c.split(":")[0] in ("dec", "comb", "face")]
+        todo = [((c,), "both") for c in enc] + [(tuple(enc), "weights"), (tuple(enc), "activations"), (tuple(enc), "both")]
+    if args.act_scale_log2 is not None:
+        STATE["act_pre"] = 2.0 ** args.act_scale_log2
+        todo = [(tuple(c for c in classes if c.split(":")[0] in ("dec", "comb", "face")), "activations")]
+    for active, which in todo:
+        got, dt = run(active, which)
+        label = (f"ALL {'encoder-decoder ' if args.fine else ''}classes" + ("" if which == "both" else f", {which} only")) if len(active) > 1 else f"{active[0]} [{STATE['seen'][active[0]]}]"
         row = f"{label:52s} " + " ".join(f"{float(np.abs(g - b).max()):11.3e}" for g, b in zip(got, base))
         print(row, flush=True)
         lines.append(row)

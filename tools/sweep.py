@@ -86,6 +86,8 @@ VARIANTS = {
     "zwt0": ["-DTHA4_Z_WRITE_THROUGH=0"],         # plain instead of write-through (sc1) stores of the z1 / z2 hand-off images
     "spread0": ["-DTHA4_RING_SPREAD=0"],          # the LDS-DMA copies a ring barrier releases in a burst behind it instead of one per step under the MFMAs
     "allregs0": ["-DTHA4_FRONT_REGS=0", "-DTHA4_L1_REGS=0"],
+    "tilewt0": ["-DTHA4_TILE_OUT_WT=0"],           # full model: plain instead of write-through (sc1) output stores of conv_tile_kernel (A/B: tools/ab_full.py)
+    "pointwt0": ["-DTHA4_POINT_OUT_WT=0"],         # ... and of conv_point_kernel
     "cwait": ["-DTHA4_NEVER_BUILT_HERE"],                                           # (a copy of an earlier build kept for a same-box A/B: never rebuilt by `build`)
     "stamps": ["-DTHA4_STAMPS"],                                                  # in-kernel time stamps (tools/stamps_student.py)
     "pf1": ["-DTHA4_REGS_PREFETCH=1"], "pf3": ["-DTHA4_REGS_PREFETCH=3"],        # A-fragment look-ahead of the register-resident kernels in steps (default 2)
