@@ -144,23 +144,26 @@ def roofline_evidence(roofline, dom, gflop_launch, event_ms, B):
         ev["kernel_rocprof_what"] = f"as-written GFLOP of the launch / rocprofv3 average launch duration ({rp.get('file')}) / peak"
     pmc, pmc_file = newest_profile("r*_student_b1_pmc.json" if B == 1 else "r*_student_b32_pmc.json")
     k = (pmc or {}).get("kernels", {}).get(short)
-    if k:
-        ev["mfma_busy"] = k.get("mfma_busy")
-        ev["wave_time"] = {x: k.get(x) for x in ("active", "issue_stall", "parked") if k.get(x) is not None}
-        ev["valu_per_mfma"] = k.get("valu_per_mfma")
-        ev["pmc_source"] = pmc_file
-        busy = k.get("mfma_busy") or 0.0
-        parked, stall = k.get("parked") or 0.0, k.get("issue_stall") or 0.0
-        if busy >= 0.6:
-            ev["limiter"] = f"mfma: matrix pipe busy {busy:.0%} of the launch"
-        elif parked >= stall:
-            ev["limiter"] = (f"memory / barrier waits: a resident wave is parked at s_waitcnt or s_barrier {parked:.0%} of its time "
-                             f"(matrix pipe busy {busy:.0%})")
-        else:
-            ev["limiter"] = (f"instruction issue: MFMA and VALU share a SIMD's issue port - {k.get('valu_per_mfma')} VALU per MFMA, waves issue-stalled {stall:.0%} "
-                             f"of their time (matrix pipe busy {busy:.0%})")
+    ev.update(pmc_evidence(k, pmc_file))
+    return ev
+
+
+def pmc_evidence(k, source):
+    """`mfma_busy`, the wave-time split, VALU per MFMA and the `limiter` sentence for one kernel entry of a committed PMC summary (tools/pmc_json.py)."""
+    if not k:
+        return {"limiter": "unknown: no PMC capture committed for this kernel (tools/pmc_json.py)"}
+    ev = {"mfma_busy": k.get("mfma_busy"), "wave_time": {x: k.get(x) for x in ("active", "issue_stall", "parked") if k.get(x) is not None},
+          "valu_per_mfma": k.get("valu_per_mfma"), "clock_mhz_in_capture": k.get("clock_mhz"), "pmc_source": source}
+    busy = k.get("mfma_busy") or 0.0
+    parked, stall = k.get("parked") or 0.0, k.get("issue_stall") or 0.0
+    if busy >= 0.6:
+        ev["limiter"] = f"mfma: matrix pipe busy {busy:.0%} of the launch"
+    elif parked >= stall:
+        ev["limiter"] = (f"memory / barrier waits: a resident wave is parked at s_waitcnt or s_barrier {parked:.0%} of its time "
+                         f"(matrix pipe busy {busy:.0%})")
     else:
-        ev["limiter"] = "unknown: no PMC capture committed for this kernel (tools/pmc_json.py)"
+        ev["limiter"] = (f"instruction issue: MFMA and VALU share a SIMD's issue port - {k.get('valu_per_mfma')} VALU per MFMA, waves issue-stalled {stall:.0%} "
+                         f"of their time (matrix pipe busy {busy:.0%})")
     return ev
 
 
@@ -906,6 +909,18 @@ def full_roofline(fps_per_gpu, gflop, cold, batch1, work=None):
             top = {"event_timed_frame_ms": round(event_ms, 3), "classes": rows[:8]}
         except Exception as e:                     # a measurement aid must not take the line down
             dominant = {"error": repr(e)}
+    # what the dominant class's kernel waits for, from the newest committed SQ capture of the full model (tools/pmc_json.py --mode full): the template instance of
+    # that kernel with the largest share of the capture
+    evidence = None
+    if isinstance(dominant, dict) and "class" in dominant and "[" in dominant["class"]:
+        kname = dominant["class"].split("[")[-1].split("]")[0].split(",")[0].strip()
+        pmc, pmc_file = newest_profile("r*_full_b1_pmc.json" if batch1 else "r*_full_b8_pmc.json")
+        cands = {n: e for n, e in (pmc or {}).get("kernels", {}).items() if n.split("<")[0] == kname}
+        if cands:
+            n = max(cands, key=lambda x: cands[x].get("launches_per_pass", 0) * cands[x].get("avg_us", 0.0))
+            evidence = dict(pmc_evidence(cands[n], pmc_file), kernel=n)
+        else:
+            evidence = pmc_evidence(None, None)
     layers, layers_file = newest_profile("r*_full_b1_layers.json")
     rocprof = None
     if layers and batch1 and layers.get("classes"):
@@ -917,7 +932,8 @@ def full_roofline(fps_per_gpu, gflop, cold, batch1, work=None):
             "vs_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
             "mfma": "v_mfma_f32_16x16x32_f16 on fp16 hi/lo operand halves, 3 per product block, fp32 accumulate",
             "traffic": per_frame, "traffic_unit": f"bytes/frame = sum over the frame's launches of 2 x FETCH_SIZE + WRITE_SIZE ({prof_file})",
-            "dominant_class": dominant, "dominant_class_rocprof": rocprof, "live_classes": top, "algorithmic_gflop_per_frame": gflop}
+            "dominant_class": dominant, "dominant_class_evidence": evidence, "dominant_class_rocprof": rocprof, "live_classes": top,
+            "algorithmic_gflop_per_frame": gflop}
 
 
 def full_extras(args, work, dev, world, fps, B):

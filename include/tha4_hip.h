@@ -225,8 +225,9 @@ int tha4_full_flags(const tha4_full* h);
  *   outputs_dev[i]  device pointer for output i of the reference's 33-entry list (order mode_07.py:126-132:
  *                   upscaler 0-4, face_morphed_full 5, body_morpher 6-10, face_morpher 11-18,
  *                   eyebrow_morphing_combiner 19-26, eyebrow_decomposer 27-32), fp32 NCHW [B,C,S,S];
- *                   NULL = not wanted and not computed into caller memory; at least one must be given
- *                   (e.g. the distiller asks for 0,1,2,3,5 only, siren_morpher_protocols_03.py:56-72).
+ *                   NULL = not wanted: nothing is written for it at all unless a later stage of the pipeline reads it
+ *                   (outputs 5, 6, 9, 11 and 19 + eyebrow_morphed_image_index then go to the handle's workspace); at least
+ *                   one must be given (e.g. the distiller asks for 0,1,2,3,5 only, siren_morpher_protocols_03.py:56-72).
  *   reuse_decomposer  non-zero: the image (and batch) is unchanged since the previous call on this handle,
  *                   reuse the cached eyebrow-decomposer result (the reference detects this with a
  *                   max|delta| device->host sync, mode_07.py:56-61; here the caller states it). */
@@ -246,8 +247,11 @@ int tha4_full_numeric_status(tha4_full* h, int synchronize);
  * price of one refused frame).  THA4_FAULT_STATUS_ONLY: tha4_full_pose never refuses; the fault is reported through
  * tha4_full_numeric_status only - for real-time callers that poll it (synchronize = 0 costs nothing) and cannot lose a frame to a
  * deferred report; while a fault is pending (raised, not yet polled) reuse_decomposer is ignored - the persistent eyebrow-decomposer
- * outputs may be the faulted call's, so they are recomputed every call until the status is read.  Either way the outputs of the
- * faulting call itself are not finite / not trustworthy. */
+ * outputs may be the faulted call's, so they are recomputed every call until the status is read.  The flag is peeked at ENQUEUE time
+ * without synchronising: "pending" starts with the first call enqueued after the fault has become host-visible - calls enqueued while
+ * the faulting call was still queued or running (a caller that submits several frames ahead) may still reuse the decomposer outputs
+ * of the faulting call; a caller that needs the guarantee from the very next call polls with synchronize != 0 after each new image.
+ * Either way the outputs of the faulting call itself are not finite / not trustworthy. */
 #define THA4_FAULT_REFUSE_NEXT 0
 #define THA4_FAULT_STATUS_ONLY 1
 int tha4_full_set_fault_policy(tha4_full* h, int policy);

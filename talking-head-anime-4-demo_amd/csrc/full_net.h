@@ -143,7 +143,6 @@ class FullModel {
   // ---- schedule -------------------------------------------------------------------------------
   struct Frame {            // per-call bindings
     const float* image; long long image_stride; const float* pose; int batch; hipStream_t stream;
-    hipStream_t side;       // second stream of the handle for independent side branches (null: everything on `stream`)
     float* out[33];         // NCHW outputs in the reference order; null = not requested and read by no later stage (the kernels skip its stores)
     unsigned char* rgba8; int rgba8_has_bg; float rgba8_bg[3];    // fused display epilogue of out[0] (tha4_display) or null
   };
@@ -159,58 +158,9 @@ class FullModel {
     if (v.size() < ops.size()) v.push_back(OpInfo{label, gflop});
   }
 
-  // ---- side branches (round 5): MEASURED NEGATIVE, off unless THA4_TUNING + THA4_SIDE_STREAM are set ------------------------------
-  // A batch-1 frame is a chain of ~320 DEPENDENT launches, each a chain of dependent memory round trips: the chip idles
-  // on latency, not on throughput.  The few branches of the graph that do NOT lie on that chain - the 1x1 skip convolution of every
-  // ResBlock that changes width (unet.py:149-152: it reads the block's INPUT, the chain runs norm0 -> conv0 -> norm1 beside it: 27 per
-  // frame, ~0.35 ms), the cond MLP + FiLM projections of both U-Nets (they read the pose only) - can be enqueued on a second stream of the
-  // handle between a fork (side waits for main) and a join (main waits for side).  Same kernels on the same operands: the bytes of a frame
-  // do not change (the GPU suite passes with it on).  But every fork and every join is a cross-queue dependency, and on this stack one costs
-  // ~8 us of chain time - more than the 7-38 us launches it hides save: same-box A/B (profiles/r05_raw/c2_ab.txt) 185.2 -> 169.2 frames/s
-  // steady (-9 %), 172.6 -> 157.9 cold, batch 8 343.5 -> 338.5.  Kept as a tuning aid; the product plan keeps one stream.
-  // Events are taken round-robin from a small pool; hipStreamWaitEvent captures the state of the event at the call, so re-recording it
-  // later is safe.
-  hipStream_t side_stream = nullptr;               // owned by the C ABI handle (created / destroyed there)
-  std::vector<hipEvent_t> side_events;
-  size_t side_cursor = 0;
-  int side_branches = 0;                           // fork / join pairs per steady frame (diagnostics)
-  hipEvent_t next_side_event() { return side_events[side_cursor++ % side_events.size()]; }
-  bool side_planned() const { return tune_env("THA4_SIDE_STREAM") != nullptr; }
-  // fork: everything emitted between side_fork() and side_join() that is wrapped by side_wrap() runs on the side stream
-  size_t side_fork(std::vector<Op>& ops) {
-    if (!side_planned()) return ops.size();
-    ++side_branches;
-    ops.push_back([this](const Frame& f) {
-      if (!f.side) return;
-      hipEvent_t e = next_side_event();
-      (void)hipEventRecord(e, f.stream);
-      (void)hipStreamWaitEvent(f.side, e, 0);
-    });
-    note(ops, "side-stream fork");
-    return ops.size();
-  }
-  void side_wrap(std::vector<Op>& ops, size_t first) {        // ops [first, end) -> the side stream
-    if (!side_planned()) return;
-    for (size_t i = first; i < ops.size(); ++i) {
-      Op inner = ops[i];
-      ops[i] = [inner](const Frame& f) {
-        if (!f.side) return inner(f);
-        Frame g = f;
-        g.stream = f.side;
-        inner(g);
-      };
-    }
-  }
-  void side_join(std::vector<Op>& ops) {
-    if (!side_planned()) return;
-    ops.push_back([this](const Frame& f) {
-      if (!f.side) return;
-      hipEvent_t e = next_side_event();
-      (void)hipEventRecord(e, f.side);
-      (void)hipStreamWaitEvent(f.stream, e, 0);
-    });
-    note(ops, "side-stream join");
-  }
+  // (Round 5 measured the frame's off-chain branches - the 27 skip convolutions, the FiLM gemvs - on a second stream of the handle between fork / join events:
+  //  parity-clean, 185.2 -> 169.2 frames/s steady: a cross-queue dependency costs ~8 us of chain time, more than the launches it hides.  The code was removed in
+  //  round 6; profiles/r05_boundaries_reading.md section 4 keeps the measurement.)
   size_t scratch_out[33];   // workspace offsets used for outputs the caller did not ask for
   // outputs of the 33-entry list that a later stage of the pipeline reads back (build() below): the combiner image the face morpher's input is pasted from
   // (19 + sel), the face morpher's output_image (11 -> paste_face), face_morphed_full (5 -> half image, upscaler input, the upscaler's warp source), the
@@ -740,7 +690,9 @@ class FullModel {
   // Normalisation finalize over up to two concatenated tensors; returns the pending transform per source.
   std::vector<Pending> norm(std::vector<Op>& ops, const std::vector<FTensor>& srcs, int channels, int groups,
                             const HostTensor& gamma, const HostTensor& beta, size_t film0_off = kNone,
-                            size_t film1_off = kNone, long long film1_stride = 0) {
+                            size_t film1_off = kNone, long long film1_stride = 0, bool consumers_read_acc = true) {
+    // consumers_read_acc = false: a consumer of this normalisation (affine_add_kernel) folds per-tile moments only - with the moment-accumulator tuning option
+    // on, a tensor of more than 64 tiles then takes the finalize launch instead of an accumulator-only Pending nobody could evaluate (round-5 advisor finding)
     std::vector<Pending> out(srcs.size());
     const size_t g_off = add_param(gamma.data, sizeof(float) * channels);
     const size_t b_off = add_param(beta.data, sizeof(float) * channels);
@@ -751,7 +703,7 @@ class FullModel {
     // (a batched call multiplies the consumers' workgroups, each of which would redo the reduction, while one finalize launch
     // serves all frames: fusing pays for max_batch <= 2 only - measured, profiles/r02_full_b1_reading.md)
     const int fuse_batch = fused_norm_max_batch();
-    bool all_acc = srcs.size() <= 2 && max_batch <= fuse_batch && acc_planned() && !tune_env("THA4_NO_SMALL_CONV");
+    bool all_acc = consumers_read_acc && srcs.size() <= 2 && max_batch <= fuse_batch && acc_planned() && !tune_env("THA4_NO_SMALL_CONV");
     for (auto& t : srcs) all_acc = all_acc && t.acc_off != kNone;
     const bool per_tile_ok = total_tiles <= fuse_max && max_batch <= fuse_batch && srcs.size() <= 2 && !tune_env("THA4_NO_SMALL_CONV") && !tune_env("THA4_NO_TILE_CONV") &&
                              !exact_fp32;
@@ -864,14 +816,14 @@ class FullModel {
     struct Lower { bool& f; bool saved; ~Lower() { f = saved; } } lower{exact_fp32, exact_fp32};
     if (bottleneck_on_split) exact_fp32 = false;
     x = conv(ops, K_SAME3, s0, IN_DIRECT, ACT_RELU, W("bottleneck_blocks.0.0.weight"), nullptr, 512, true);
-    px = norm(ops, {x}, 512, 0, W("bottleneck_blocks.0.1.weight"), W("bottleneck_blocks.0.1.bias"))[0];
+    px = norm(ops, {x}, 512, 0, W("bottleneck_blocks.0.1.weight"), W("bottleneck_blocks.0.1.bias"), kNone, kNone, 0, false)[0];      // (also read by affine_add)
     int act_x = ACT_RELU;       // x is "raw + pending IN/ReLU" after block 0, a plain tensor after every ResnetBlock
     for (int i = 1; i < 6; ++i) {
       const std::string b = "bottleneck_blocks." + std::to_string(i) + ".resnet_path.";
       FTensor r1 = conv(ops, K_SAME3, {src_tensor(x, 512, px)}, IN_DIRECT, act_x, W(b + "0.weight"), nullptr, 512, true);
       Pending p1 = norm(ops, {r1}, 512, 0, W(b + "1.weight"), W(b + "1.bias"))[0];
       FTensor r2 = conv(ops, K_SAME3, {src_tensor(r1, 512, p1)}, IN_DIRECT, ACT_RELU, W(b + "3.weight"), nullptr, 512, true);
-      Pending p2 = norm(ops, {r2}, 512, 0, W(b + "4.weight"), W(b + "4.bias"))[0];
+      Pending p2 = norm(ops, {r2}, 512, 0, W(b + "4.weight"), W(b + "4.bias"), kNone, kNone, 0, false)[0];                            // (read by affine_add)
       x = affine_add(ops, x, px, act_x, r2, p2);      // x + resnet_path(x)   (resnet_block.py:63-67)
       px = Pending();
       act_x = ACT_NONE;
@@ -965,16 +917,14 @@ class FullModel {
     int cin = 0;
     std::vector<FTensor> ts;
     for (auto& f : ins) { cin += f.channels; ts.push_back(f.t); }
-    // skip branch (unet.py:149-152,165) FIRST, on the side stream: it reads the block's inputs only, the chain norm0 -> conv0 -> norm1 runs beside it
+    // skip branch (unet.py:149-152,165) first: it reads the block's inputs only
     FTensor res;
     int res_mode = mode;
     const bool has_skip = cin != cout;
     if (has_skip) {
       std::vector<Src> ss;
       for (auto& f : ins) ss.push_back(src_tensor(f.t, f.channels));
-      const size_t first = side_fork(ops);
       res = conv(ops, K_SAME1, ss, IN_DIRECT, ACT_NONE, get(w, p + ".skip.weight"), get(w, p + ".skip.bias").data, cout, false);
-      side_wrap(ops, first);
       res_mode = IN_DIRECT;
     } else {
       res = ins[0].t;     // resampling blocks and same-width blocks have a single input
@@ -989,7 +939,6 @@ class FullModel {
     const size_t my_row = film1_row;
     film1_row += 2 * (size_t)cout;
     Pending p1 = norm(ops, {h}, cout, 32, get(w, p + ".norm1.weight"), get(w, p + ".norm1.bias"), f0_off, film1_base + my_row, film1_stride)[0];
-    if (has_skip) side_join(ops);
     FTensor o = conv(ops, K_SAME3, {src_tensor(h, cout, p1)}, IN_DIRECT, ACT_SILU, get(w, p + ".conv1.weight"),
                      get(w, p + ".conv1.bias").data, cout, true, &res, res_mode);
     return Feat{o, cout};
@@ -1045,17 +994,14 @@ class FullModel {
     const size_t c2b = add_param(get(w, key("cond_embed.2.bias")).data, sizeof(float) * 256);
     const size_t fw = add_param(wall), fb = add_param(ball);
     const size_t h1 = alloc_work(256), cemb = alloc_work(256), film1 = alloc_work(rows);
-    // cond MLP + all FiLM-1 projections: they read the pose only - on the side stream, under the first convolution
-    const size_t side_first = side_fork(ops);
+    // cond MLP + all FiLM-1 projections (they read the pose only)
     gemv(ops, c0w, c0b, 256, 6, [](const Frame& f) { return f.pose + 39; }, 45, h1, ACT_NONE, ACT_SILU);   // rotation pose = pose[:, 39:45]
     gemv(ops, c2w, c2b, 256, 256, [=](const Frame&) { return (const float*)Wk(h1); }, 256, cemb, ACT_NONE, ACT_NONE);
     gemv(ops, fw, fb, (int)rows, 256, [=](const Frame&) { return (const float*)Wk(cemb); }, 256, film1, ACT_SILU, ACT_NONE);
-    side_wrap(ops, side_first);
 
     size_t row = 0;
     const long long fstride = (long long)rows;
     FTensor h0 = conv(ops, K_SAME3, first_srcs, IN_DIRECT, ACT_NONE, first_w, nullptr, cfg.model, true, nullptr, IN_DIRECT, nullptr, &first_bias);
-    side_join(ops);
     std::vector<Feat> hs = {Feat{h0, cfg.model}};
     Feat h = hs[0];
     for (int i = 0; i < L; ++i) {

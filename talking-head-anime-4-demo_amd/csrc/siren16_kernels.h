@@ -766,6 +766,10 @@ __global__ void __launch_bounds__(WAVES * 64) level2_16p_kernel(StudentDev d) {
   // a workgroup's strips all belong to one frame (STRIPS is a multiple of PGW * WAVES): its pose-folded bias goes to LDS
   float* pb = reinterpret_cast<float*>(smem + Cfg::LDS);
   pose_bias_to_lds<kNB2, WAVES * 64>(d, 3, (xcd_tile(blockIdx.x, gridDim.x) * SPW) / STRIPS, pb);
+  // (Round 6, measured negative: publishing the 78 KiB of weight copies BEHIND the first strip's taps - an LDS-only barrier here, vmcnt(0) + s_barrier in
+  //  front of the first strip's first matrix layer - so that the copies' round trip hides under the taps' (ablation: the launch is 4 us shorter without the
+  //  copies).  With an LDS-DMA pending at the loop's entry the compiler's wait insertion puts s_waitcnt vmcnt(0) in front of every LDS read of the strip loop
+  //  - the pose-bias reads between the tap requests among them - and the two-block tap pipeline collapses: 45 -> 109 us, tools/runs_r06/gpu_r06_c20.sh.)
   __syncthreads();
   const char* w1 = smem + w.lane * 16;
   const char* w2 = w1 + (size_t)Cfg::kHidden * 2048;
@@ -992,6 +996,11 @@ THA4_DEV void first16_up_batched(const float* zframe, int lowS, const float* wx,
   }
 }
 
+#ifndef THA4_L1_ONE_TRIP_PROLOGUE
+#define THA4_L1_ONE_TRIP_PROLOGUE 1
+#endif
+template <int NB, int THREADS, int NBIAS, int NSCL>
+THA4_DEV void prologue_to_lds(const StudentDev& d, int net, int n, const float* bsrc, const float* ssrc, float* pb, float* bias_lds);      // (defined with the front kernel below)
 template <int WAVES, int PG, int SLOTS>
 __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
   warm_kernarg<(int)sizeof(StudentDev)>();
@@ -1005,17 +1014,27 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
   const bool son = blockIdx.x == 0 && w.wave == 0;
   THA4_SPAN(d, 2, 0);
   THA4_STAMP(d, son, 3, 0);
-#pragma unroll
-  for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
   int pix0[PG], X0[PG], Y[PG];
   float px[PG], py[PG];
   const int n = slot_pixels<G, S>(w, d.pos256, pix0, X0, Y, px, py);
   float* pb = reinterpret_cast<float*>(smem + Cfg::kPbOff);
   float* bias_lds = reinterpret_cast<float*>(smem + Cfg::kBiasOff);
+#if THA4_L1_ONE_TRIP_PROLOGUE
+  // (as in front16r_kernel: every table load of the prologue requested before any is consumed - one memory round trip instead of three - and IN FRONT of the
+  //  ring's first 48 KiB, behind which they would queue; LDS-only barrier: the ring copies stay in flight under the first layer's taps, chunk 0's own counted
+  //  barrier publishes them)
+  prologue_to_lds<kNB1, WAVES * 64, Cfg::kBiasFloats, 3>(d, 2, n, d.b_l1, d.s_l1, pb, bias_lds);
+#pragma unroll
+  for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
+  THA4_BARRIER_LDS();
+#else
+#pragma unroll
+  for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
   pose_bias_to_lds<kNB1, WAVES * 64>(d, 2, n, pb);
   for (int c = threadIdx.x; c < Cfg::kBiasFloats + 3; c += WAVES * 64) bias_lds[c] = c < Cfg::kBiasFloats ? d.b_l1[c] : d.s_l1[c - Cfg::kBiasFloats];
   for (int c = threadIdx.x; c < 2 * kNB1 * 16; c += WAVES * 64) pb[kNB1 * 16 + c] = c < kNB1 * 16 ? d.wx[2][c] : d.wy[2][c - kNB1 * 16];
   __syncthreads();                                             // (drains vmcnt: chunks 0 .. kPre - 1 have landed for every wave)
+#endif
   THA4_STAMP(d, son, 3, 2);
   const int g4 = (w.lane >> 4) * 4;
   f16x8 xh[kKG1][PG], xl[kKG1][PG];
@@ -1260,9 +1279,16 @@ THA4_DEV void layer_regs(const Ring& ring, int c0, int nc, const f16x8 (&xh)[KGX
 }
 
 // sine epilogue of a register-resident layer: x <- split(sin(acc / S + c b)), biases and 1/S from LDS
-template <int NB, int KG, int PG>
+// PB: priority base of the calling workgroup (front16r_kernel: THA4_FRONT_L0_PRIO lifts the level-0 waves - the launch's critical path - above the face
+// waves they share their SIMDs with: matrix phase PB, VALU phase PB + 1)
+#if !defined(THA4_EMU) && THA4_PHASE_PRIO
+#define THA4_PRIO_SET(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define THA4_PRIO_SET(p)
+#endif
+template <int NB, int KG, int PG, int PB = 0>
 THA4_DEV void sine_regs(const f32x4 (&acc)[NB][PG], const float* bias_lds, float inv, int g4, f16x8 (&xh)[KG][PG], f16x8 (&xl)[KG][PG]) {
-  THA4_PRIO_VALU();
+  THA4_PRIO_SET(PB + 1);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + b * 16 + g4);
@@ -1275,7 +1301,7 @@ THA4_DEV void sine_regs(const f32x4 (&acc)[NB][PG], const float* bias_lds, float
     }
   }
   pin_rows<KG, PG>(xh, xl);
-  THA4_PRIO_MFMA();
+  THA4_PRIO_SET(PB);
 }
 
 // (wx, wy, pb: LDS copies - 2 x NB global loads per wave here would either all be in flight at once (4 VGPRs each) or serialise into NB round trips)
@@ -1327,7 +1353,7 @@ THA4_DEV void prologue_to_lds(const StudentDev& d, int net, int n, const float* 
     s[r][1] = 0.f;
     s[r][2] = 0.f;
 #pragma unroll
-    for (int k = 0; k < kPose; ++k) s[r][k % 3] = fmaf(wp[(size_t)k * W], pose[k], s[r][k % 3]);
+    for (int k = 0; k < kPose; ++k) s[r][k % 3] = fmaf(wp[(size_t)THA4_HOOK_POSE_ROW(k) * W], pose[k], s[r][k % 3]);
   }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
@@ -1346,6 +1372,9 @@ THA4_DEV void prologue_to_lds(const StudentDev& d, int net, int n, const float* 
   }
 }
 
+#ifndef THA4_FRONT_L0_PRIO
+#define THA4_FRONT_L0_PRIO 0     // priority base of the level-0 waves of front16r_kernel (the face waves stay at 0): 1 = level 0 wins every issue conflict
+#endif
 template <int NBC0, int SLOTS0, int NBCF, int SLOTSF>
 struct FrontRCfg {
   static constexpr int WAVES = 4, PG = 1, THREADS = WAVES * 64, PX = WAVES * PG * 16;
@@ -1374,6 +1403,7 @@ THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w
   using Ring = typename Cfg::Ring0;
   constexpr int PG = Cfg::PG, S = 128, NPIX = S * S, NC = Cfg::kChunks0, NBC = Ring::kChunk / 2048;
   const Ring ring{reinterpret_cast<const char*>(d.w_l0), smem, w.wave, w.lane};
+  THA4_PRIO_SET(THA4_FRONT_L0_PRIO);
   const bool son = (w.blk == 0 && w.wave == 0) || (w.blk == 131 && w.wave == 3);
   const StampCtx st{&d, son, w.blk == 0 ? 0 : 1};
   THA4_STAMP(d, son, st.slot, 0);
@@ -1393,17 +1423,18 @@ THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w
   const int g4 = (w.lane >> 4) * 4;
   const float* scl = bias_lds + Cfg::kBias0;
   f16x8 xh[kKG0][PG], xl[kKG0][PG];
-  THA4_PRIO_VALU();
+  constexpr int PB = THA4_FRONT_L0_PRIO;
+  THA4_PRIO_SET(PB + 1);
   first16_pos_to<G, kNB0>(pb + kNB0 * 16, pb + 2 * kNB0 * 16, pb, px, py, [&](int pg, int b, const f32x4& v) { put_rows<kKG0, PG>(xh, xl, pg, b, v); }, w);
   pin_rows<kKG0, PG>(xh, xl);
-  THA4_PRIO_MFMA();
+  THA4_PRIO_SET(PB);
   THA4_STAMP(d, son, st.slot, 3);
   {   // 360 -> 360, sine
     f32x4 acc[kNB0][PG];
     zero_acc<kNB0, PG>(acc);
     layer_regs_e<kNB0, kKG0, NBC, 1>(ring, 0, NC, xh, xl, acc, st);
     THA4_STAMP(d, son, st.slot, 4);
-    sine_regs<kNB0, kKG0, PG>(acc, bias_lds, scl[0], g4, xh, xl);
+    sine_regs<kNB0, kKG0, PG, PB>(acc, bias_lds, scl[0], g4, xh, xl);
     THA4_STAMP(d, son, st.slot, 5);
   }
   f16x8 yh[kKG1][PG], yl[kKG1][PG];
@@ -1412,7 +1443,7 @@ THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w
     zero_acc<kNB1, PG>(acc);
     layer_regs_e<kNB1, kKG0, NBC, 1>(ring, Cfg::kChunksA, NC, xh, xl, acc);
     THA4_STAMP(d, son, st.slot, 6);
-    sine_regs<kNB1, kKG1, PG>(acc, bias_lds + kNB0 * 16, scl[1], g4, yh, yl);
+    sine_regs<kNB1, kKG1, PG, PB>(acc, bias_lds + kNB0 * 16, scl[1], g4, yh, yl);
     THA4_STAMP(d, son, st.slot, 7);
   }
   {   // z1 = c W10[:, :180] h0 (fp32) -> global z[n][b][g][pix][4]; the consumer is level 1's first (sine) layer

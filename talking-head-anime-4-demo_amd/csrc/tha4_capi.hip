@@ -492,24 +492,6 @@ struct tha4_full {
   int fault_policy = THA4_FAULT_REFUSE_NEXT;
   StreamOrder order;
   int* fault = nullptr;        // pinned host memory, device-visible: the kernels' sticky numeric-fault flag
-  // second stream + event pool for the side branches of a frame (FullModel::side_fork / side_join)
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> side_events;
-  hipError_t create_side() {
-    hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-    for (int i = 0; i < 16 && e == hipSuccess; ++i) {
-      hipEvent_t ev = nullptr;
-      e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      if (e == hipSuccess) side_events.push_back(ev);
-    }
-    return e;
-  }
-  void destroy_side() {
-    for (hipEvent_t ev : side_events) (void)hipEventDestroy(ev);
-    side_events.clear();
-    if (side) (void)hipStreamDestroy(side);
-    side = nullptr;
-  }
 };
 
 int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
@@ -577,14 +559,11 @@ int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_im
   if (e == hipSuccess && m.acc_floats) e = hipMemset(m.dev_acc, 0, m.acc_floats * sizeof(float));
   if (e == hipSuccess) e = FullModel::allow_all_conv_lds();
   if (e == hipSuccess) e = h->order.create();
-  if (e == hipSuccess && m.side_planned()) e = h->create_side();
-  if (e == hipSuccess) { m.side_stream = h->side; m.side_events = h->side_events; }
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->fault, 64, hipHostMallocMapped);
   if (e == hipSuccess) { *h->fault = 0; m.fault = h->fault; }
   std::vector<char>().swap(m.host_params);
   if (e != hipSuccess) {
     h->order.destroy();
-    h->destroy_side();
     if (h->fault) (void)hipHostFree(h->fault);
     if (m.dev_params) (void)hipFree(m.dev_params);
     if (m.dev_work) (void)hipFree(m.dev_work);
@@ -635,7 +614,6 @@ int tha4_full_pose_ex(tha4_full* h, const float* image_dev, int64_t image_batch_
   FullModel::Frame f{};
   f.image = image_dev; f.image_stride = image_batch_stride; f.pose = pose_dev; f.batch = batch;
   f.stream = static_cast<hipStream_t>(stream);
-  f.side = (m.side_stream && !m.side_events.empty()) ? m.side_stream : nullptr;
   f.rgba8 = rgba8;
   f.rgba8_has_bg = rgba8 && display->background_rgb ? 1 : 0;
   for (int k = 0; k < 3; ++k) f.rgba8_bg[k] = f.rgba8_has_bg ? display->background_rgb[k] : 0.0f;
@@ -677,7 +655,14 @@ int tha4_full_set_timing(tha4_full* h, int enable) {
     m.timing_events.clear();
     for (size_t i = 0; i < want; ++i) {
       hipEvent_t e = nullptr;
-      HIP_TRY(hipEventCreate(&e));
+      const hipError_t err = hipEventCreate(&e);
+      if (err != hipSuccess) {               // nothing half-built stays behind: timing is off and untouched by a failed switch
+        for (hipEvent_t d : m.timing_events) (void)hipEventDestroy(d);
+        m.timing_events.clear();
+        m.timing_on = false;
+        m.timing_recorded = false;
+        return fail(THA4_ERR_HIP, std::string("tha4_full_set_timing: ") + hipGetErrorString(err));
+      }
       m.timing_events.push_back(e);
     }
   }
@@ -745,7 +730,6 @@ void tha4_full_destroy(tha4_full* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
   h->order.destroy();
-  h->destroy_side();
   for (hipEvent_t e : h->model.timing_events) (void)hipEventDestroy(e);
   h->model.timing_events.clear();
   if (h->fault) (void)hipHostFree(h->fault);

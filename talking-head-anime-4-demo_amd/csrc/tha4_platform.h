@@ -48,6 +48,9 @@
 #ifndef THA4_HOOK_CHUNK_BARRIER            // the per-chunk workgroup barrier of the streamed SIREN layers
 #define THA4_HOOK_CHUNK_BARRIER() __syncthreads()
 #endif
+#ifndef THA4_HOOK_POSE_ROW                 // row of the pose-weight matrix the fold reads for pose parameter k
+#define THA4_HOOK_POSE_ROW(k) (k)
+#endif
 #ifndef THA4_HOOK_ZLOAD                    // one z tap of the x2 upsample
 #define THA4_HOOK_ZLOAD(ptr, instead) (*reinterpret_cast<const f32x4*>(ptr))
 #endif
@@ -330,7 +333,7 @@ THA4_DEV void store16_wt(void* p, const tha4::f32x4& v) {
 #define THA4_TILE_OUT_WT 1
 #endif
 #ifndef THA4_POINT_OUT_WT
-#define THA4_POINT_OUT_WT 1
+#define THA4_POINT_OUT_WT 1      // the same for conv_point_kernel's outputs (1x1 convolutions on 64x64 .. 512x512 maps): +0.3 % steady on both rounds of gpu_r06_c16.sh
 #endif
 template <bool WT = (THA4_TILE_OUT_WT != 0)>
 THA4_DEV void store16_out(float* p, const tha4::f32x4& v) {

@@ -25,6 +25,9 @@
 #ifdef THA4_ABLATE_ZLOAD                   // no z-tap loads of the x2 upsample
 #define THA4_HOOK_ZLOAD(ptr, instead) (instead)
 #endif
+#ifdef THA4_ABLATE_POSEFOLD                // the pose fold of the register kernels' prologues reads 4 of its 45 weight rows (what a precomputed pose bias could save at most)
+#define THA4_HOOK_POSE_ROW(k) ((k) & 3)
+#endif
 #ifdef THA4_ABLATE_TILE_STAGE_VALU         // conv_tile_kernel: raw bits into the window (loads + LDS writes stay, the staging VALU goes)
 #define THA4_HOOK_TILE_STAGE_VALU_BYPASS 1
 #endif

@@ -48,6 +48,9 @@ def full():
     shutil.copy(os.path.join(G, "pf_kernel_stats.csv"), os.path.join(P, f"{tag}_full_b1_kernel_stats.csv"))
     if os.path.exists(os.path.join(G, "full_b1_traffic.json")):
         shutil.copy(os.path.join(G, "full_b1_traffic.json"), os.path.join(P, f"{tag}_full_b1_traffic.json"))
+    for b in (1, 8):                                                     # SQ summary per kernel template instance (tools/pmc_json.py --mode full, round 6)
+        if os.path.exists(os.path.join(G, f"full_b{b}_pmc.json")):
+            shutil.copy(os.path.join(G, f"full_b{b}_pmc.json"), os.path.join(P, f"{tag}_full_b{b}_pmc.json"))
     if os.path.exists(os.path.join(G, "full_b1_layers.json")):          # per-launch-class table of the last cold frame (bench.py quotes its dominant class)
         shutil.copy(os.path.join(G, "full_b1_layers.json"), os.path.join(P, f"{tag}_full_b1_layers.json"))
     md = [f"# {tag} - full THA4 model (mode_07), batch 1, MI355X",

@@ -25,6 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--mode", choices=("student", "full"), default="student",
+                    help="full: every kernel of the capture under its full template name (conv_tile_kernel<4, 4, 0, 1, 4>, ...), no grid filter")
     ap.add_argument("-o", required=True)
     a = ap.parse_args()
     out = {"source": "rocprofv3 --kernel-trace --pmc <SQ counters> (one pass per counter group), per-launch averages; tools/pmc_json.py", "batch": a.batch, "kernels": {}}
@@ -33,13 +35,18 @@ def main():
             acc = defaultdict(lambda: defaultdict(list))
             dur = defaultdict(dict)
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]
-                if k not in NAMES:
-                    continue
-                short = NAMES[k]
-                wgs = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) if "Grid_Size" in r and r.get("Workgroup_Size") else None
-                if wgs is not None and wgs not in tuple(g * a.batch for g in GRID_B1[short]):
-                    continue
+                if a.mode == "full":
+                    short = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tha4::", "").strip()
+                    if short.startswith("__amd") or "student" in short.lower():
+                        continue
+                else:
+                    k = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]
+                    if k not in NAMES:
+                        continue
+                    short = NAMES[k]
+                    wgs = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) if "Grid_Size" in r and r.get("Workgroup_Size") else None
+                    if wgs is not None and wgs not in tuple(g * a.batch for g in GRID_B1[short]):
+                        continue
                 acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 dur[short][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             for short, cs in acc.items():
@@ -49,15 +56,24 @@ def main():
                 e["passes"].append({"counters": sorted(avg), "launches": len(dur[short]), "avg_us_in_pass": round(us, 2)})
                 e["counters"].update({c: round(v, 1) for c, v in avg.items()})
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
-                    cyc = avg["GRBM_GUI_ACTIVE"] / 8.0 if "GRBM_GUI_ACTIVE" in avg else us * 2400.0
-                    e["mfma_busy"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)
-                    e["mfma_busy_clock"] = "GRBM_GUI_ACTIVE / 8 of the same pass" if "GRBM_GUI_ACTIVE" in avg else "2.4 GHz x the pass's launch duration (upper clock: a lower bound of the fraction)"
+                    e["_mfma_pass_us"] = us
+                if "GRBM_GUI_ACTIVE" in avg and us > 0:
+                    e["clock_mhz"] = round(avg["GRBM_GUI_ACTIVE"] / 8.0 / us, 1)          # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles: the shader clock the launch really ran at
                 if "SQ_WAVE_CYCLES" in avg:
                     for key, c in (("active", "SQ_ACTIVE_INST_ANY"), ("issue_stall", "SQ_WAIT_INST_ANY"), ("parked", "SQ_WAIT_ANY")):
                         if c in avg:
                             e[key] = round(avg[c] / avg["SQ_WAVE_CYCLES"], 4)
                 if "SQ_INSTS_MFMA" in avg and avg["SQ_INSTS_MFMA"] > 0 and "SQ_INSTS_VALU" in avg:
                     e["valu_per_mfma"] = round(avg["SQ_INSTS_VALU"] / avg["SQ_INSTS_MFMA"], 2)
+    for e in out["kernels"].values():          # matrix-pipe busy fraction: busy cycles / (1024 SIMDs x launch cycles), the cycles at the MEASURED clock where a GRBM pass exists
+        us = e.pop("_mfma_pass_us", None)
+        if us:
+            mhz = e.get("clock_mhz") or 2400.0
+            e["mfma_busy"] = round(e["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * mhz), 4)
+            e["mfma_busy_clock"] = ("launch duration of the SQ pass x the shader clock measured by the GRBM_GUI_ACTIVE pass" if e.get("clock_mhz")
+                                    else "2.4 GHz x the pass's launch duration (upper clock: a lower bound of the fraction)")
+        e["launches_per_pass"] = max(p_["launches"] for p_ in e["passes"])
+        e["avg_us"] = round(sum(p_["avg_us_in_pass"] for p_ in e["passes"]) / len(e["passes"]), 2)
     with open(a.o, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: {x: y for x, y in v.items() if x not in ("counters", "passes")} for k, v in out["kernels"].items()}, indent=1))

@@ -15,6 +15,14 @@ for B in 1 32; do
   timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pj${B}_c -- $SB > $R/gpurun_out/pj${B}_c.log 2>&1
   (cd $R && python tools/pmc_json.py gpurun_out/pj${B}_a gpurun_out/pj${B}_b gpurun_out/pj${B}_c --batch $B -o gpurun_out/student_b${B}_pmc.json; rm -rf gpurun_out/pj${B}_a gpurun_out/pj${B}_b gpurun_out/pj${B}_c)
 done
+# the same three SQ passes for the full model (batch 1 steady + cold frames, batch 8): per kernel template instance (tools/pmc_json.py --mode full)
+for B in 1 8; do
+  if [ $B = 1 ]; then FB="python $R/tools/time_full.py --frames 3"; else FB="python $R/tools/time_full.py --batch 8 --frames 5"; fi
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pjf${B}_a -- $FB > $R/gpurun_out/pjf${B}_a.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $R/gpurun_out/pjf${B}_b -- $FB > $R/gpurun_out/pjf${B}_b.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pjf${B}_c -- $FB > $R/gpurun_out/pjf${B}_c.log 2>&1
+  (cd $R && python tools/pmc_json.py --mode full gpurun_out/pjf${B}_a gpurun_out/pjf${B}_b gpurun_out/pjf${B}_c --batch $B -o gpurun_out/full_b${B}_pmc.json > gpurun_out/pjf${B}_summary.txt; rm -rf gpurun_out/pjf${B}_a gpurun_out/pjf${B}_b gpurun_out/pjf${B}_c)
+done
 cd $R
 cat gpurun_out/student_b1_pmc.json
 bash tools/profile_r03.sh

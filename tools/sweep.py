@@ -45,7 +45,7 @@ VARIANTS = {
     "allpg2_wait0": ["-DTHA4_L116_CFG=4,2,2,1,1", "-DTHA4_L016_CFG=2,4,2,3,1", "-DTHA4_FACE16_CFG=2,4,2,2", "-mllvm", "-amdgpu-waitcnt-forcezero=1"],
     # ---- timing ablations (results are wrong; tools/runs_r03/gpu_r03_ablate.sh) ----
     "ab_mfma": ["-DTHA4_ABLATE_MFMA"], "ab_sin": ["-DTHA4_ABLATE_SIN"], "ab_fetch": ["-DTHA4_ABLATE_FETCH"], "ab_barrier": ["-DTHA4_ABLATE_BARRIER"],
-    "ab_zload": ["-DTHA4_ABLATE_ZLOAD"], "ab_mfma_sin": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN"],
+    "ab_zload": ["-DTHA4_ABLATE_ZLOAD"], "ab_posefold": ["-DTHA4_ABLATE_POSEFOLD"], "ab_mfma_sin": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN"],
     "ab_fetch_barrier": ["-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER"],
     "ab_all": ["-DTHA4_ABLATE_MFMA", "-DTHA4_ABLATE_SIN", "-DTHA4_ABLATE_FETCH", "-DTHA4_ABLATE_BARRIER", "-DTHA4_ABLATE_ZLOAD"],
     # ---- conv_tile_kernel ablations (round 4; results are wrong): what pre-staged operands / async window fills could buy at most ----
@@ -88,6 +88,8 @@ VARIANTS = {
     "allregs0": ["-DTHA4_FRONT_REGS=0", "-DTHA4_L1_REGS=0"],
     "tilewt0": ["-DTHA4_TILE_OUT_WT=0"],           # full model: plain instead of write-through (sc1) output stores of conv_tile_kernel (A/B: tools/ab_full.py)
     "pointwt0": ["-DTHA4_POINT_OUT_WT=0"],         # ... and of conv_point_kernel
+    "l1pro0": ["-DTHA4_L1_ONE_TRIP_PROLOGUE=0"],   # level1_16r_kernel: the prologue of its first form (ring burst first, three table loops, vmcnt-draining barrier)
+    "l0prio1": ["-DTHA4_FRONT_L0_PRIO=1"], "l0prio2": ["-DTHA4_FRONT_L0_PRIO=2"],   # front16r_kernel: level-0 waves above the face waves of their SIMDs
     "cwait": ["-DTHA4_NEVER_BUILT_HERE"],                                           # (a copy of an earlier build kept for a same-box A/B: never rebuilt by `build`)
     "stamps": ["-DTHA4_STAMPS"],                                                  # in-kernel time stamps (tools/stamps_student.py)
     "pf1": ["-DTHA4_REGS_PREFETCH=1"], "pf3": ["-DTHA4_REGS_PREFETCH=3"],        # A-fragment look-ahead of the register-resident kernels in steps (default 2)
