@@ -153,7 +153,7 @@ def pmc_evidence(k, source):
     if not k:
         return {"limiter": "unknown: no PMC capture committed for this kernel (tools/pmc_json.py)"}
     ev = {"mfma_busy": k.get("mfma_busy"), "wave_time": {x: k.get(x) for x in ("active", "issue_stall", "parked") if k.get(x) is not None},
-          "valu_per_mfma": k.get("valu_per_mfma"), "clock_mhz_in_capture": k.get("clock_mhz"), "pmc_source": source}
+          "valu_per_mfma": k.get("valu_per_mfma"), "pmc_source": source}
     busy = k.get("mfma_busy") or 0.0
     parked, stall = k.get("parked") or 0.0, k.get("issue_stall") or 0.0
     if busy >= 0.6:

@@ -58,7 +58,9 @@ def main():
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
                     e["_mfma_pass_us"] = us
                 if "GRBM_GUI_ACTIVE" in avg and us > 0:
-                    e["clock_mhz"] = round(avg["GRBM_GUI_ACTIVE"] / 8.0 / us, 1)          # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles: the shader clock the launch really ran at
+                    # (diagnostic only: GRBM_GUI_ACTIVE / 8 XCDs / launch duration comes out at 2.5 - 2.9 GHz - the counter also runs while the launch is dispatched and
+                    #  retired - so it is NOT used as the clock of the busy fraction)
+                    e["grbm_gui_active_mhz"] = round(avg["GRBM_GUI_ACTIVE"] / 8.0 / us, 1)
                 if "SQ_WAVE_CYCLES" in avg:
                     for key, c in (("active", "SQ_ACTIVE_INST_ANY"), ("issue_stall", "SQ_WAIT_INST_ANY"), ("parked", "SQ_WAIT_ANY")):
                         if c in avg:
@@ -68,10 +70,8 @@ def main():
     for e in out["kernels"].values():          # matrix-pipe busy fraction: busy cycles / (1024 SIMDs x launch cycles), the cycles at the MEASURED clock where a GRBM pass exists
         us = e.pop("_mfma_pass_us", None)
         if us:
-            mhz = e.get("clock_mhz") or 2400.0
-            e["mfma_busy"] = round(e["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * mhz), 4)
-            e["mfma_busy_clock"] = ("launch duration of the SQ pass x the shader clock measured by the GRBM_GUI_ACTIVE pass" if e.get("clock_mhz")
-                                    else "2.4 GHz x the pass's launch duration (upper clock: a lower bound of the fraction)")
+            e["mfma_busy"] = round(e["counters"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * 2400.0), 4)
+            e["mfma_busy_clock"] = "2.4 GHz (the part's peak shader clock) x the SQ pass's launch duration: a LOWER bound of the fraction when the chip clocks lower under load"
         e["launches_per_pass"] = max(p_["launches"] for p_ in e["passes"])
         e["avg_us"] = round(sum(p_["avg_us_in_pass"] for p_ in e["passes"]) / len(e["passes"]), 2)
     with open(a.o, "w") as fh:
