@@ -594,7 +594,7 @@ THA4_DEV void warp_blend_store(const StudentDev& d, int n, const float* head_bia
     const size_t pix = (size_t)pix0[pg] + p;
     THA4_HOOK_BEFORE_STORES();
     if (d.out_rgba8) store_display(d, n, pix, g, p, blended);      // (first: it LOADS the background colour, and a load behind a store waits for the store's acknowledgement)
-    if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;
+    if (d.out_blended) d.out_blended[((size_t)n * 4 + g) * NPIX + pix] = blended;      // (write-through stores of the posed frame: measured neutral, tools/runs_r06/gpu_r06_c23.sh)
     if (d.out_color) d.out_color[((size_t)n * 4 + g) * NPIX + pix] = col;
     if (d.out_warped) d.out_warped[((size_t)n * 4 + g) * NPIX + pix] = wv;
     if (d.out_alpha && g == 0) d.out_alpha[(size_t)n * NPIX + pix] = al;
@@ -931,9 +931,11 @@ THA4_DEV void mma_chunk_regs(const char* wv, const f16x8 (&xh)[KG][PG], const f1
 #ifndef THA4_TAP_BATCH
 #define THA4_TAP_BATCH 4
 #endif
-template <class G, int NB, int TB, class Sink>
+// `between()` (round 6): called once BEHIND the first two batches' requests and in front of the first consume - the caller's prologue (table loads -> LDS,
+// ring burst, barrier) then runs under the first taps' round trip instead of in front of it; wx / wy / pb need only be valid when it returns.
+template <class G, int NB, int TB, class Sink, class Between>
 THA4_DEV void first16_up_batched(const float* zframe, int lowS, const float* wx, const float* wy, const float* pb, const int (&X0)[G::PG], const int (&Y)[G::PG],
-                                 const float (&x)[G::PG], const float (&y)[G::PG], Sink&& sink, const WaveCtx& w) {
+                                 const float (&x)[G::PG], const float (&y)[G::PG], Sink&& sink, const WaveCtx& w, Between&& between) {
   constexpr int PG = G::PG, KB = NB / TB, STEPS = PG * KB;
   static_assert(NB % TB == 0, "the tap batch must divide the layer's blocks");
   const int p = w.lane & 15, g4 = (w.lane >> 4) * 4;
@@ -984,20 +986,23 @@ THA4_DEV void first16_up_batched(const float* zframe, int lowS, const float* wx,
       sink(pg, b, v);
     }
   };
-  Batch cur = request(0);
+  static_assert(STEPS >= 2, "two batches are requested ahead");
+  Batch cur = request(0), nxt = request(1);
+  THA4_SCHED_FENCE();
+  between();
+  THA4_SCHED_FENCE();
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    Batch nxt = cur;
-    if (s + 1 < STEPS) nxt = request(s + 1);
     THA4_SCHED_FENCE();
     consume(s, cur);
     THA4_SCHED_FENCE();
     cur = nxt;
+    if (s + 2 < STEPS) nxt = request(s + 2);
   }
 }
 
-#ifndef THA4_L1_ONE_TRIP_PROLOGUE
-#define THA4_L1_ONE_TRIP_PROLOGUE 1
+#ifndef THA4_L1_TAPS_FIRST
+#define THA4_L1_TAPS_FIRST 0      // 1: the first two tap batches are requested in front of the prologue - measured neutral (35.7 vs 35.6 us, stream -0.4 %: tools/runs_r06/gpu_r06_c24.sh); 0: prologue, then taps
 #endif
 template <int NB, int THREADS, int NBIAS, int NSCL>
 THA4_DEV void prologue_to_lds(const StudentDev& d, int net, int n, const float* bsrc, const float* ssrc, float* pb, float* bias_lds);      // (defined with the front kernel below)
@@ -1019,28 +1024,23 @@ __global__ void __launch_bounds__(WAVES * 64) level1_16r_kernel(StudentDev d) {
   const int n = slot_pixels<G, S>(w, d.pos256, pix0, X0, Y, px, py);
   float* pb = reinterpret_cast<float*>(smem + Cfg::kPbOff);
   float* bias_lds = reinterpret_cast<float*>(smem + Cfg::kBiasOff);
-#if THA4_L1_ONE_TRIP_PROLOGUE
-  // (as in front16r_kernel: every table load of the prologue requested before any is consumed - one memory round trip instead of three - and IN FRONT of the
-  //  ring's first 48 KiB, behind which they would queue; LDS-only barrier: the ring copies stay in flight under the first layer's taps, chunk 0's own counted
-  //  barrier publishes them)
-  prologue_to_lds<kNB1, WAVES * 64, Cfg::kBiasFloats, 3>(d, 2, n, d.b_l1, d.s_l1, pb, bias_lds);
+  // The prologue - every table load requested before any is consumed (one memory round trip), IN FRONT of the ring's first 48 KiB (behind which the loads would
+  // queue), LDS-only barrier (the ring copies stay in flight; chunk 0's own counted barrier publishes them) - runs UNDER the round trip of the first two tap
+  // batches (THA4_L1_TAPS_FIRST; stamps of the first form: prologue 5.5 us, then 4.2 us of taps, before the first MFMA of a 27-us workgroup).
+  auto prologue = [&]() {
+    prologue_to_lds<kNB1, WAVES * 64, Cfg::kBiasFloats, 3>(d, 2, n, d.b_l1, d.s_l1, pb, bias_lds);
 #pragma unroll
-  for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
-  THA4_BARRIER_LDS();
-#else
-#pragma unroll
-  for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
-  pose_bias_to_lds<kNB1, WAVES * 64>(d, 2, n, pb);
-  for (int c = threadIdx.x; c < Cfg::kBiasFloats + 3; c += WAVES * 64) bias_lds[c] = c < Cfg::kBiasFloats ? d.b_l1[c] : d.s_l1[c - Cfg::kBiasFloats];
-  for (int c = threadIdx.x; c < 2 * kNB1 * 16; c += WAVES * 64) pb[kNB1 * 16 + c] = c < kNB1 * 16 ? d.wx[2][c] : d.wy[2][c - kNB1 * 16];
-  __syncthreads();                                             // (drains vmcnt: chunks 0 .. kPre - 1 have landed for every wave)
-#endif
-  THA4_STAMP(d, son, 3, 2);
+    for (int c = 0; c < Cfg::kPre; ++c) fetch(c);
+    THA4_BARRIER_LDS();
+    THA4_STAMP(d, son, 3, 2);
+  };
+  if (!THA4_L1_TAPS_FIRST) prologue();
   const int g4 = (w.lane >> 4) * 4;
   f16x8 xh[kKG1][PG], xl[kKG1][PG];
   THA4_PRIO_VALU();
   first16_up_batched<G, kNB1, THA4_TAP_BATCH>(d.z1 + (size_t)n * kNB1 * (128 * 128) * 16, 128, pb + kNB1 * 16, pb + 2 * kNB1 * 16, pb, X0, Y, px, py,
-                                              [&](int pg, int b, const f32x4& v) { put_rows<kKG1, PG>(xh, xl, pg, b, v); }, w);
+                                              [&](int pg, int b, const f32x4& v) { put_rows<kKG1, PG>(xh, xl, pg, b, v); }, w,
+                                              [&]() { if (THA4_L1_TAPS_FIRST) prologue(); });
   pin_rows<kKG1, PG>(xh, xl);
   THA4_PRIO_MFMA();
 #pragma unroll
@@ -1419,6 +1419,7 @@ THA4_DEV void level0_regs_body(const StudentDev& d, char* smem, const WaveCtx& w
 #pragma unroll
   for (int c = 0; c < Ring::kAhead; ++c) ring.fetch(c);        // (top(c) requests chunk c + kAhead)
   THA4_BARRIER_LDS();                                          // (the tables are in LDS for every wave; the ring copies stay in flight)
+  THA4_SPAN(d, 4, 0);                                          // (stamps builds: earliest / latest "prologue done" over the level-0 workgroups)
   THA4_STAMP(d, son, st.slot, 2);
   const int g4 = (w.lane >> 4) * 4;
   const float* scl = bias_lds + Cfg::kBias0;
@@ -1480,6 +1481,7 @@ THA4_DEV void face_regs_body(const StudentDev& d, char* smem, const WaveCtx& w) 
 #pragma unroll
   for (int c = 0; c < Ring::kAhead; ++c) ring.fetch(c);
   THA4_BARRIER_LDS();
+  THA4_SPAN(d, 4, 1);                                          // (... over the face workgroups)
   THA4_STAMP(d, son, 2, 2);
   const int g4 = (w.lane >> 4) * 4;
   const float* scl = bias_lds + Cfg::kBiasF;

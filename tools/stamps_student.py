@@ -38,7 +38,7 @@ def main():
     rows, spans = [], []
     host = torch.empty(800, dtype=torch.float32)
     init = torch.zeros(800, dtype=torch.float32).numpy().view(np.uint64)
-    init[320:336:2] = np.uint64(2 ** 63)                         # span slots: min fields start high, max fields at 0
+    init[320:340:2] = np.uint64(2 ** 63)                         # span slots: min fields start high, max fields at 0
     poser.pose(image, poses[0])                                  # (the handle is created lazily)
     torch.cuda.synchronize()
     for i in range(40):
@@ -50,7 +50,7 @@ def main():
         assert rc == 0, "not a -DTHA4_STAMPS build?"
         if i >= 8:
             rows.append(host.numpy().view(np.uint64).copy())
-            spans.append(host.numpy().view(np.uint64)[320:336].astype(np.int64).copy())
+            spans.append(host.numpy().view(np.uint64)[320:340].astype(np.int64).copy())
     a = np.stack(rows).astype(np.int64)                      # [frames, 400]
     for slot, names, title in ((0, L0, "level 0, workgroup 0 wave 0"), (1, L0, "level 0, workgroup 131 wave 3"), (2, FACE, "face, workgroup 0 wave 0"), (3, L1, "level 1, workgroup 0 wave 0")):
         s = a[:, slot * 64:(slot + 1) * 64]
@@ -69,6 +69,10 @@ def main():
     for k in range(4):
         v = np.median((sp[:, 4 * k:4 * k + 4] - t0) / 100.0, axis=0)
         print(f"  {names[k]:12s} first entry {v[0]:7.2f}  last entry {v[1]:7.2f}  first exit {v[2]:7.2f}  last exit {v[3]:7.2f}")
+
+
+    v = np.median((sp[:, 16:20] - t0) / 100.0, axis=0)
+    print(f"  prologue done (tables in LDS, barrier passed): level 0 wgs earliest {v[0]:7.2f} latest {v[1]:7.2f}   face wgs earliest {v[2]:7.2f} latest {v[3]:7.2f}")
 
 
 if __name__ == "__main__":

@@ -88,7 +88,7 @@ VARIANTS = {
     "allregs0": ["-DTHA4_FRONT_REGS=0", "-DTHA4_L1_REGS=0"],
     "tilewt0": ["-DTHA4_TILE_OUT_WT=0"],           # full model: plain instead of write-through (sc1) output stores of conv_tile_kernel (A/B: tools/ab_full.py)
     "pointwt0": ["-DTHA4_POINT_OUT_WT=0"],         # ... and of conv_point_kernel
-    "l1pro0": ["-DTHA4_L1_ONE_TRIP_PROLOGUE=0"],   # level1_16r_kernel: the prologue of its first form (ring burst first, three table loops, vmcnt-draining barrier)
+    "l1taps1": ["-DTHA4_L1_TAPS_FIRST=1"],         # level1_16r_kernel: the first two tap batches requested in front of the prologue
     "l0prio1": ["-DTHA4_FRONT_L0_PRIO=1"], "l0prio2": ["-DTHA4_FRONT_L0_PRIO=2"],   # front16r_kernel: level-0 waves above the face waves of their SIMDs
     "cwait": ["-DTHA4_NEVER_BUILT_HERE"],                                           # (a copy of an earlier build kept for a same-box A/B: never rebuilt by `build`)
     "stamps": ["-DTHA4_STAMPS"],                                                  # in-kernel time stamps (tools/stamps_student.py)
