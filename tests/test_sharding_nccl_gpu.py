@@ -153,9 +153,13 @@ def _solo_worker(port, q):
             mine = frames(0, total)
             full = FrameShardedStream(frames, total, (4, 512, 512), torch.float32, dev, chunk=4, gather=True, force_collective=True).run()
             got = {}
-            FrameShardedStream(frames_u8, total, (512, 512, 4), torch.uint8, dev, chunk=4, gather=True, force_collective=True, ring_slots=2,
-                               on_chunk=lambda lo, hi, fr: got.update({i: fr[i - lo].clone() for i in range(lo, hi)})).run()
+            st = FrameShardedStream(frames_u8, total, (512, 512, 4), torch.uint8, dev, chunk=4, gather=True, force_collective=True, ring_slots=2,
+                                    on_chunk=lambda lo, hi, fr: got.update({i: fr[i - lo].clone() for i in range(lo, hi)}), record_rounds=True)
+            st.run()
             torch.cuda.synchronize(dev)
+            # first-contact diagnostics (round 6): the per-round events on the gather's side stream, on the device
+            rep = st.round_report()
+            assert [r["frames_this_rank"] for r in rep] == [4, 4, 3] and all(r["ms"] > 0 and r["frames_all_ranks"] == r["frames_this_rank"] for r in rep), rep
             from tha4_amd import image_io
             want = image_io.to_display_rgba8(mine)
             ok = bool(torch.equal(full, mine)) and sorted(got) == list(range(total)) and all(bool(torch.equal(got[i], want[i])) for i in range(total))
