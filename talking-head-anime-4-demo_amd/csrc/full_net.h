@@ -828,7 +828,7 @@ class FullModel {
       px = Pending();
       act_x = ACT_NONE;
     }
-    exact_fp32 = lower.saved;
+    if (!(bottleneck_on_split && tune_env("THA4_DEC_DOWN_ONLY"))) exact_fp32 = lower.saved;      // (tuning aid: the up-sampling convolutions on the split plan too)
     for (int i = 0; i < 3; ++i) {
       const std::string b = "upsample_blocks." + std::to_string(i);
       x = conv(ops, K_CONVT, {src_tensor(x, c, px)}, IN_DIRECT, act_x, W(b + ".0.weight"), nullptr, c / 2, true);
@@ -1076,6 +1076,7 @@ class FullModel {
       image_op(ops, crop_eyebrow_kernel, 128 * 128, [=](const Frame&, ImgArgs& a) { a.c16_out = Wk(x.off); });
       FTensor feat; Pending fp;
       if (!encdec(ops, nets[0], "body.", x, 4, 0, 0, feat, fp)) return false;
+      if (bottleneck_on_split && tune_env("THA4_DEC_DOWN_ONLY")) exact_fp32 = false;                 // (... and the heads)
       FTensor hd = heads(ops, nets[0], {{"background_layer_alpha.0", 1, ACT_SIGMOID, true}, {"background_layer_color_change.0", 4, ACT_TANH, true},
                                         {"eyebrow_layer_alpha.0", 1, ACT_SIGMOID, true}, {"eyebrow_layer_color_change.0", 4, ACT_TANH, true}}, feat, fp);
       comb_in = new_tensor(1, 128, 128);

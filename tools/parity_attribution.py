@@ -55,7 +55,8 @@ def conv_class(net, x, w, transposed):
             return "encdec (decomposer + combiner + face morpher)"
         cin = w.shape[0] if transposed else w.shape[1]
         co = w.shape[1] if transposed else w.shape[0]
-        role = "first conv" if cin <= 8 else ("heads" if co <= 4 else ("bottleneck <= 32x32" if h <= 32 else "down / up convs"))
+        role = ("first conv" if cin <= 8 else "heads" if co <= 4 else "up convs (transposed 4x4)" if transposed else
+                "bottleneck 3x3" if w.shape[-1] == 3 else "down convs (4x4 stride 2)")
         return f"{net}: {role}"
     cout = w.shape[1] if transposed else w.shape[0]
     if cout == 7:
