@@ -426,25 +426,28 @@ __global__ void __launch_bounds__(64 * NW * MSW, NW == kTileWaves ? 2 * MSW : 2)
           bh[pg] = *reinterpret_cast<const f16x8*>(win_hi + rd + boff[pg] + toff);
           bl[pg] = *reinterpret_cast<const f16x8*>(win_lo + rd + boff[pg] + toff);
         }
-        if (TMBW == 4) {
-          // all A fragments of the tap are requested together with the B fragments: one LDS wait per tap instead of one per
+        if (TMBW % 4 == 0) {
+          // all A fragments of (four blocks of) the tap are requested together with the B fragments: one LDS wait per tap instead of one per
           // output block (the compiler otherwise reuses one register pair and waits lgkmcnt(0) before every block).  Only for
-          // the four-block tiles: with two blocks the extra registers cost the <2,4> kernels their third wave per SIMD
-          f16x8 ah[TMBW], al[TMBW];
+          // the four- and eight-block tiles: with two blocks the extra registers cost the <2,4> kernels their third wave per SIMD
 #pragma unroll
-          for (int b = 0; b < TMBW; ++b) {
-            ah[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048);
-            al[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + b) * 2048 + 1024);
-          }
-          THA4_SCHED_FENCE();
+          for (int hb = 0; hb < TMBW; hb += 4) {
+            f16x8 ah[4], al[4];
 #pragma unroll
-          for (int b = 0; b < TMBW; ++b) {
+            for (int b = 0; b < 4; ++b) {
+              ah[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + hb + b) * 2048);
+              al[b] = *reinterpret_cast<const f16x8*>(wsl + (size_t)(tt * TMB + hb + b) * 2048 + 1024);
+            }
+            THA4_SCHED_FENCE();
 #pragma unroll
-            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah[b], bh[pg], acc[b][pg]);
+            for (int b = 0; b < 4; ++b) {
 #pragma unroll
-            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(ah[b], bl[pg], acc[b][pg]);
+              for (int pg = 0; pg < PG; ++pg) acc[hb + b][pg] = mfma16h(ah[b], bh[pg], acc[hb + b][pg]);
 #pragma unroll
-            for (int pg = 0; pg < PG; ++pg) acc[b][pg] = mfma16h(al[b], bh[pg], acc[b][pg]);
+              for (int pg = 0; pg < PG; ++pg) acc[hb + b][pg] = mfma16h(ah[b], bl[pg], acc[hb + b][pg]);
+#pragma unroll
+              for (int pg = 0; pg < PG; ++pg) acc[hb + b][pg] = mfma16h(al[b], bh[pg], acc[hb + b][pg]);
+            }
           }
         } else {
 #pragma unroll

@@ -271,7 +271,7 @@ class FullModel {
     }
 #endif
 #define THA4_TCASE(TM, PGV) if (tmb == TM && pg == PGV) return launch_tile<TM, PGV>(inmode, a, grid, lds, s);
-    THA4_TCASE(4, 4) THA4_TCASE(4, 2) THA4_TCASE(4, 1) THA4_TCASE(2, 4) THA4_TCASE(2, 2) THA4_TCASE(2, 1)
+    THA4_TCASE(8, 2) THA4_TCASE(4, 4) THA4_TCASE(4, 2) THA4_TCASE(4, 1) THA4_TCASE(2, 4) THA4_TCASE(2, 2) THA4_TCASE(2, 1)
     THA4_TCASE(1, 4) THA4_TCASE(1, 2) THA4_TCASE(1, 1)
 #undef THA4_TCASE
   }
@@ -304,7 +304,7 @@ class FullModel {
   set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_DIRECT>));        \
   set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_UP2>));           \
   set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_POOL2>));
-    THA4_TALLOW(4, 4) THA4_TALLOW(4, 2) THA4_TALLOW(4, 1) THA4_TALLOW(2, 4) THA4_TALLOW(2, 2) THA4_TALLOW(2, 1)
+    THA4_TALLOW(8, 2) THA4_TALLOW(4, 4) THA4_TALLOW(4, 2) THA4_TALLOW(4, 1) THA4_TALLOW(2, 4) THA4_TALLOW(2, 2) THA4_TALLOW(2, 1)
     THA4_TALLOW(1, 4) THA4_TALLOW(1, 2) THA4_TALLOW(1, 1)
 #undef THA4_TALLOW
 #define THA4_TALLOW4(TM, PGV)                                                            \
@@ -421,6 +421,17 @@ class FullModel {
         small = sp.ok && sp.lds + table_bytes + 128 <= 160 * 1024;
       }
       if (small) { tiled = false; tmb = 1; mtiles = nb; }
+    }
+    // <8,2> output tile (round-5 review, task 2; tuning option THA4_TILE_TMB8): 128 output channels x 256 positions per eight-wave workgroup where the plan took <4,4> -
+    // the same sixteen accumulators per wave, half the window staging per FLOP, 20 instead of 16 LDS fragment reads per tap (profiles/r06_full_b8_reading.md)
+    if (tiled && !small && !point && tune_env("THA4_TILE_TMB8") && kind != K_SAME1 && nb % 8 == 0 && tmb == 4 && plan.pg == 4 && plan.ksplit == 1) {
+      const ConvGeom g0 = kind == K_SAME3 ? geom_conv_same(3) : kind == K_S2K4 ? geom_conv4_s2() : geom_convT4_s2(0, 0);
+      TileGeom best8;
+      for (int twl : {4, 5, 3}) {
+        const TileGeom t = tile_geom(g0, th, tw, 2, 8, twl, table_bytes);
+        if (t.ok && t.efficiency > best8.efficiency * 1.1f) best8 = t;
+      }
+      if (best8.ok && (long)best8.tiles * (nb / 8) * max_batch >= 256) { tmb = 8; mtiles = nb / 8; plan.pg = 2; plan.geom = best8; }
     }
     // four-wave workgroups, two per CU (conv_tile_kernel<..., NW = 4>): same per-wave tile, half the workgroup tile.  Only without a
     // K split (phase 2 reads the partials of an eight-wave phase 1) and where every parity class has a geometry within 80 KiB

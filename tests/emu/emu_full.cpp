@@ -327,7 +327,7 @@ int emu_conv(int kind, int k, int tmb, int pg, int in_mode, int act_in, int n, i
     else if (in_mode == IN_UP2) THA4_RUN((conv_tile_kernel<TM, PGV, IN_UP2>), grid, kTileThreads, lds, a);  \
     else THA4_RUN((conv_tile_kernel<TM, PGV, IN_POOL2>), grid, kTileThreads, lds, a);                       \
   }
-    RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 4) RUNT(1, 2) RUNT(1, 1)
+    RUNT(8, 2) RUNT(4, 4) RUNT(4, 2) RUNT(4, 1) RUNT(2, 4) RUNT(2, 2) RUNT(2, 1) RUNT(1, 4) RUNT(1, 2) RUNT(1, 1)
 #undef RUNT
 #define RUNT4(TM, PGV)                                                                                         \
   if (tiled && tile4 && run_tmb == TM && tpg == PGV) {                                                         \

@@ -117,6 +117,7 @@ CASES = [
     (0, 3, 2, 12, 0, "relu", 96, 27, True, 16, 16, 64, True, True, False, True, (4, 4)),    # split-K x4 (8 K groups), pose vector, residual
     (0, 3, 4, 12, 0, "silu", 80, 0, False, 16, 16, 64, True, False, False, True, (4, 3)),   # split-K x3 over 3 K groups (5 quads)
     (0, 3, 2, 11, 0, "relu", 32, 0, False, 24, 24, 32, True, True, False, True, (3, 1)),    # ragged: 24x24 map in 16x8 tiles (rows 24..31 masked)
+    (0, 3, 8, 12, 0, "silu", 48, 16, False, 16, 16, 128, True, True, False, True, (4, 1)),  # <8,2> tile (round 6, tuning option THA4_TILE_TMB8): 128 output channels per workgroup, concat + residual
     (0, 3, 2, 12, 0, "relu", 64, 0, False, 24, 24, 32, True, False, False, True, (5, 2)),   # ragged 8x32 tiles (cols 24..31 masked) + split-K
     (2, 4, 2, 11, 0, "relu", 64, 0, False, 12, 12, 32, False, False, False, True, (4, 2)),  # convT on a 12x12 map: ragged + split-K, 4 classes
     (1, 4, 2, 11, 0, "relu", 32, 0, False, 48, 48, 32, False, False, False, True, (3, 1)),  # 4x4 s2 -> 24x24 in 16x8 tiles (34x18 window)
