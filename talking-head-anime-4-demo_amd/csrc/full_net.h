@@ -260,7 +260,7 @@ class FullModel {
   static void dispatch_tile(int tmb, int pg, int inmode, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, bool nw4 = false) {
     if (nw4) {
 #define THA4_TCASE4(TM, PGV) if (tmb == TM && pg == PGV) return launch_tile4<TM, PGV>(inmode, a, grid, lds, s);
-      THA4_TCASE4(4, 4) THA4_TCASE4(4, 2) THA4_TCASE4(4, 1) THA4_TCASE4(2, 4) THA4_TCASE4(2, 2) THA4_TCASE4(2, 1)
+      THA4_TCASE4(8, 2) THA4_TCASE4(4, 4) THA4_TCASE4(4, 2) THA4_TCASE4(4, 1) THA4_TCASE4(2, 4) THA4_TCASE4(2, 2) THA4_TCASE4(2, 1)
 #undef THA4_TCASE4
     }
 #ifdef THA4_TILE16_BUILD
@@ -311,7 +311,7 @@ class FullModel {
   set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_DIRECT, 1, 4>));        \
   set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_UP2, 1, 4>));           \
   set(reinterpret_cast<const void*>(conv_tile_kernel<TM, PGV, IN_POOL2, 1, 4>));
-    THA4_TALLOW4(4, 4) THA4_TALLOW4(4, 2) THA4_TALLOW4(4, 1) THA4_TALLOW4(2, 4) THA4_TALLOW4(2, 2) THA4_TALLOW4(2, 1)
+    THA4_TALLOW4(8, 2) THA4_TALLOW4(4, 4) THA4_TALLOW4(4, 2) THA4_TALLOW4(4, 1) THA4_TALLOW4(2, 4) THA4_TALLOW4(2, 2) THA4_TALLOW4(2, 1)
 #undef THA4_TALLOW4
 #ifdef THA4_TILE16_BUILD
 #define THA4_TALLOW16(TM, PGV)                                                        \
@@ -422,6 +422,8 @@ class FullModel {
       }
       if (small) { tiled = false; tmb = 1; mtiles = nb; }
     }
+    bool tmb8_nw4 = false;
+    int tmb8_twl4 = 4;
     // <8,2> output tile (round-5 review, task 2; tuning option THA4_TILE_TMB8): 128 output channels x 256 positions per eight-wave workgroup where the plan took <4,4> -
     // the same sixteen accumulators per wave, half the window staging per FLOP, 20 instead of 16 LDS fragment reads per tap (profiles/r06_full_b8_reading.md)
     if (tiled && !small && !point && tune_env("THA4_TILE_TMB8") && kind != K_SAME1 && nb % 8 == 0 && tmb == 4 && plan.pg == 4 && plan.ksplit == 1) {
@@ -432,6 +434,15 @@ class FullModel {
         if (t.ok && t.efficiency > best8.efficiency * 1.1f) best8 = t;
       }
       if (best8.ok && (long)best8.tiles * (nb / 8) * max_batch >= 256) { tmb = 8; mtiles = nb / 8; plan.pg = 2; plan.geom = best8; }
+      // THA4_TILE_TMB8=2: the same tile on FOUR-wave workgroups (128 positions, two workgroups per CU: one's staging under the other's MFMAs)
+      if (tmb == 8 && std::atoi(tune_env("THA4_TILE_TMB8")) == 2) {
+        TileGeom b4;
+        for (int twl : {4, 3, 5}) {
+          const TileGeom t = tile_geom(g0, th, tw, 2, 8, twl, table_bytes, 4);
+          if (t.ok && t.efficiency > b4.efficiency * 1.1f) { b4 = t; tmb8_twl4 = twl; }
+        }
+        tmb8_nw4 = b4.ok && (long)b4.tiles * (nb / 8) * max_batch >= 512;
+      }
     }
     // four-wave workgroups, two per CU (conv_tile_kernel<..., NW = 4>): same per-wave tile, half the workgroup tile.  Only without a
     // K split (phase 2 reads the partials of an eight-wave phase 1) and where every parity class has a geometry within 80 KiB
@@ -451,6 +462,7 @@ class FullModel {
       const long min_wgs = tune_env("THA4_TILE_NW4_MIN_WGS") ? std::atol(tune_env("THA4_TILE_NW4_MIN_WGS")) : (max_batch == 1 ? 512 : 2 * 512);
       if (nw4 && (long)tiles4 * mtiles * max_batch < min_wgs) nw4 = false;
     }
+    if (tmb8_nw4) { nw4 = true; twl4 = tmb8_twl4; }
     // 1x1 convolutions on SMALL maps of a batched plan (round 5): conv_small_kernel refuses grids of several rounds, and these 32 launches of a batch-8 step
     // (qkv / attention projections / skips at 16x16 and 32x32) used to fall back to the exact-fp32 conv_splitk_kernel (2 % of the step): with the frames of the
     // batch there are enough pixel tiles for conv_point_kernel
