@@ -187,7 +187,9 @@ typedef struct tha4_full_weights {
 typedef struct tha4_full tha4_full; /* opaque */
 
 /* Replaces: the five mode_07.load_* loaders + GeneralPoser02.get_modules (mode_07.py:137-269,
- * general_poser_02.py:41-49).  `eyebrow_morphed_image_index` as in mode_07.create_poser (:275). */
+ * general_poser_02.py:41-49).  `eyebrow_morphed_image_index` as in mode_07.create_poser (:275).
+ * = tha4_full_create_ex(..., num_networks = 5, flags = THA4_FULL_EXACT_DECOMPOSER_OUTER): the recommended (mixed) plan, the one the
+ * Python mirror creates by default (ABI v6; rounds 1-5: flags = 0, the pure fp16 hi/lo plan - still available through _ex). */
 int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
                      tha4_full** out);
 

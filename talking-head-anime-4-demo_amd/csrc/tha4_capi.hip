@@ -496,7 +496,7 @@ struct tha4_full {
 
 int tha4_full_create(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
                      tha4_full** out) {
-  return tha4_full_create_ex(weights, eyebrow_morphed_image_index, device, max_batch, 5, 0u, out);
+  return tha4_full_create_ex(weights, eyebrow_morphed_image_index, device, max_batch, 5, THA4_FULL_EXACT_DECOMPOSER_OUTER, out);      // the mixed default plan (ABI v6)
 }
 
 int tha4_full_create_ex(const tha4_full_weights* weights, int eyebrow_morphed_image_index, int device, int max_batch,
