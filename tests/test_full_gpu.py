@@ -687,6 +687,25 @@ def test_midgain_set_all_33_outputs_vs_reference_fixture(plan, golden_io):
     assert a.min() < 0.25 and a.max() > 0.8                               # the set is what it claims to be (stride-3 subset; full maps 0.13 .. 0.91)
 
 
+def test_c_abi_plain_create_takes_the_mixed_default_plan(weights):
+    """ABI v6: `tha4_full_create` (the entry point without a flags argument) plans the handle like the Python mirror's default - the "outer" mixed plan;
+    `tha4_full_create_ex(..., flags = 0)` stays the pure fp16 hi/lo plan of rounds 1-5."""
+    import ctypes as C
+    from tha4_amd import _capi
+    lib = _capi.load_library()
+    conv = {n: {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()} for n, sd in weights.items()}
+    ws, keep = _capi.build_full_weights(conv)
+    h = C.c_void_p()
+    _capi.check(lib, lib.tha4_full_create(C.byref(ws), 2, 0, 1, C.byref(h)), "tha4_full_create")
+    assert lib.tha4_full_flags(h) == _capi.FULL_EXACT_DECOMPOSER_OUTER
+    lib.tha4_full_destroy(h)
+    h2 = C.c_void_p()
+    _capi.check(lib, lib.tha4_full_create_ex(C.byref(ws), 2, 0, 1, 5, 0, C.byref(h2)), "tha4_full_create_ex")
+    assert lib.tha4_full_flags(h2) == 0
+    lib.tha4_full_destroy(h2)
+    del keep
+
+
 def test_per_op_timing_and_labels(poser1, full_io, golden_io):
     """ABI v5 measurement aid (bench.py's live full-model roofline): every op of the schedule has a label naming the reference layer and
     the kernel, the convolution labels carry the as-written GFLOP of their layer - their sum is the reference's own FLOP count of a frame -
